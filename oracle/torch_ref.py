@@ -1,0 +1,192 @@
+"""CPU fp32 restatement of the reference's hot-path module graph (TEST INFRASTRUCTURE ONLY).
+
+Plain ``torch.nn.functional`` calls on CPU tensors driven by a flat ``state_dict`` — the same
+arithmetic the reference delegates to ``torch.nn`` ("the CPU oracle is torch CPU
+kernels driven by the reference's module graph").  Every function cites the reference lines it
+follows.  It is pinned against the reference itself by ``oracle/gen_golden.py`` (fixtures under
+``tests/golden``); the reference has no tests/golden vectors of its own.
+
+Never imported by the product package.  Tolerance contract (BASELINE.json north_star):
+HIP fp32 path within 1e-3 relative of this oracle, argmax masks identical.
+"""
+import torch
+import torch.nn.functional as F
+
+
+class OracleNet:
+    """Functional model over a flat state_dict.
+
+    sd        : dict name -> CPU tensor (parameters may require grad for train-mode oracles)
+    training  : BN uses batch statistics and updates running stats (in ``sd``, in place)
+    eps_encoder / eps_decoder : what segmentron/solver/optimizer.py:18-30 setattr's on every
+                BatchNorm2d after construction (cfg.MODEL.BN_EPS_FOR_ENCODER / _DECODER);
+                None -> torch default 1e-5.
+    momentum  : cfg.MODEL.BN_MOMENTUM or torch default 0.1.
+    drop_p    : ASPP Dropout2d / FCN-head Dropout probability (0 for parity runs).
+    """
+
+    def __init__(self, sd, training=False, eps_encoder=None, eps_decoder=None, momentum=None,
+                 drop_p=0.1, output_stride=16, aux=False, nclass=19):
+        self.sd = sd
+        self.training = training
+        self.eps_encoder = 1e-5 if eps_encoder is None else eps_encoder
+        self.eps_decoder = 1e-5 if eps_decoder is None else eps_decoder
+        self.momentum = 0.1 if momentum is None else momentum
+        self.drop_p = drop_p
+        self.output_stride = output_stride
+        self.aux = aux
+        self.nclass = nclass
+
+    # ------------------------------------------------------------------ primitives
+    def _eps(self, prefix):
+        return self.eps_encoder if prefix.startswith("encoder.") else self.eps_decoder
+
+    def bn(self, x, prefix):
+        """nn.BatchNorm2d forward: train = biased batch var for
+        normalisation, unbiased for running_var; eval = running stats."""
+        sd = self.sd
+        if self.training:
+            sd[prefix + ".num_batches_tracked"] += 1
+        return F.batch_norm(x, sd[prefix + ".running_mean"], sd[prefix + ".running_var"],
+                            sd[prefix + ".weight"], sd[prefix + ".bias"], self.training,
+                            self.momentum, self._eps(prefix))
+
+    def conv(self, x, prefix, stride=1, padding=0, dilation=1, groups=1):
+        return F.conv2d(x, self.sd[prefix + ".weight"], self.sd.get(prefix + ".bias"),
+                        stride, padding, dilation, groups)
+
+    # ------------------------------------------------------------------ blocks
+    def separable_conv(self, x, prefix, stride=1, dilation=1, relu_first=True):
+        """SeparableConv2d — segmentron/modules/basic.py:34-62.
+        relu_first: ReLU(non-inplace) -> dw3x3 -> BN -> pw1x1 -> BN
+        else      : dw3x3 -> BN -> ReLU -> pw1x1 -> BN -> ReLU
+        depthwise padding = dilation (basic.py:38-40)."""
+        p = prefix + ".block."
+        c = x.shape[1]
+        if relu_first:
+            x = F.relu(x)
+            x = self.conv(x, p + "depthwise", stride, dilation, dilation, groups=c)
+            x = self.bn(x, p + "bn_depth")
+            x = self.conv(x, p + "pointwise")
+            x = self.bn(x, p + "bn_point")
+        else:
+            x = self.conv(x, p + "depthwise", stride, dilation, dilation, groups=c)
+            x = F.relu(self.bn(x, p + "bn_depth"))
+            x = self.conv(x, p + "pointwise")
+            x = F.relu(self.bn(x, p + "bn_point"))
+        return x
+
+    def conv_bn_relu(self, x, prefix, stride=1, padding=0, dilation=1, groups=1, relu6=False):
+        """_ConvBNReLU — segmentron/modules/basic.py:65-77."""
+        x = self.bn(self.conv(x, prefix + ".conv", stride, padding, dilation, groups),
+                    prefix + ".bn")
+        return F.relu6(x) if relu6 else F.relu(x)
+
+    def xception_block(self, x, prefix, stride=1, dilation=1, skip="conv", relu_first=True,
+                       low_feat=False):
+        """XceptionBlock — segmentron/models/backbones/xception.py:10-51."""
+        sc1 = self.separable_conv(x, prefix + ".sep_conv1", 1, dilation, relu_first)
+        sc2 = self.separable_conv(sc1, prefix + ".sep_conv2", 1, dilation, relu_first)
+        res = self.separable_conv(sc2, prefix + ".sep_conv3", stride, dilation, relu_first)
+        if skip == "conv":
+            short = self.bn(self.conv(x, prefix + ".conv", stride), prefix + ".bn")
+            out = res + short
+        elif skip == "sum":
+            out = res + x
+        else:
+            out = res
+        return (out, sc2) if low_feat else out
+
+    def xception65(self, x, prefix="encoder"):
+        """Xception65 — segmentron/models/backbones/xception.py:54-165."""
+        os_ = self.output_stride
+        if os_ == 32:
+            b3s, mid_d, exit_d, exit_s = 2, 1, (1, 1), 2
+        elif os_ == 16:
+            b3s, mid_d, exit_d, exit_s = 2, 1, (1, 2), 1
+        elif os_ == 8:
+            b3s, mid_d, exit_d, exit_s = 1, 2, (2, 4), 1
+        else:
+            raise NotImplementedError
+        p = prefix + "."
+        x = F.relu(self.bn(self.conv(x, p + "conv1", 2, 1), p + "bn1"))
+        x = F.relu(self.bn(self.conv(x, p + "conv2", 1, 1), p + "bn2"))
+        x = self.xception_block(x, p + "block1", stride=2)
+        x, c1 = self.xception_block(x, p + "block2", stride=2, low_feat=True)
+        x, c2 = self.xception_block(x, p + "block3", stride=b3s, low_feat=True)
+        for i in range(4, 20):
+            x = self.xception_block(x, p + "block%d" % i, dilation=mid_d, skip="sum")
+        c3 = x
+        x = self.xception_block(c3, p + "block20", stride=exit_s, dilation=exit_d[0])
+        c4 = self.xception_block(x, p + "block21", dilation=exit_d[1], skip="none",
+                                 relu_first=False)
+        return c1, c2, c3, c4
+
+    def aspp(self, x, prefix="head.aspp"):
+        """_ASPP — segmentron/modules/module.py:32-77."""
+        os_ = self.output_stride
+        if os_ in (16, 32):
+            dil = (6, 12, 18)
+        elif os_ == 8:
+            dil = (12, 24, 36)
+        else:
+            raise NotImplementedError
+        p = prefix + "."
+        pool = F.adaptive_avg_pool2d(x, 1)
+        pool = F.relu(self.bn(self.conv(pool, p + "image_pooling.conv"), p + "image_pooling.bn"))
+        pool = F.interpolate(pool, size=x.shape[2:], mode="bilinear", align_corners=True)
+        x0 = F.relu(self.bn(self.conv(x, p + "aspp0.conv"), p + "aspp0.bn"))
+        x1 = self.separable_conv(x, p + "aspp1", 1, dil[0], relu_first=False)
+        x2 = self.separable_conv(x, p + "aspp2", 1, dil[1], relu_first=False)
+        x3 = self.separable_conv(x, p + "aspp3", 1, dil[2], relu_first=False)
+        x = torch.cat((pool, x0, x1, x2, x3), dim=1)
+        x = F.relu(self.bn(self.conv(x, p + "conv"), p + "bn"))
+        return F.dropout2d(x, self.drop_p, self.training)
+
+    def fcn_head(self, x, prefix):
+        """_FCNHead — segmentron/modules/module.py:13-26."""
+        p = prefix + ".block."
+        x = F.relu(self.bn(self.conv(x, p + "0", 1, 1), p + "1"))
+        x = F.dropout(x, self.drop_p, self.training)
+        return self.conv(x, p + "4")
+
+    def deeplab_head(self, c4, c1, prefix="head"):
+        """_DeepLabHead — segmentron/models/deeplabv3_plus.py:49-75 (USE_ASPP, ENABLE_DECODER)."""
+        p = prefix + "."
+        x = self.aspp(c4, p + "aspp")
+        x = F.interpolate(x, c1.shape[2:], mode="bilinear", align_corners=True)
+        c1 = self.conv_bn_relu(c1, p + "c1_block")
+        x = torch.cat([x, c1], dim=1)
+        x = self.separable_conv(x, p + "block.0", relu_first=False)
+        x = self.separable_conv(x, p + "block.1", relu_first=False)
+        return self.conv(x, p + "block.2")
+
+    def deeplabv3_plus_xception65(self, x):
+        """DeepLabV3Plus.forward — segmentron/models/deeplabv3_plus.py:33-46."""
+        size = x.shape[2:]
+        c1, _, c3, c4 = self.xception65(x)
+        out = self.deeplab_head(c4, c1)
+        outs = [F.interpolate(out, size, mode="bilinear", align_corners=True)]
+        if self.aux:
+            a = self.fcn_head(c3, "auxlayer")
+            outs.append(F.interpolate(a, size, mode="bilinear", align_corners=True))
+        return tuple(outs)
+
+
+def mix_softmax_ce(outputs, target, aux_weight=0.4, ignore_index=-1):
+    """MixSoftmaxCrossEntropyLoss — segmentron/solver/loss.py:16-46 (sum of per-output CE,
+    aux outputs weighted by cfg.SOLVER.AUX_WEIGHT)."""
+    loss = F.cross_entropy(outputs[0], target, ignore_index=ignore_index)
+    for o in outputs[1:]:
+        loss = loss + aux_weight * F.cross_entropy(o, target, ignore_index=ignore_index)
+    return loss
+
+
+def clone_state(sd, requires_grad=False):
+    out = {}
+    for k, v in sd.items():
+        t = v.detach().clone()
+        if requires_grad and t.is_floating_point() and "running_" not in k:
+            t.requires_grad_(True)
+        out[k] = t
+    return out
