@@ -1,0 +1,136 @@
+/* segmentron_hip.h — C ABI of libsegmentron_hip.so (gfx950 / MI355X).
+ *
+ * Drop-in boundary for SegmenTron's dense-convolution hot path.  The reference has NO native
+ * boundary for this path: all arithmetic is delegated to torch.nn / torch.nn.functional
+ * (ATen -> MIOpen/oneDNN), see SURVEY.md §1 "Op layer" and §8(b).  Each entry point below is what
+ * a binding for the corresponding reference call site would call instead of the ATen op; the
+ * reference-side binding (ctypes stub) is shown in INTEGRATION.md.  The reference's only native
+ * code (segmentron/modules/csrc/vision.cpp:6-11, CCNet criss-cross attention) is out of scope.
+ *
+ * Conventions
+ *   - plain pointers + sizes, no torch types; every pointer is DEVICE memory unless noted
+ *   - activations are NHWC: element (n,h,w,c) of a tensor with row pitch `ld` (elements) lives at
+ *     base + ((n*H + h)*W + w)*ld + c ; `ld >= C` lets an op read/write a channel slice of a wider
+ *     (concatenation) buffer.  C and ld must be multiples of 16 bytes / sizeof(element).
+ *   - dtype: 0 = float32, 1 = bfloat16 (element type of activations / packed weights);
+ *     BatchNorm parameters, statistics and all accumulation are float32 / float64
+ *   - pro_mode ("prologue"): the producer's BatchNorm(+ReLU) applied on the fly to an input:
+ *     0 none, 1 relu(x), 2 x*scale[c]+shift[c], 3 relu(x*scale[c]+shift[c])
+ *   - `stream` is a hipStream_t; all launches are asynchronous on it; no host synchronisation,
+ *     no allocation, no global mutable state (re-entrant, graph-capturable)
+ *   - return value 0 = ok; otherwise seg_last_error() (thread-local) describes the failure.
+ *     Never aborts.
+ */
+#ifndef SEGMENTRON_HIP_H
+#define SEGMENTRON_HIP_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* seg_last_error(void);
+int seg_version(void);
+
+/* ---- nn.Conv2d, groups=1 (1x1 any stride, dense KxK): implicit GEMM on MFMA ----------------
+ * Replaces F.conv2d for segmentron/modules/basic.py:42,69; segmentron/modules/module.py:45,57;
+ * segmentron/models/backbones/xception.py:21,77,81; segmentron/models/deeplabv3_plus.py:64.
+ * y[n,ho,wo,o] = bias[o] + sum_{kh,kw,c} act(x[n,ho*stride-pad+kh*dil, wo*stride-pad+kw*dil, c])
+ *                                        * w[o][(kh*KW+kw)*C + c]
+ * w is packed [O][KH*KW*C] in `dtype`.  stat_partial (nullable): [seg_conv_gemm_tiles_m][2][O]
+ * fp32 per-tile (sum, sum of squares) of the pre-bias fp32 results, for the following BatchNorm.
+ * out_s != 1 scatters output pixel (n,ho,wo) to row ((n*out_H + ho*out_s)*out_W + wo*out_s)
+ * (data-gradient of a strided 1x1 conv; the caller zero-fills y first).
+ * The same entry point computes data gradients: pass dy as x and the transposed/flipped weights. */
+int seg_conv_gemm_fwd(int dtype, const void* x, long ldx, int N, int Hi, int Wi, int C,
+                      const void* w, int O, int KH, int KW, int stride, int pad, int dil,
+                      int pro_mode, const float* pro_scale, const float* pro_shift,
+                      const float* bias, void* y, long ldy, int Ho, int Wo, int out_H, int out_W,
+                      int out_s, float* stat_partial, void* stream);
+int seg_conv_gemm_tiles_m(int N, int Ho, int Wo);
+
+/* Weight gradient of the same convolution (autograd's conv2d backward wrt weight):
+ * partial[s][o][k] for s < splits (fp32); sum over s with seg_colsum gives dW[O][KH*KW*C].
+ * The forward prologue is re-applied to x (the activated input is never stored). */
+int seg_conv_gemm_wgrad(int dtype, const void* x, long ldx, int N, int Hi, int Wi, int C,
+                        const void* dy, long lddy, int Ho, int Wo, int O, int KH, int KW,
+                        int stride, int pad, int dil, int pro_mode, const float* pro_scale,
+                        const float* pro_shift, float* partial, int splits, void* stream);
+int seg_conv_gemm_wgrad_splits(int dtype, int N, int Ho, int Wo, int O, int K);
+
+/* ---- nn.Conv2d, groups=C, 3x3, padding=dilation (depthwise) --------------------------------
+ * Replaces segmentron/modules/basic.py:38-40 (SeparableConv2d.depthwise), :152-153.
+ * w9c: fp32 [9][C] (tap-major).  mode 0: forward (x -> y).  mode 1: data gradient
+ * (x = dy with geometry N,Hi,Wi; y = dx with geometry Ho,Wo; same w9c, stride, dil).
+ * stat_partial (forward only, nullable): [grid_y][2][C].  grid_y from seg_dwconv_grid_y. */
+int seg_dwconv3x3(int dtype, int mode, const void* x, long ldx, int N, int Hi, int Wi, int C,
+                  const float* w9c, int stride, int dil, int pro_mode, const float* pro_scale,
+                  const float* pro_shift, void* y, long ldy, int Ho, int Wo, float* stat_partial,
+                  int grid_y, void* stream);
+int seg_dwconv_grid_y(int dtype, int C, int N, int Ho, int Wo);
+/* partial: fp32 [grid_y][9][C]; column-sum gives dW[9][C]. */
+int seg_dwconv3x3_wgrad(int dtype, const void* x, long ldx, int N, int Hi, int Wi, int C,
+                        const void* dy, long lddy, int Ho, int Wo, int stride, int dil,
+                        int pro_mode, const float* pro_scale, const float* pro_shift,
+                        float* partial, int grid_y, void* stream);
+
+/* ---- nn.BatchNorm2d / nn.SyncBatchNorm (train + eval, forward + backward) -------------------
+ * Replaces F.batch_norm behind every `bn*` module (segmentron/modules/basic.py:41,43,70;
+ * segmentron/modules/module.py:46,54,58; xception.py:22,78,82) and torch's SyncBatchNorm
+ * collectives (tools/train.py:76): the caller all-reduces the 2C doubles between seg_colsum
+ * and the finalize call.  eps / momentum are read at call time. */
+/* out[l] = sum_r in[r][l]  (in: fp32 [R][L]); ws: >= 64*L doubles (needed when R > 128). */
+int seg_colsum(const float* in, long R, int L, double* out_d, float* out_f, double* ws,
+               void* stream);
+/* sums = [sum x (C), sum x^2 (C)] over `count` samples.  Writes mean, invstd (biased var),
+ * scale = gamma*invstd, shift = beta - mean*scale; updates running stats (nullable) with the
+ * unbiased variance and `momentum`. */
+int seg_bn_finalize(const double* sums, double count, const float* gamma, const float* beta,
+                    float eps, float momentum, float* running_mean, float* running_var,
+                    float* mean, float* invstd, float* scale, float* shift, int C, void* stream);
+/* eval mode: scale/shift from running statistics. */
+int seg_bn_eval_affine(const float* gamma, const float* beta, const float* rm, const float* rv,
+                       float eps, float* scale, float* shift, int C, void* stream);
+/* Materialise: y = post_relu?( act_x(x) * chan_mul[n][c] + act_r(r) )  (r, chan_mul nullable).
+ * Covers BN+ReLU materialisation, the residual adds of xception.py:40,42 / resnet.py:38,78 and
+ * nn.Dropout2d (segmentron/modules/module.py:60; chan_mul = mask/(1-p), rows_per_n = H*W). */
+int seg_bn_apply(int dtype, const void* x, long ldx, int mode_x, const float* sx, const float* tx,
+                 const void* r, long ldr, int mode_r, const float* sr, const float* tr,
+                 const float* chan_mul, long rows_per_n, int post_relu, void* y, long ldy, long M,
+                 int C, void* stream);
+/* Backward of "act(x) consumed with gradient g": g' = g * chan_mul * relu_mask.
+ * reduce  : partial[grid_y][2][C] = (sum g', sum g'*x) per block
+ * finalize: dgamma, dbeta and the coefficients c0,c1 of  dx = scale*g' - c0 - c1*x
+ * apply   : dx (may alias g).  With mode lacking the affine bit: dx = g' (ReLU backward). */
+int seg_bn_bwd_grid_y(int dtype, int C, long M);
+int seg_bn_bwd_reduce(int dtype, const void* g, long ldg, const void* x, long ldx, int mode,
+                      const float* scale, const float* shift, const float* chan_mul,
+                      long rows_per_n, long M, int C, float* partial, int grid_y, void* stream);
+int seg_bn_bwd_finalize(const double* sums, double count, const float* mean, const float* invstd,
+                        const float* gamma, float* dgamma, float* dbeta, float* c0, float* c1,
+                        int C, void* stream);
+int seg_bn_bwd_apply(int dtype, const void* g, long ldg, const void* x, long ldx, int mode,
+                     const float* scale, const float* shift, const float* c0, const float* c1,
+                     const float* chan_mul, long rows_per_n, void* dx, long lddx, long M, int C,
+                     void* stream);
+
+/* ---- F.interpolate(mode='bilinear') ---------------------------------------------------------
+ * Replaces segmentron/models/deeplabv3_plus.py:39,44,71; segmentron/modules/module.py:64,96;
+ * segmentron/models/segbase.py:83.  NHWC -> NHWC with optional prologue and per-(n,c) multiplier. */
+int seg_bilinear_fwd(int dtype, const void* x, long ldx, int N, int Hi, int Wi, int C,
+                     int pro_mode, const float* pro_scale, const float* pro_shift,
+                     const float* chan_mul, void* y, long ldy, int Ho, int Wo, int align_corners,
+                     void* stream);
+int seg_bilinear_bwd(int dtype, void* gx, long ldgx, int N, int Hi, int Wi, int C, const void* gy,
+                     long ldgy, int Ho, int Wo, int align_corners, void* stream);
+/* Model boundary: NHWC logits (C valid channels, pitch ldx) -> NCHW float32 [N,C,Ho,Wo] and back. */
+int seg_upsample_to_nchw(int dtype, const void* x, long ldx, int N, int Hi, int Wi, int C,
+                         float* out, int Ho, int Wo, int align_corners, void* stream);
+int seg_upsample_to_nchw_bwd(int dtype, void* gx, long ldgx, int N, int Hi, int Wi, int C,
+                             const float* gy, int Ho, int Wo, int align_corners, void* stream);
+/* Input boundary: NCHW float32 image [N,Cin,H,W] -> NHWC [N,H,W,16/sizeof(elem)] zero-padded. */
+int seg_nchw_to_nhwc_pad(int dtype, const float* x, int N, int Cin, int H, int W, void* y,
+                         void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEGMENTRON_HIP_H */

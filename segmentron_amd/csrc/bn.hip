@@ -1,0 +1,430 @@
+// BatchNorm2d (train / eval / sync) as a set of small bandwidth-bound kernels around the fused
+// conv kernels.  Replaces nn.BatchNorm2d / nn.SyncBatchNorm forward + backward
+// (reference call sites: every `bn*` module of segmentron/modules/basic.py:34-77,
+// segmentron/modules/module.py:32-77, segmentron/models/backbones/xception.py:10-165;
+// semantics: SURVEY.md Appendix B).
+//
+// Forward (train):  conv epilogues emit per-tile (sum, sumsq) partials  ->  seg_colsum (fp64)
+//                   -> [RCCL all-reduce of 2C doubles when SyncBN]  -> seg_bn_finalize
+//                   -> (mean, invstd, scale = gamma*invstd, shift = beta - mean*scale), running
+//                   stats updated with the UNBIASED variance, exactly as torch does.
+//                   The normalisation itself is applied inside the CONSUMER kernels' prologue.
+// Backward:         g' = g * relu_mask ;  seg_bn_bwd_reduce -> (sum g', sum g'*x) partials
+//                   -> seg_colsum -> [all-reduce] -> seg_bn_bwd_finalize -> (dgamma, dbeta, c0, c1)
+//                   -> seg_bn_bwd_apply:  dx = scale*g' - c0 - c1*x
+// Wavefront (64-lane) layout: lanes run along 16-byte channel vectors of NHWC rows.
+#include "common.h"
+
+namespace seg {
+
+constexpr int EW_THREADS = 256;
+
+// ------------------------------------------------------------------ column sums of partials
+// in [R][L] fp32 -> out[gridDim.y][L] (fp64 or fp32)
+template <typename TOUT>
+__global__ __launch_bounds__(EW_THREADS) void colsum_kernel(const float* __restrict__ in, long R,
+                                                            int L, TOUT* __restrict__ out) {
+  __shared__ double red[8][33];
+  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+  const int col = blockIdx.x * 32 + cx;
+  const long rows_per = (R + gridDim.y - 1) / gridDim.y;
+  const long r0 = (long)blockIdx.y * rows_per;
+  const long r1 = min(R, r0 + rows_per);
+  double acc = 0.0;
+  if (col < L) {
+    for (long r = r0 + ry; r < r1; r += 8) acc += (double)in[r * L + col];
+  }
+  red[ry][cx] = acc;
+  __syncthreads();
+  if (ry == 0 && col < L) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += red[k][cx];
+    out[(long)blockIdx.y * L + col] = (TOUT)t;
+  }
+}
+
+__global__ __launch_bounds__(EW_THREADS) void colsum_f64_kernel(const double* __restrict__ in,
+                                                                int R, int L, double* out_d,
+                                                                float* out_f) {
+  const int col = blockIdx.x * EW_THREADS + threadIdx.x;
+  if (col >= L) return;
+  double t = 0.0;
+  for (int r = 0; r < R; ++r) t += in[(long)r * L + col];
+  if (out_d) out_d[col] = t;
+  if (out_f) out_f[col] = (float)t;
+}
+
+// ------------------------------------------------------------------ finalize (forward)
+__global__ void bn_finalize_kernel(const double* __restrict__ sums, double count,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float eps, float momentum, float* running_mean,
+                                   float* running_var, float* mean_o, float* invstd_o,
+                                   float* scale_o, float* shift_o, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double mean = sums[c] / count;
+  double var = sums[C + c] / count - mean * mean;  // biased
+  if (var < 0.0) var = 0.0;
+  const double invstd = 1.0 / sqrt(var + (double)eps);
+  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  mean_o[c] = (float)mean;
+  invstd_o[c] = (float)invstd;
+  const float sc = (float)((double)g * invstd);
+  scale_o[c] = sc;
+  shift_o[c] = (float)((double)b - mean * (double)g * invstd);
+  if (running_mean) {
+    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+    running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * mean);
+    running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unbiased);
+  }
+}
+
+__global__ void bn_eval_affine_kernel(const float* __restrict__ gamma,
+                                      const float* __restrict__ beta,
+                                      const float* __restrict__ rm, const float* __restrict__ rv,
+                                      float eps, float* scale_o, float* shift_o, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  const float invstd = 1.0f / sqrtf(rv[c] + eps);
+  scale_o[c] = g * invstd;
+  shift_o[c] = b - rm[c] * g * invstd;
+}
+
+// ------------------------------------------------------------------ apply (+ residual)
+struct ApplyArgs {
+  const void* x; const void* r; void* y;
+  const float* sx; const float* tx; const float* sr; const float* tr;
+  const float* chan_mul;  // optional [N][C] multiplier (Dropout2d mask * 1/(1-p)); rows_per_n rows each
+  long ldx, ldr, ldy;
+  long M; int C, CV;
+  int mode_x, mode_r, post_relu;
+  long rows_per_n;
+};
+
+template <typename T>
+__global__ __launch_bounds__(EW_THREADS) void bn_apply_kernel(const ApplyArgs a) {
+  constexpr int VEC = Vec<T>::N;
+  const T* __restrict__ X = reinterpret_cast<const T*>(a.x);
+  const T* __restrict__ R = reinterpret_cast<const T*>(a.r);
+  T* __restrict__ Y = reinterpret_cast<T*>(a.y);
+  const long total = a.M * a.CV;
+  for (long i = (long)blockIdx.x * EW_THREADS + threadIdx.x; i < total;
+       i += (long)gridDim.x * EW_THREADS) {
+    const long row = i / a.CV;
+    const int c0 = (int)(i - row * a.CV) * VEC;
+    float f[VEC];
+    Vec<T>::unpack(ldg16(X + row * a.ldx + c0), f);
+    apply_prologue<VEC>(f, a.mode_x, a.sx, a.tx, c0);
+    if (a.chan_mul) {
+      const float* m = a.chan_mul + (row / a.rows_per_n) * a.C + c0;
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) f[k] *= m[k];
+    }
+    if (R) {
+      float g[VEC];
+      Vec<T>::unpack(ldg16(R + row * a.ldr + c0), g);
+      apply_prologue<VEC>(g, a.mode_r, a.sr, a.tr, c0);
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) f[k] += g[k];
+    }
+    if (a.post_relu) {
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) f[k] = fmaxf(f[k], 0.f);
+    }
+    stg16(Y + row * a.ldy + c0, Vec<T>::pack(f));
+  }
+}
+
+// ------------------------------------------------------------------ backward reduce
+struct BwdArgs {
+  const void* g; const void* x; void* dx;
+  const float* scale; const float* shift; const float* c0; const float* c1;
+  const float* chan_mul; long rows_per_n;
+  float* partial;  // [gridDim.y][2][C]
+  long ldg, ldx, lddx;
+  long M; int C, CV;
+  int mode;  // PRO_* of the forward prologue this is the backward of
+  int cvb_log2;
+};
+
+template <typename T>
+__device__ __forceinline__ void masked_grad(const BwdArgs& a, const T* G, const T* X, long row,
+                                            int c0, float* g, float* x) {
+  constexpr int VEC = Vec<T>::N;
+  Vec<T>::unpack(ldg16(G + row * a.ldg + c0), g);
+  Vec<T>::unpack(ldg16(X + row * a.ldx + c0), x);
+  if (a.chan_mul) {
+    const float* m = a.chan_mul + (row / a.rows_per_n) * a.C + c0;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) g[k] *= m[k];
+  }
+  if (a.mode & PRO_RELU) {
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      const float y = (a.mode & PRO_AFFINE) ? fmaf(x[k], a.scale[c0 + k], a.shift[c0 + k]) : x[k];
+      g[k] = y > 0.f ? g[k] : 0.f;
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(EW_THREADS) void bn_bwd_reduce_kernel(const BwdArgs a) {
+  constexpr int VEC = Vec<T>::N;
+  extern __shared__ __attribute__((aligned(16))) float bn_smem[];
+  const int tid = threadIdx.x;
+  const int cvb = 1 << a.cvb_log2;
+  const int cx = tid & (cvb - 1), sy = tid >> a.cvb_log2;
+  const int spb = EW_THREADS >> a.cvb_log2;
+  const int cv = blockIdx.x * cvb + cx;
+  const int c0 = cv * VEC;
+  const T* __restrict__ G = reinterpret_cast<const T*>(a.g);
+  const T* __restrict__ X = reinterpret_cast<const T*>(a.x);
+  float s1[VEC], s2[VEC];
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) s1[k] = s2[k] = 0.f;
+  if (cv < a.CV) {
+    for (long row = (long)blockIdx.y * spb + sy; row < a.M; row += (long)gridDim.y * spb) {
+      float g[VEC], x[VEC];
+      masked_grad<T>(a, G, X, row, c0, g, x);
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) {
+        s1[k] += g[k];
+        s2[k] = fmaf(g[k], x[k], s2[k]);
+      }
+    }
+  }
+  float* mine = bn_smem + ((long)sy * cvb + cx) * 2 * VEC;
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) {
+    mine[k] = s1[k];
+    mine[VEC + k] = s2[k];
+  }
+  __syncthreads();
+  for (int e = tid; e < cvb * 2 * VEC; e += EW_THREADS) {
+    float tot = 0.f;
+    for (int r = 0; r < spb; ++r) tot += bn_smem[(long)r * cvb * 2 * VEC + e];
+    const int lcx = e / (2 * VEC), k = e % (2 * VEC);
+    const int which = k / VEC, ci = k % VEC;
+    const int c = (blockIdx.x * cvb + lcx) * VEC + ci;
+    if (c < a.C) a.partial[((long)blockIdx.y * 2 + which) * a.C + c] = tot;
+  }
+}
+
+__global__ void bn_bwd_finalize_kernel(const double* __restrict__ sums, double count,
+                                       const float* __restrict__ mean,
+                                       const float* __restrict__ invstd,
+                                       const float* __restrict__ gamma, float* dgamma,
+                                       float* dbeta, float* c0_o, float* c1_o, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double sg = sums[c], sgx = sums[C + c];
+  const double mu = mean[c], is = invstd[c];
+  const double dg = (sgx - mu * sg) * is;  // sum g' * xhat
+  const double g = gamma ? (double)gamma[c] : 1.0;
+  const double s = g * is;
+  const double m1 = sg / count, m2 = dg / count;
+  const double c1 = s * m2 * is;
+  if (dgamma) dgamma[c] = (float)dg;
+  if (dbeta) dbeta[c] = (float)sg;
+  c1_o[c] = (float)c1;
+  c0_o[c] = (float)(s * m1 - c1 * mu);
+}
+
+template <typename T>
+__global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_kernel(const BwdArgs a) {
+  constexpr int VEC = Vec<T>::N;
+  const T* __restrict__ G = reinterpret_cast<const T*>(a.g);
+  const T* __restrict__ X = reinterpret_cast<const T*>(a.x);
+  T* __restrict__ DX = reinterpret_cast<T*>(a.dx);
+  const long total = a.M * a.CV;
+  for (long i = (long)blockIdx.x * EW_THREADS + threadIdx.x; i < total;
+       i += (long)gridDim.x * EW_THREADS) {
+    const long row = i / a.CV;
+    const int c0 = (int)(i - row * a.CV) * VEC;
+    float g[VEC], x[VEC];
+    masked_grad<T>(a, G, X, row, c0, g, x);
+    if (a.mode & PRO_AFFINE) {
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) {
+        g[k] *= a.scale[c0 + k];
+        if (a.c0) g[k] = g[k] - a.c0[c0 + k] - a.c1[c0 + k] * x[k];
+      }
+    }
+    stg16(DX + row * a.lddx + c0, Vec<T>::pack(g));
+  }
+}
+
+static int pick_cvb_log2_ew(int CV) {
+  int best = 5;
+  double bu = 0;
+  for (int l = 5; l >= 3; --l) {
+    const int b = 1 << l;
+    const double u = (double)CV / (double)(((CV + b - 1) / b) * b);
+    if (u > bu + 1e-9) { bu = u; best = l; }
+  }
+  return best;
+}
+
+static int ew_grid(long total_vec) {
+  long g = (total_vec + EW_THREADS - 1) / EW_THREADS;
+  if (g > 4096) g = 4096;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+}  // namespace seg
+
+// out = column sums of in[R][L]; ws must hold >= 64*L doubles.  Exactly one of out_d/out_f may be
+// null.  Two-level when R is large.
+extern "C" int seg_colsum(const float* in, long R, int L, double* out_d, float* out_f, double* ws,
+                          void* stream) {
+  using namespace seg;
+  SEG_REQUIRE(R >= 1 && L >= 1, "colsum: empty");
+  SEG_REQUIRE(out_d || out_f, "colsum: no output");
+  hipStream_t st = (hipStream_t)stream;
+  int gy = (int)((R + 127) / 128);
+  if (gy > 64) gy = 64;
+  const dim3 grid((L + 31) / 32, gy);
+  if (gy == 1) {
+    if (out_d)
+      hipLaunchKernelGGL((colsum_kernel<double>), grid, dim3(EW_THREADS), 0, st, in, R, L, out_d);
+    if (out_f)
+      hipLaunchKernelGGL((colsum_kernel<float>), grid, dim3(EW_THREADS), 0, st, in, R, L, out_f);
+    return check_launch("colsum");
+  }
+  SEG_REQUIRE(ws != nullptr, "colsum: workspace required for R=%ld", R);
+  hipLaunchKernelGGL((colsum_kernel<double>), grid, dim3(EW_THREADS), 0, st, in, R, L, ws);
+  hipLaunchKernelGGL(colsum_f64_kernel, dim3((L + EW_THREADS - 1) / EW_THREADS), dim3(EW_THREADS),
+                     0, st, ws, gy, L, out_d, out_f);
+  return check_launch("colsum");
+}
+
+extern "C" int seg_bn_finalize(const double* sums, double count, const float* gamma,
+                               const float* beta, float eps, float momentum, float* running_mean,
+                               float* running_var, float* mean, float* invstd, float* scale,
+                               float* shift, int C, void* stream) {
+  using namespace seg;
+  SEG_REQUIRE(count >= 1.0 && C >= 1, "bn_finalize: bad count/C");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                     sums, count, gamma, beta, eps, momentum, running_mean, running_var, mean,
+                     invstd, scale, shift, C);
+  return check_launch("bn_finalize");
+}
+
+extern "C" int seg_bn_eval_affine(const float* gamma, const float* beta, const float* rm,
+                                  const float* rv, float eps, float* scale, float* shift, int C,
+                                  void* stream) {
+  using namespace seg;
+  hipLaunchKernelGGL(bn_eval_affine_kernel, dim3((C + 255) / 256), dim3(256), 0,
+                     (hipStream_t)stream, gamma, beta, rm, rv, eps, scale, shift, C);
+  return check_launch("bn_eval_affine");
+}
+
+// y = post_relu?( act_x(x) * chan_mul + act_r(r) )
+extern "C" int seg_bn_apply(int dtype, const void* x, long ldx, int mode_x, const float* sx,
+                            const float* tx, const void* r, long ldr, int mode_r, const float* sr,
+                            const float* tr, const float* chan_mul, long rows_per_n, int post_relu,
+                            void* y, long ldy, long M, int C, void* stream) {
+  using namespace seg;
+  const int vec = dtype == DT_BF16 ? 8 : 4;
+  SEG_REQUIRE(dtype == DT_F32 || dtype == DT_BF16, "bn_apply: bad dtype %d", dtype);
+  SEG_REQUIRE(C % vec == 0 && ldx % vec == 0 && ldy % vec == 0 && (r == nullptr || ldr % vec == 0),
+              "bn_apply: C/ld must be multiples of %d", vec);
+  SEG_REQUIRE(((mode_x & PRO_AFFINE) == 0) || (sx && tx), "bn_apply: missing scale/shift (x)");
+  SEG_REQUIRE(r == nullptr || ((mode_r & PRO_AFFINE) == 0) || (sr && tr),
+              "bn_apply: missing scale/shift (r)");
+  ApplyArgs a;
+  a.x = x; a.r = r; a.y = y; a.sx = sx; a.tx = tx; a.sr = sr; a.tr = tr; a.chan_mul = chan_mul;
+  a.ldx = ldx; a.ldr = ldr; a.ldy = ldy; a.M = M; a.C = C; a.CV = C / vec;
+  a.mode_x = mode_x; a.mode_r = mode_r; a.post_relu = post_relu;
+  a.rows_per_n = rows_per_n > 0 ? rows_per_n : 1;
+  const int grid = ew_grid(M * a.CV);
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL((bn_apply_kernel<bf16_t>), dim3(grid), dim3(EW_THREADS), 0,
+                       (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL((bn_apply_kernel<float>), dim3(grid), dim3(EW_THREADS), 0,
+                       (hipStream_t)stream, a);
+  return check_launch("bn_apply");
+}
+
+extern "C" int seg_bn_bwd_grid_y(int dtype, int C, long M) {
+  using namespace seg;
+  const int vec = dtype == DT_BF16 ? 8 : 4;
+  const int CV = C / vec;
+  const int l = pick_cvb_log2_ew(CV);
+  const int spb = EW_THREADS >> l;
+  const int gx = (CV + (1 << l) - 1) >> l;
+  long gy = (M + (long)spb * 8 - 1) / ((long)spb * 8);  // >= 8 rows per thread
+  long cap = 2048 / gx;
+  if (cap < 1) cap = 1;
+  if (gy > cap) gy = cap;
+  if (gy < 1) gy = 1;
+  return (int)gy;
+}
+
+// partial[grid_y][2][C] = per-block (sum g', sum g'*x),  g' = g * chan_mul * relu_mask(mode)
+extern "C" int seg_bn_bwd_reduce(int dtype, const void* g, long ldg, const void* x, long ldx,
+                                 int mode, const float* scale, const float* shift,
+                                 const float* chan_mul, long rows_per_n, long M, int C,
+                                 float* partial, int grid_y, void* stream) {
+  using namespace seg;
+  const int vec = dtype == DT_BF16 ? 8 : 4;
+  SEG_REQUIRE(dtype == DT_F32 || dtype == DT_BF16, "bn_bwd_reduce: bad dtype %d", dtype);
+  SEG_REQUIRE(C % vec == 0 && ldg % vec == 0 && ldx % vec == 0,
+              "bn_bwd_reduce: C/ld must be multiples of %d", vec);
+  SEG_REQUIRE(grid_y >= 1, "bn_bwd_reduce: grid_y");
+  BwdArgs a;
+  a.g = g; a.x = x; a.dx = nullptr; a.scale = scale; a.shift = shift; a.c0 = nullptr; a.c1 = nullptr;
+  a.chan_mul = chan_mul; a.rows_per_n = rows_per_n > 0 ? rows_per_n : 1;
+  a.partial = partial; a.ldg = ldg; a.ldx = ldx; a.lddx = 0; a.M = M; a.C = C; a.CV = C / vec;
+  a.mode = mode; a.cvb_log2 = pick_cvb_log2_ew(a.CV);
+  const int gx = (a.CV + (1 << a.cvb_log2) - 1) >> a.cvb_log2;
+  const size_t lds = (size_t)EW_THREADS * 2 * vec * sizeof(float);
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16_t>), dim3(gx, grid_y), dim3(EW_THREADS), lds,
+                       (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<float>), dim3(gx, grid_y), dim3(EW_THREADS), lds,
+                       (hipStream_t)stream, a);
+  return check_launch("bn_bwd_reduce");
+}
+
+extern "C" int seg_bn_bwd_finalize(const double* sums, double count, const float* mean,
+                                   const float* invstd, const float* gamma, float* dgamma,
+                                   float* dbeta, float* c0, float* c1, int C, void* stream) {
+  using namespace seg;
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0,
+                     (hipStream_t)stream, sums, count, mean, invstd, gamma, dgamma, dbeta, c0, c1,
+                     C);
+  return check_launch("bn_bwd_finalize");
+}
+
+// dx = scale * g' - c0 - c1 * x   (mode has AFFINE);  dx = g'  (mode without AFFINE: plain ReLU
+// backward / dropout-mask backward).  c0/c1 null with AFFINE -> eval-mode BN backward (scale only).
+extern "C" int seg_bn_bwd_apply(int dtype, const void* g, long ldg, const void* x, long ldx,
+                                int mode, const float* scale, const float* shift, const float* c0,
+                                const float* c1, const float* chan_mul, long rows_per_n, void* dx,
+                                long lddx, long M, int C, void* stream) {
+  using namespace seg;
+  const int vec = dtype == DT_BF16 ? 8 : 4;
+  SEG_REQUIRE(dtype == DT_F32 || dtype == DT_BF16, "bn_bwd_apply: bad dtype %d", dtype);
+  SEG_REQUIRE(C % vec == 0 && ldg % vec == 0 && ldx % vec == 0 && lddx % vec == 0,
+              "bn_bwd_apply: C/ld must be multiples of %d", vec);
+  SEG_REQUIRE(((mode & PRO_AFFINE) == 0) || (scale && shift), "bn_bwd_apply: missing scale/shift");
+  BwdArgs a;
+  a.g = g; a.x = x; a.dx = dx; a.scale = scale; a.shift = shift; a.c0 = c0; a.c1 = c1;
+  a.chan_mul = chan_mul; a.rows_per_n = rows_per_n > 0 ? rows_per_n : 1;
+  a.partial = nullptr; a.ldg = ldg; a.ldx = ldx; a.lddx = lddx; a.M = M; a.C = C; a.CV = C / vec;
+  a.mode = mode; a.cvb_log2 = 0;
+  const int grid = ew_grid(M * a.CV);
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t>), dim3(grid), dim3(EW_THREADS), 0,
+                       (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<float>), dim3(grid), dim3(EW_THREADS), 0,
+                       (hipStream_t)stream, a);
+  return check_launch("bn_bwd_apply");
+}

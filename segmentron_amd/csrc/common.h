@@ -1,0 +1,111 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) kernels.
+// Activations are NHWC ("channels_last" memory), element type T in {float, bf16}; per-channel
+// BatchNorm parameters / statistics are always fp32; accumulation is always fp32.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace seg {
+
+typedef uint16_t bf16_t;  // raw bfloat16 storage
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+enum { DT_F32 = 0, DT_BF16 = 1 };
+// prologue applied to a conv / elementwise input:  v = x*scale[c] + shift[c]  (if AFFINE), then relu
+enum { PRO_NONE = 0, PRO_RELU = 1, PRO_AFFINE = 2, PRO_AFFINE_RELU = 3 };
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) {
+  return __uint_as_float(((uint32_t)v) << 16);
+}
+// round-to-nearest-even, finite inputs (NaN payloads are not preserved; not needed here)
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+  uint32_t u = __float_as_uint(f);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+
+// 16-byte vector view of T: VEC elements
+template <typename T> struct Vec;
+template <> struct Vec<float> {
+  static constexpr int N = 4;
+  __device__ static __forceinline__ void unpack(const uint4& v, float* f) {
+    f[0] = __uint_as_float(v.x); f[1] = __uint_as_float(v.y);
+    f[2] = __uint_as_float(v.z); f[3] = __uint_as_float(v.w);
+  }
+  __device__ static __forceinline__ uint4 pack(const float* f) {
+    return make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]),
+                      __float_as_uint(f[3]));
+  }
+  __device__ static __forceinline__ float load1(const float* p) { return *p; }
+  __device__ static __forceinline__ void store1(float* p, float v) { *p = v; }
+};
+template <> struct Vec<bf16_t> {
+  static constexpr int N = 8;
+  __device__ static __forceinline__ void unpack(const uint4& v, float* f) {
+    f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xFFFF0000u);
+    f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xFFFF0000u);
+    f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xFFFF0000u);
+    f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xFFFF0000u);
+  }
+  __device__ static __forceinline__ uint4 pack(const float* f) {
+    return make_uint4(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]), pack_bf16x2(f[4], f[5]),
+                      pack_bf16x2(f[6], f[7]));
+  }
+  __device__ static __forceinline__ float load1(const bf16_t* p) { return bf16_to_f32(*p); }
+  __device__ static __forceinline__ void store1(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+};
+
+__device__ __forceinline__ uint4 ldg16(const void* p) { return *reinterpret_cast<const uint4*>(p); }
+__device__ __forceinline__ void stg16(void* p, const uint4& v) { *reinterpret_cast<uint4*>(p) = v; }
+
+// Apply the fused-BatchNorm prologue to VEC consecutive channels starting at c.
+template <int N>
+__device__ __forceinline__ void apply_prologue(float* f, int mode, const float* __restrict__ scale,
+                                               const float* __restrict__ shift, int c) {
+  if (mode & PRO_AFFINE) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) f[i] = fmaf(f[i], scale[c + i], shift[c + i]);
+  }
+  if (mode & PRO_RELU) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) f[i] = fmaxf(f[i], 0.f);
+  }
+}
+
+// MI355X has 8 XCDs with private L2s and the dispatcher places block b on XCD b % 8
+// (speed-only assumption).  Remap so each XCD works on a contiguous range of logical tiles
+// (bijective for any block count).
+__device__ __forceinline__ int xcd_remap(int b, int nblk) {
+  const int q = nblk >> 3, r = nblk & 7;
+  const int xcd = b & 7, idx = b >> 3;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+}  // namespace seg
+
+// ---- host side error plumbing (C-ABI: int status + thread-local message) -------------------
+namespace seg {
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+}  // namespace seg
+
+#define SEG_REQUIRE(cond, ...)            \
+  do {                                    \
+    if (!(cond)) {                        \
+      seg::set_error(__VA_ARGS__);        \
+      return 1;                           \
+    }                                     \
+  } while (0)

@@ -1,0 +1,236 @@
+// Implicit-GEMM convolution, forward orientation (also used for dgrad with transposed weights):
+//   Y[p, o] = sum_{kh,kw,c} act(X[n, ho*s - pad + kh*d, wo*s - pad + kw*d, c]) * W[o, kh, kw, c]
+// with p = (n*Ho + ho)*Wo + wo, NHWC activations, packed weights [O][KH*KW*C] (k contiguous).
+// Replaces nn.Conv2d for 1x1 (any stride) and dense KxK convs — the reference call sites are
+// segmentron/modules/basic.py:42 (pointwise), :69 (_ConvBNReLU), segmentron/modules/module.py:45,57
+// (ASPP), segmentron/models/backbones/xception.py:21,81 (shortcut / conv2),
+// segmentron/models/deeplabv3_plus.py:64 (classifier).
+//
+// Fusions (the net is HBM-bound unless BN/ReLU ride along with the convs):
+//   prologue : the *producer's* BatchNorm (+ReLU) applied to X while staging it into LDS
+//              (scale/shift per input channel), zero padding applied after the activation
+//   epilogue : + bias; per-channel sum / sum-of-squares partials of the fp32 accumulators for
+//              the BatchNorm that follows (one row of partials per M-tile, reduced in fp64 by
+//              bn_finalize — deterministic, no atomics); output written into a channel slice
+//              of a wider buffer (ldy) so torch.cat never copies; optional strided row scatter
+//              (dgrad of a stride-2 1x1 conv).
+#include "conv_gemm.h"
+
+namespace seg {
+
+struct ConvGemmArgs {
+  const void* x;
+  const void* w;
+  void* y;
+  const float* pro_scale;
+  const float* pro_shift;
+  const float* bias;
+  float* stat_partial;  // [tiles_m][2][O] or null
+  long ldx, ldy;
+  int N, Hi, Wi, C, Ho, Wo, O;
+  int KH, KW, stride, pad, dil;
+  int pro_mode;
+  int M, K;
+  int out_H, out_W, out_s;  // output row scatter geometry (out_s == 1 -> dense rows)
+  int tiles_m, tiles_n;
+};
+
+template <typename T>
+__global__ __launch_bounds__(GEMM_THREADS) void conv_gemm_fwd_kernel(const ConvGemmArgs a) {
+  constexpr int VEC = Vec<T>::N;
+  constexpr int BK = ROW_BYTES / (int)sizeof(T);
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TILE_BYTES];
+  unsigned char* sA = smem;
+  unsigned char* sB = smem + TILE_BYTES;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int L = xcd_remap(blockIdx.x, a.tiles_m * a.tiles_n);
+  const int tile_m = L / a.tiles_n, tile_n = L - tile_m * a.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  // ---- staging assignment: thread -> vector column vc (16 B) of rows rb + 32*j
+  const int vc = tid & 7, rb = tid >> 3;
+  const T* __restrict__ X = reinterpret_cast<const T*>(a.x);
+  const T* __restrict__ W = reinterpret_cast<const T*>(a.w);
+
+  long a_base[4];
+  int a_hi0[4], a_wi0[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int p = m0 + rb + 32 * j;
+    if (p < a.M) {
+      const int wo = p % a.Wo;
+      const int t = p / a.Wo;
+      const int ho = t % a.Ho;
+      const int n = t / a.Ho;
+      a_base[j] = (long)n * a.Hi * a.Wi;
+      a_hi0[j] = ho * a.stride - a.pad;
+      a_wi0[j] = wo * a.stride - a.pad;
+    } else {
+      a_base[j] = 0;
+      a_hi0[j] = -(1 << 28);  // never in range
+      a_wi0[j] = -(1 << 28);
+    }
+  }
+  const bool single_tap = (a.KH * a.KW == 1);
+
+  uint4 ra[4], rbv[4];
+  unsigned a_ok_mask = 0;  // bit j: row j of the staged A slab is a real (in-bounds) pixel
+  int cur_c = 0;  // channel of this thread's A vector in the slab being staged
+  auto load_slab = [&](int kt) {
+    const int kv = kt * BK + vc * VEC;
+    int c = kv, dh = 0, dw = 0;
+    if (!single_tap) {
+      const int kidx = kv / a.C;
+      c = kv - kidx * a.C;
+      const int kh = kidx / a.KW;
+      dh = kh * a.dil;
+      dw = (kidx - kh * a.KW) * a.dil;
+    }
+    cur_c = c;
+    const bool kok = kv < a.K;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int hi = a_hi0[j] + dh, wi = a_wi0[j] + dw;
+      const bool ok = kok && hi >= 0 && hi < a.Hi && wi >= 0 && wi < a.Wi;
+      ra[j] = make_uint4(0, 0, 0, 0);
+      if (ok) ra[j] = ldg16(X + (a_base[j] + (long)hi * a.Wi + wi) * a.ldx + c);
+      a_ok_mask = ok ? (a_ok_mask | (1u << j)) : (a_ok_mask & ~(1u << j));
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int o = n0 + rb + 32 * j;
+      rbv[j] = make_uint4(0, 0, 0, 0);
+      if (kok && o < a.O) rbv[j] = ldg16(W + (long)o * a.K + kv);
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int nk = (a.K + BK - 1) / BK;
+  load_slab(0);
+  for (int kt = 0; kt < nk; ++kt) {
+    // registers -> LDS (fused BN/ReLU prologue on the activation operand; padding stays zero)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      uint4 v = ra[j];
+      if (a.pro_mode != PRO_NONE && ((a_ok_mask >> j) & 1u)) {
+        float f[VEC];
+        Vec<T>::unpack(v, f);
+        apply_prologue<VEC>(f, a.pro_mode, a.pro_scale, a.pro_shift, cur_c);
+        v = Vec<T>::pack(f);
+      }
+      *reinterpret_cast<uint4*>(sA + (rb + 32 * j) * ROW_STRIDE + vc * 16) = v;
+      *reinterpret_cast<uint4*>(sB + (rb + 32 * j) * ROW_STRIDE + vc * 16) = rbv[j];
+    }
+    __syncthreads();
+    if (kt + 1 < nk) load_slab(kt + 1);  // global loads in flight under the MFMAs
+    mma_slab<T>(sA, sB, wm, wn, lane, acc);
+    __syncthreads();
+  }
+
+  // ---- epilogue
+  const int col = lane & 31, hh = lane >> 5;
+  T* __restrict__ Y = reinterpret_cast<T*>(a.y);
+  float csum[2] = {0.f, 0.f}, csq[2] = {0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int o = n0 + wn * 64 + j * 32 + col;
+    const float bias = (a.bias != nullptr && o < a.O) ? a.bias[o] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int r = (e & 3) + 8 * (e >> 2) + 4 * hh;
+        const int p = m0 + wm * 64 + i * 32 + r;
+        const float v = acc[i][j][e] + bias;
+        csum[j] += acc[i][j][e];
+        csq[j] += acc[i][j][e] * acc[i][j][e];
+        if (p < a.M && o < a.O) {
+          long row = p;
+          if (a.out_s != 1) {
+            const int wo = p % a.Wo;
+            const int t = p / a.Wo;
+            const int ho = t % a.Ho;
+            const int n = t / a.Ho;
+            row = ((long)n * a.out_H + (long)ho * a.out_s) * a.out_W + (long)wo * a.out_s;
+          }
+          Vec<T>::store1(Y + row * a.ldy + o, v);
+        }
+      }
+    }
+  }
+  if (a.stat_partial != nullptr) {
+    // rows beyond M were staged as zeros (after the prologue), so they add nothing.
+    float* red = reinterpret_cast<float*>(smem);  // [2 wm][2][128]
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      float s = csum[j] + __shfl_xor(csum[j], 32, 64);
+      float q = csq[j] + __shfl_xor(csq[j], 32, 64);
+      if (hh == 0) {
+        const int cl = wn * 64 + j * 32 + col;
+        red[(wm * 2 + 0) * 128 + cl] = s;
+        red[(wm * 2 + 1) * 128 + cl] = q;
+      }
+    }
+    __syncthreads();
+    if (tid < 128) {
+      const int o = n0 + tid;
+      if (o < a.O) {
+        float* dst = a.stat_partial + (long)tile_m * 2 * a.O;
+        dst[o] = red[0 * 128 + tid] + red[2 * 128 + tid];
+        dst[a.O + o] = red[1 * 128 + tid] + red[3 * 128 + tid];
+      }
+    }
+  }
+}
+
+template <typename T>
+static int launch_conv_gemm_fwd(const ConvGemmArgs& a, hipStream_t stream) {
+  const int grid = a.tiles_m * a.tiles_n;
+  hipLaunchKernelGGL((conv_gemm_fwd_kernel<T>), dim3(grid), dim3(GEMM_THREADS), 0, stream, a);
+  return check_launch("conv_gemm_fwd");
+}
+
+}  // namespace seg
+
+extern "C" int seg_conv_gemm_fwd(int dtype, const void* x, long ldx, int N, int Hi, int Wi, int C,
+                                 const void* w, int O, int KH, int KW, int stride, int pad,
+                                 int dil, int pro_mode, const float* pro_scale,
+                                 const float* pro_shift, const float* bias, void* y, long ldy,
+                                 int Ho, int Wo, int out_H, int out_W, int out_s,
+                                 float* stat_partial, void* stream) {
+  using namespace seg;
+  const int vec = dtype == DT_BF16 ? 8 : 4;
+  SEG_REQUIRE(dtype == DT_F32 || dtype == DT_BF16, "conv_gemm_fwd: bad dtype %d", dtype);
+  SEG_REQUIRE(C % vec == 0 && ldx % vec == 0,
+              "conv_gemm_fwd: C=%d / ldx=%ld must be multiples of %d", C, ldx, vec);
+  SEG_REQUIRE(N > 0 && Ho > 0 && Wo > 0 && O > 0, "conv_gemm_fwd: empty problem");
+  SEG_REQUIRE(((pro_mode & PRO_AFFINE) == 0) || (pro_scale && pro_shift),
+              "conv_gemm_fwd: affine prologue without scale/shift");
+  SEG_REQUIRE((long)N * Ho * Wo < (1L << 31), "conv_gemm_fwd: M overflows int");
+  ConvGemmArgs a;
+  a.x = x; a.w = w; a.y = y;
+  a.pro_scale = pro_scale; a.pro_shift = pro_shift; a.bias = bias; a.stat_partial = stat_partial;
+  a.ldx = ldx; a.ldy = ldy;
+  a.N = N; a.Hi = Hi; a.Wi = Wi; a.C = C; a.Ho = Ho; a.Wo = Wo; a.O = O;
+  a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad; a.dil = dil;
+  a.pro_mode = pro_mode;
+  a.M = N * Ho * Wo; a.K = KH * KW * C;
+  a.out_H = out_H; a.out_W = out_W; a.out_s = out_s;
+  a.tiles_m = (a.M + BM - 1) / BM; a.tiles_n = (O + BN - 1) / BN;
+  if (dtype == DT_BF16) return launch_conv_gemm_fwd<bf16_t>(a, (hipStream_t)stream);
+  return launch_conv_gemm_fwd<float>(a, (hipStream_t)stream);
+}
+
+extern "C" int seg_conv_gemm_tiles_m(int N, int Ho, int Wo) {
+  return (N * Ho * Wo + seg::BM - 1) / seg::BM;
+}

@@ -1,0 +1,339 @@
+// Depthwise 3x3 convolution (groups == C), NHWC, any stride / dilation, pad = dil.
+// Reference call sites: segmentron/modules/basic.py:38-40 (SeparableConv2d.depthwise),
+// :152-153 (InvertedResidual dw).  68 instances in DeepLabv3+/xception65: 1.5 % of
+// the MACs but as much HBM traffic as all 1x1 convs -> purely bandwidth-bound, so the kernel is
+// built around 16-byte channel vectors (8 bf16 / 4 f32 per lane, consecutive lanes = consecutive
+// channel vectors = fully coalesced NHWC rows) with the producer's BatchNorm(+ReLU) fused into
+// the load path and the consumer BatchNorm's sum / sum-of-squares fused into the store path.
+//
+//   MODE_FWD   : y[n,ho,wo,c] = sum_{kh,kw} act(x[n, ho*s-p+kh*d, wo*s-p+kw*d, c]) * w[kh,kw,c]
+//   MODE_DGRAD : dx[n,h,w,c]  = sum_{kh,kw} dy[n,(h+p-kh*d)/s,(w+p-kw*d)/s,c] * w[kh,kw,c]
+//                (terms kept only when the division is exact and in range)
+//   wgrad      : dw[kh,kw,c]  = sum_{n,ho,wo} dy[n,ho,wo,c] * act(x[n, ho*s-p+kh*d, ...,c])
+//
+// Thread layout: block = CVB channel-vectors (8/16/32, chosen by the host to fit C) x 256/CVB
+// pixel strips; a strip is TW=4 consecutive output pixels of one row.  blockIdx.x tiles the
+// channel vectors, blockIdx.y the strips (grid-stride), one row of statistics partials per
+// blockIdx.y (deterministic: LDS tree over the strips of a block, fp64 finish in bn_finalize).
+#include "common.h"
+
+namespace seg {
+
+constexpr int DW_TW = 4;
+constexpr int DW_THREADS = 256;
+enum { MODE_FWD = 0, MODE_DGRAD = 1 };
+
+struct DwArgs {
+  const void* x;      // fwd: input; dgrad: dy
+  const float* w;     // [9][C] fp32, tap-major
+  void* y;            // fwd: output; dgrad: dx
+  const float* pro_scale;
+  const float* pro_shift;
+  float* stat_partial;  // [gridDim.y][2][C] or null (fwd only)
+  long ldx, ldy;
+  int N, Hi, Wi, C;   // geometry of the tensor being READ
+  int Ho, Wo;         // geometry of the tensor being WRITTEN
+  int stride, pad, dil;
+  int pro_mode;
+  int cvb_log2;       // log2(CVB)
+  int CV;             // C / VEC
+  long strips;        // N * Ho * ceil(Wo / TW)
+};
+
+template <typename T, int MODE>
+__global__ __launch_bounds__(DW_THREADS) void dwconv_kernel(const DwArgs a) {
+  constexpr int VEC = Vec<T>::N;
+  extern __shared__ __attribute__((aligned(16))) float dw_smem[];
+  const int tid = threadIdx.x;
+  const int cvb = 1 << a.cvb_log2;
+  const int cx = tid & (cvb - 1), sy = tid >> a.cvb_log2;
+  const int spb = DW_THREADS >> a.cvb_log2;  // strips per block iteration
+  const int cv = blockIdx.x * cvb + cx;
+  const bool cok = cv < a.CV;
+  const int c0 = cv * VEC;
+  const T* __restrict__ X = reinterpret_cast<const T*>(a.x);
+  T* __restrict__ Y = reinterpret_cast<T*>(a.y);
+  const int WQ = (a.Wo + DW_TW - 1) / DW_TW;
+
+  float ssum[VEC], ssq[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) ssum[i] = ssq[i] = 0.f;
+
+  for (long s = (long)blockIdx.y * spb + sy; s < a.strips; s += (long)gridDim.y * spb) {
+    if (!cok) continue;
+    const int wq = (int)(s % WQ);
+    const long t = s / WQ;
+    const int ho = (int)(t % a.Ho);
+    const int n = (int)(t / a.Ho);
+    const int w0 = wq * DW_TW;
+    float acc[DW_TW][VEC];
+#pragma unroll
+    for (int j = 0; j < DW_TW; ++j)
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) acc[j][i] = 0.f;
+
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      int hi;
+      if (MODE == MODE_FWD) {
+        hi = ho * a.stride - a.pad + kh * a.dil;
+      } else {
+        const int hn = ho + a.pad - kh * a.dil;
+        if (hn < 0 || (hn % a.stride) != 0) continue;
+        hi = hn / a.stride;
+      }
+      if (hi < 0 || hi >= a.Hi) continue;
+      const long rowbase = ((long)n * a.Hi + hi) * a.Wi;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        float wv[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) wv[i] = a.w[(kh * 3 + kw) * a.C + c0 + i];
+#pragma unroll
+        for (int j = 0; j < DW_TW; ++j) {
+          const int wo = w0 + j;
+          int wi;
+          bool ok = wo < a.Wo;
+          if (MODE == MODE_FWD) {
+            wi = wo * a.stride - a.pad + kw * a.dil;
+          } else {
+            const int wn = wo + a.pad - kw * a.dil;
+            ok = ok && wn >= 0 && (wn % a.stride) == 0;
+            wi = wn / a.stride;
+          }
+          ok = ok && wi >= 0 && wi < a.Wi;
+          if (ok) {
+            float f[VEC];
+            Vec<T>::unpack(ldg16(X + (rowbase + wi) * a.ldx + c0), f);
+            apply_prologue<VEC>(f, a.pro_mode, a.pro_scale, a.pro_shift, c0);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) acc[j][i] = fmaf(f[i], wv[i], acc[j][i]);
+          }
+        }
+      }
+    }
+    const long orow = ((long)n * a.Ho + ho) * a.Wo;
+#pragma unroll
+    for (int j = 0; j < DW_TW; ++j) {
+      if (w0 + j < a.Wo) {
+        stg16(Y + (orow + w0 + j) * a.ldy + c0, Vec<T>::pack(acc[j]));
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+          ssum[i] += acc[j][i];
+          ssq[i] += acc[j][i] * acc[j][i];
+        }
+      }
+    }
+  }
+
+  if (a.stat_partial != nullptr) {
+    // dw_smem: [spb][cvb][2*VEC]
+    float* mine = dw_smem + ((long)sy * cvb + cx) * 2 * VEC;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      mine[i] = ssum[i];
+      mine[VEC + i] = ssq[i];
+    }
+    __syncthreads();
+    for (int e = tid; e < cvb * 2 * VEC; e += DW_THREADS) {
+      float tot = 0.f;
+      for (int r = 0; r < spb; ++r) tot += dw_smem[(long)r * cvb * 2 * VEC + e];
+      const int lcx = e / (2 * VEC), k = e % (2 * VEC);
+      const int which = k / VEC, ci = k % VEC;
+      const int c = (blockIdx.x * cvb + lcx) * VEC + ci;
+      if (c < a.C) a.stat_partial[((long)blockIdx.y * 2 + which) * a.C + c] = tot;
+    }
+  }
+}
+
+// ---- weight gradient: partial[blockIdx.y][9][C]
+struct DwWgradArgs {
+  const void* x;   // forward input (pre-activation raw tensor + prologue)
+  const void* dy;  // grad wrt dw output
+  float* partial;  // [gridDim.y][9][C]
+  const float* pro_scale;
+  const float* pro_shift;
+  long ldx, lddy;
+  int N, Hi, Wi, C, Ho, Wo;
+  int stride, pad, dil;
+  int pro_mode;
+  int cvb_log2, CV;
+  long strips;
+};
+
+template <typename T>
+__global__ __launch_bounds__(DW_THREADS) void dwconv_wgrad_kernel(const DwWgradArgs a) {
+  constexpr int VEC = Vec<T>::N;
+  extern __shared__ __attribute__((aligned(16))) float dw_smem[];
+  const int tid = threadIdx.x;
+  const int cvb = 1 << a.cvb_log2;
+  const int cx = tid & (cvb - 1), sy = tid >> a.cvb_log2;
+  const int spb = DW_THREADS >> a.cvb_log2;
+  const int cv = blockIdx.x * cvb + cx;
+  const bool cok = cv < a.CV;
+  const int c0 = cv * VEC;
+  const T* __restrict__ X = reinterpret_cast<const T*>(a.x);
+  const T* __restrict__ DY = reinterpret_cast<const T*>(a.dy);
+  const int WQ = (a.Wo + DW_TW - 1) / DW_TW;
+
+  float acc[9][VEC];
+#pragma unroll
+  for (int k = 0; k < 9; ++k)
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) acc[k][i] = 0.f;
+
+  for (long s = (long)blockIdx.y * spb + sy; s < a.strips; s += (long)gridDim.y * spb) {
+    if (!cok) continue;
+    const int wq = (int)(s % WQ);
+    const long t = s / WQ;
+    const int ho = (int)(t % a.Ho);
+    const int n = (int)(t / a.Ho);
+    const int w0 = wq * DW_TW;
+    const long orow = ((long)n * a.Ho + ho) * a.Wo;
+    float g[DW_TW][VEC];
+#pragma unroll
+    for (int j = 0; j < DW_TW; ++j) {
+      if (w0 + j < a.Wo) {
+        Vec<T>::unpack(ldg16(DY + (orow + w0 + j) * a.lddy + c0), g[j]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) g[j][i] = 0.f;
+      }
+    }
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int hi = ho * a.stride - a.pad + kh * a.dil;
+      if (hi < 0 || hi >= a.Hi) continue;
+      const long rowbase = ((long)n * a.Hi + hi) * a.Wi;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+#pragma unroll
+        for (int j = 0; j < DW_TW; ++j) {
+          const int wi = (w0 + j) * a.stride - a.pad + kw * a.dil;
+          if (w0 + j < a.Wo && wi >= 0 && wi < a.Wi) {
+            float f[VEC];
+            Vec<T>::unpack(ldg16(X + (rowbase + wi) * a.ldx + c0), f);
+            apply_prologue<VEC>(f, a.pro_mode, a.pro_scale, a.pro_shift, c0);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) acc[kh * 3 + kw][i] = fmaf(f[i], g[j][i], acc[kh * 3 + kw][i]);
+          }
+        }
+      }
+    }
+  }
+  // block reduction over the strips, three taps at a time (LDS: [spb][cvb][3*VEC])
+#pragma unroll
+  for (int k3 = 0; k3 < 3; ++k3) {
+    float* mine = dw_smem + ((long)sy * cvb + cx) * 3 * VEC;
+#pragma unroll
+    for (int kk = 0; kk < 3; ++kk)
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) mine[kk * VEC + i] = acc[k3 * 3 + kk][i];
+    __syncthreads();
+    for (int e = tid; e < cvb * 3 * VEC; e += DW_THREADS) {
+      float tot = 0.f;
+      for (int r = 0; r < spb; ++r) tot += dw_smem[(long)r * cvb * 3 * VEC + e];
+      const int lcx = e / (3 * VEC), k = e % (3 * VEC);
+      const int kk = k / VEC, ci = k % VEC;
+      const int c = (blockIdx.x * cvb + lcx) * VEC + ci;
+      if (c < a.C) a.partial[((long)blockIdx.y * 9 + k3 * 3 + kk) * a.C + c] = tot;
+    }
+    __syncthreads();
+  }
+}
+
+static int pick_cvb_log2(int CV) {
+  // largest utilisation among 32/16/8 channel vectors per block; ties -> wider
+  int best = 5;
+  double bu = 0;
+  for (int l = 5; l >= 3; --l) {
+    const int b = 1 << l;
+    const double u = (double)CV / (double)(((CV + b - 1) / b) * b);
+    if (u > bu + 1e-9) { bu = u; best = l; }
+  }
+  return best;
+}
+
+}  // namespace seg
+
+extern "C" int seg_dwconv_grid_y(int dtype, int C, int N, int Ho, int Wo) {
+  using namespace seg;
+  const int vec = dtype == DT_BF16 ? 8 : 4;
+  const int CV = C / vec;
+  const int l = pick_cvb_log2(CV);
+  const int spb = DW_THREADS >> l;
+  const long strips = (long)N * Ho * ((Wo + DW_TW - 1) / DW_TW);
+  const int gx = (CV + (1 << l) - 1) >> l;
+  long gy = (strips + spb - 1) / spb;
+  long cap = 4096 / gx;  // ~16 blocks per CU in total
+  if (cap < 1) cap = 1;
+  if (gy > cap) gy = cap;
+  return (int)gy;
+}
+
+// mode: 0 forward, 1 dgrad (x = dy, y = dx; (N,Hi,Wi) is dy's geometry, (Ho,Wo) dx's)
+extern "C" int seg_dwconv3x3(int dtype, int mode, const void* x, long ldx, int N, int Hi, int Wi,
+                             int C, const float* w9c, int stride, int dil, int pro_mode,
+                             const float* pro_scale, const float* pro_shift, void* y, long ldy,
+                             int Ho, int Wo, float* stat_partial, int grid_y, void* stream) {
+  using namespace seg;
+  const int vec = dtype == DT_BF16 ? 8 : 4;
+  SEG_REQUIRE(dtype == DT_F32 || dtype == DT_BF16, "dwconv3x3: bad dtype %d", dtype);
+  SEG_REQUIRE(C % vec == 0 && ldx % vec == 0 && ldy % vec == 0,
+              "dwconv3x3: C/ldx/ldy must be multiples of %d", vec);
+  SEG_REQUIRE(((pro_mode & PRO_AFFINE) == 0) || (pro_scale && pro_shift),
+              "dwconv3x3: affine prologue without scale/shift");
+  SEG_REQUIRE(mode == MODE_FWD || stat_partial == nullptr, "dwconv3x3: stats only in forward");
+  DwArgs a;
+  a.x = x; a.w = w9c; a.y = y; a.pro_scale = pro_scale; a.pro_shift = pro_shift;
+  a.stat_partial = stat_partial; a.ldx = ldx; a.ldy = ldy;
+  a.N = N; a.Hi = Hi; a.Wi = Wi; a.C = C; a.Ho = Ho; a.Wo = Wo;
+  a.stride = stride; a.pad = dil; a.dil = dil; a.pro_mode = pro_mode;
+  a.CV = C / vec; a.cvb_log2 = pick_cvb_log2(a.CV);
+  a.strips = (long)N * Ho * ((Wo + DW_TW - 1) / DW_TW);
+  const int gx = (a.CV + (1 << a.cvb_log2) - 1) >> a.cvb_log2;
+  SEG_REQUIRE(grid_y >= 1, "dwconv3x3: grid_y must be >= 1");
+  const dim3 grid(gx, grid_y);
+  const size_t lds = stat_partial ? (size_t)DW_THREADS * 2 * vec * sizeof(float) : 0;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == DT_BF16) {
+    if (mode == MODE_FWD)
+      hipLaunchKernelGGL((dwconv_kernel<bf16_t, MODE_FWD>), grid, dim3(DW_THREADS), lds, st, a);
+    else
+      hipLaunchKernelGGL((dwconv_kernel<bf16_t, MODE_DGRAD>), grid, dim3(DW_THREADS), lds, st, a);
+  } else {
+    if (mode == MODE_FWD)
+      hipLaunchKernelGGL((dwconv_kernel<float, MODE_FWD>), grid, dim3(DW_THREADS), lds, st, a);
+    else
+      hipLaunchKernelGGL((dwconv_kernel<float, MODE_DGRAD>), grid, dim3(DW_THREADS), lds, st, a);
+  }
+  return check_launch("dwconv3x3");
+}
+
+extern "C" int seg_dwconv3x3_wgrad(int dtype, const void* x, long ldx, int N, int Hi, int Wi,
+                                   int C, const void* dy, long lddy, int Ho, int Wo, int stride,
+                                   int dil, int pro_mode, const float* pro_scale,
+                                   const float* pro_shift, float* partial, int grid_y,
+                                   void* stream) {
+  using namespace seg;
+  const int vec = dtype == DT_BF16 ? 8 : 4;
+  SEG_REQUIRE(dtype == DT_F32 || dtype == DT_BF16, "dwconv3x3_wgrad: bad dtype %d", dtype);
+  SEG_REQUIRE(C % vec == 0 && ldx % vec == 0 && lddy % vec == 0,
+              "dwconv3x3_wgrad: C/ldx/lddy must be multiples of %d", vec);
+  DwWgradArgs a;
+  a.x = x; a.dy = dy; a.partial = partial; a.pro_scale = pro_scale; a.pro_shift = pro_shift;
+  a.ldx = ldx; a.lddy = lddy; a.N = N; a.Hi = Hi; a.Wi = Wi; a.C = C; a.Ho = Ho; a.Wo = Wo;
+  a.stride = stride; a.pad = dil; a.dil = dil; a.pro_mode = pro_mode;
+  a.CV = C / vec; a.cvb_log2 = pick_cvb_log2(a.CV);
+  a.strips = (long)N * Ho * ((Wo + DW_TW - 1) / DW_TW);
+  const int gx = (a.CV + (1 << a.cvb_log2) - 1) >> a.cvb_log2;
+  SEG_REQUIRE(grid_y >= 1, "dwconv3x3_wgrad: grid_y must be >= 1");
+  const dim3 grid(gx, grid_y);
+  const size_t lds = (size_t)DW_THREADS * 3 * vec * sizeof(float);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL((dwconv_wgrad_kernel<bf16_t>), grid, dim3(DW_THREADS), lds, st, a);
+  else
+    hipLaunchKernelGGL((dwconv_wgrad_kernel<float>), grid, dim3(DW_THREADS), lds, st, a);
+  return check_launch("dwconv3x3_wgrad");
+}

@@ -1,0 +1,351 @@
+// Bilinear resampling (F.interpolate mode='bilinear', align_corners True/False) on NHWC tensors,
+// the NHWC(T) -> NCHW(fp32) logits upsample at the model boundary, and the NCHW fp32 image ->
+// channel-padded NHWC(T) conversion at the input boundary.
+// Reference call sites: segmentron/models/deeplabv3_plus.py:39,44,71, segmentron/modules/module.py:64,96,
+// segmentron/models/segbase.py:83; semantics SURVEY.md Appendix B (same float32 source-index
+// arithmetic as ATen's upsample_bilinear2d: scale = (in-1)/(out-1), src = scale*dst,
+// i0 = floor(src), i1 = min(i0+1, in-1), lambda = src - i0).
+// Backward is written as a GATHER over the forward's own tap computation (no atomics, bitwise
+// deterministic): an input pixel scans the small window of outputs that can reference it and
+// re-derives their (i0, i1, lambda).
+#include "common.h"
+
+namespace seg {
+
+constexpr int RS_THREADS = 256;
+
+__device__ __forceinline__ float src_index(float scale, int dst, int align) {
+  if (align) return scale * (float)dst;
+  const float s = scale * ((float)dst + 0.5f) - 0.5f;
+  return s < 0.f ? 0.f : s;
+}
+__device__ __forceinline__ void taps(float scale, int dst, int in, int align, int& i0, int& i1,
+                                     float& lam) {
+  const float s = src_index(scale, dst, align);
+  i0 = (int)s;
+  if (i0 > in - 1) i0 = in - 1;
+  i1 = i0 + (i0 < in - 1 ? 1 : 0);
+  lam = s - (float)i0;
+}
+static float host_scale(int in, int out, int align) {
+  if (align) return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
+  return (float)in / (float)out;
+}
+// candidate output range [lo, hi] whose taps may touch input index i
+__device__ __forceinline__ void cand_range(float scale, int i, int out, int& lo, int& hi) {
+  if (scale <= 0.f) { lo = 0; hi = out - 1; return; }
+  const float inv = 1.f / scale;
+  lo = (int)floorf(((float)i - 1.f) * inv) - 1;
+  hi = (int)ceilf(((float)i + 1.f) * inv) + 1;
+  if (lo < 0) lo = 0;
+  if (hi > out - 1) hi = out - 1;
+}
+__device__ __forceinline__ float tap_weight(float scale, int dst, int in, int align, int i) {
+  int i0, i1; float lam;
+  taps(scale, dst, in, align, i0, i1, lam);
+  float w = 0.f;
+  if (i0 == i) w += 1.f - lam;
+  if (i1 == i) w += lam;
+  return w;
+}
+
+struct ResizeArgs {
+  const void* x; void* y;
+  const float* scale; const float* shift; const float* chan_mul;
+  long ldx, ldy;
+  int N, Hi, Wi, Ho, Wo, C, CV;
+  int mode, align;
+  float sh, sw;
+};
+
+template <typename T>
+__global__ __launch_bounds__(RS_THREADS) void bilinear_fwd_kernel(const ResizeArgs a) {
+  constexpr int VEC = Vec<T>::N;
+  const T* __restrict__ X = reinterpret_cast<const T*>(a.x);
+  T* __restrict__ Y = reinterpret_cast<T*>(a.y);
+  const long total = (long)a.N * a.Ho * a.Wo * a.CV;
+  for (long i = (long)blockIdx.x * RS_THREADS + threadIdx.x; i < total;
+       i += (long)gridDim.x * RS_THREADS) {
+    const int cv = (int)(i % a.CV);
+    long p = i / a.CV;
+    const int wo = (int)(p % a.Wo); p /= a.Wo;
+    const int ho = (int)(p % a.Ho);
+    const int n = (int)(p / a.Ho);
+    const int c0 = cv * VEC;
+    int h0, h1, w0, w1; float lh, lw;
+    taps(a.sh, ho, a.Hi, a.align, h0, h1, lh);
+    taps(a.sw, wo, a.Wi, a.align, w0, w1, lw);
+    const long base = (long)n * a.Hi * a.Wi;
+    float f00[VEC], f01[VEC], f10[VEC], f11[VEC];
+    Vec<T>::unpack(ldg16(X + (base + (long)h0 * a.Wi + w0) * a.ldx + c0), f00);
+    Vec<T>::unpack(ldg16(X + (base + (long)h0 * a.Wi + w1) * a.ldx + c0), f01);
+    Vec<T>::unpack(ldg16(X + (base + (long)h1 * a.Wi + w0) * a.ldx + c0), f10);
+    Vec<T>::unpack(ldg16(X + (base + (long)h1 * a.Wi + w1) * a.ldx + c0), f11);
+    apply_prologue<VEC>(f00, a.mode, a.scale, a.shift, c0);
+    apply_prologue<VEC>(f01, a.mode, a.scale, a.shift, c0);
+    apply_prologue<VEC>(f10, a.mode, a.scale, a.shift, c0);
+    apply_prologue<VEC>(f11, a.mode, a.scale, a.shift, c0);
+    float o[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      const float top = (1.f - lw) * f00[k] + lw * f01[k];
+      const float bot = (1.f - lw) * f10[k] + lw * f11[k];
+      o[k] = (1.f - lh) * top + lh * bot;
+    }
+    if (a.chan_mul) {
+      const float* m = a.chan_mul + (long)n * a.C + c0;
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) o[k] *= m[k];
+    }
+    stg16(Y + (((long)n * a.Ho + ho) * a.Wo + wo) * a.ldy + c0, Vec<T>::pack(o));
+  }
+}
+
+// gx[n,hi,wi,:] = sum over outputs of weight * gy  (x side: Hi x Wi, y side: Ho x Wo)
+template <typename T>
+__global__ __launch_bounds__(RS_THREADS) void bilinear_bwd_kernel(const ResizeArgs a) {
+  constexpr int VEC = Vec<T>::N;
+  const T* __restrict__ GY = reinterpret_cast<const T*>(a.y);
+  T* __restrict__ GX = reinterpret_cast<T*>(const_cast<void*>(a.x));
+  const long total = (long)a.N * a.Hi * a.Wi * a.CV;
+  for (long i = (long)blockIdx.x * RS_THREADS + threadIdx.x; i < total;
+       i += (long)gridDim.x * RS_THREADS) {
+    const int cv = (int)(i % a.CV);
+    long p = i / a.CV;
+    const int wi = (int)(p % a.Wi); p /= a.Wi;
+    const int hi = (int)(p % a.Hi);
+    const int n = (int)(p / a.Hi);
+    const int c0 = cv * VEC;
+    int hlo, hhi, wlo, whi;
+    cand_range(a.sh, hi, a.Ho, hlo, hhi);
+    cand_range(a.sw, wi, a.Wo, wlo, whi);
+    float acc[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
+    for (int ho = hlo; ho <= hhi; ++ho) {
+      const float wh = tap_weight(a.sh, ho, a.Hi, a.align, hi);
+      if (wh == 0.f) continue;
+      for (int wo = wlo; wo <= whi; ++wo) {
+        const float ww = tap_weight(a.sw, wo, a.Wi, a.align, wi);
+        if (ww == 0.f) continue;
+        float g[VEC];
+        Vec<T>::unpack(ldg16(GY + (((long)n * a.Ho + ho) * a.Wo + wo) * a.ldy + c0), g);
+        const float w = wh * ww;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[k] = fmaf(w, g[k], acc[k]);
+      }
+    }
+    stg16(GX + (((long)n * a.Hi + hi) * a.Wi + wi) * a.ldx + c0, Vec<T>::pack(acc));
+  }
+}
+
+// ---- logits: NHWC (T, C valid channels, row pitch ldx) -> NCHW fp32 at (Ho, Wo)
+template <typename T>
+__global__ __launch_bounds__(RS_THREADS) void upsample_to_nchw_kernel(const ResizeArgs a,
+                                                                      float* __restrict__ out) {
+  constexpr int VEC = Vec<T>::N;
+  const T* __restrict__ X = reinterpret_cast<const T*>(a.x);
+  const long total = (long)a.N * a.Ho * a.Wo;
+  const long plane = (long)a.Ho * a.Wo;
+  for (long i = (long)blockIdx.x * RS_THREADS + threadIdx.x; i < total;
+       i += (long)gridDim.x * RS_THREADS) {
+    long p = i;
+    const int wo = (int)(p % a.Wo); p /= a.Wo;
+    const int ho = (int)(p % a.Ho);
+    const int n = (int)(p / a.Ho);
+    int h0, h1, w0, w1; float lh, lw;
+    taps(a.sh, ho, a.Hi, a.align, h0, h1, lh);
+    taps(a.sw, wo, a.Wi, a.align, w0, w1, lw);
+    const long base = (long)n * a.Hi * a.Wi;
+    float* o = out + (long)n * a.C * plane + (long)ho * a.Wo + wo;
+    for (int cv = 0; cv < a.CV; ++cv) {
+      const int c0 = cv * VEC;
+      float f00[VEC], f01[VEC], f10[VEC], f11[VEC];
+      Vec<T>::unpack(ldg16(X + (base + (long)h0 * a.Wi + w0) * a.ldx + c0), f00);
+      Vec<T>::unpack(ldg16(X + (base + (long)h0 * a.Wi + w1) * a.ldx + c0), f01);
+      Vec<T>::unpack(ldg16(X + (base + (long)h1 * a.Wi + w0) * a.ldx + c0), f10);
+      Vec<T>::unpack(ldg16(X + (base + (long)h1 * a.Wi + w1) * a.ldx + c0), f11);
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) {
+        if (c0 + k < a.C) {
+          const float top = (1.f - lw) * f00[k] + lw * f01[k];
+          const float bot = (1.f - lw) * f10[k] + lw * f11[k];
+          o[(long)(c0 + k) * plane] = (1.f - lh) * top + lh * bot;
+        }
+      }
+    }
+  }
+}
+
+// gx NHWC (T, padded channels written as 0) <- gy NCHW fp32
+template <typename T>
+__global__ __launch_bounds__(RS_THREADS) void upsample_to_nchw_bwd_kernel(
+    const ResizeArgs a, const float* __restrict__ gy) {
+  constexpr int VEC = Vec<T>::N;
+  T* __restrict__ GX = reinterpret_cast<T*>(const_cast<void*>(a.x));
+  const long total = (long)a.N * a.Hi * a.Wi;
+  const long plane = (long)a.Ho * a.Wo;
+  for (long i = (long)blockIdx.x * RS_THREADS + threadIdx.x; i < total;
+       i += (long)gridDim.x * RS_THREADS) {
+    long p = i;
+    const int wi = (int)(p % a.Wi); p /= a.Wi;
+    const int hi = (int)(p % a.Hi);
+    const int n = (int)(p / a.Hi);
+    int hlo, hhi, wlo, whi;
+    cand_range(a.sh, hi, a.Ho, hlo, hhi);
+    cand_range(a.sw, wi, a.Wo, wlo, whi);
+    for (int cv = 0; cv < a.CV; ++cv) {
+      const int c0 = cv * VEC;
+      float acc[VEC];
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
+      for (int ho = hlo; ho <= hhi; ++ho) {
+        const float wh = tap_weight(a.sh, ho, a.Hi, a.align, hi);
+        if (wh == 0.f) continue;
+        for (int wo = wlo; wo <= whi; ++wo) {
+          const float ww = tap_weight(a.sw, wo, a.Wi, a.align, wi);
+          if (ww == 0.f) continue;
+          const float w = wh * ww;
+          const float* g = gy + (long)n * a.C * plane + (long)ho * a.Wo + wo;
+#pragma unroll
+          for (int k = 0; k < VEC; ++k)
+            if (c0 + k < a.C) acc[k] = fmaf(w, g[(long)(c0 + k) * plane], acc[k]);
+        }
+      }
+      stg16(GX + (((long)n * a.Hi + hi) * a.Wi + wi) * a.ldx + c0, Vec<T>::pack(acc));
+    }
+  }
+}
+
+// ---- image boundary: NCHW fp32 [N,Cin,H,W] -> NHWC T [N,H,W,VEC] (channels >= Cin zero)
+template <typename T>
+__global__ __launch_bounds__(RS_THREADS) void nchw_to_nhwc_pad_kernel(const float* __restrict__ x,
+                                                                      T* __restrict__ y, int N,
+                                                                      int Cin, long HW) {
+  constexpr int VEC = Vec<T>::N;
+  const long total = (long)N * HW;
+  for (long i = (long)blockIdx.x * RS_THREADS + threadIdx.x; i < total;
+       i += (long)gridDim.x * RS_THREADS) {
+    const long n = i / HW, p = i - n * HW;
+    float f[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) f[k] = (k < Cin) ? x[(n * Cin + k) * HW + p] : 0.f;
+    stg16(y + i * VEC, Vec<T>::pack(f));
+  }
+}
+
+static int rs_grid(long total) {
+  long g = (total + RS_THREADS - 1) / RS_THREADS;
+  if (g > 8192) g = 8192;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+static int fill_args(ResizeArgs& a, int dtype, const void* x, long ldx, int N, int Hi, int Wi,
+                     int C, void* y, long ldy, int Ho, int Wo, int align, bool need_vec_c) {
+  const int vec = dtype == DT_BF16 ? 8 : 4;
+  SEG_REQUIRE(dtype == DT_F32 || dtype == DT_BF16, "resize: bad dtype %d", dtype);
+  SEG_REQUIRE(ldx % vec == 0 && (!need_vec_c || (C % vec == 0 && ldy % vec == 0)),
+              "resize: C/ld must be multiples of %d", vec);
+  SEG_REQUIRE(N > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0, "resize: empty");
+  a.x = x; a.y = y; a.scale = nullptr; a.shift = nullptr; a.chan_mul = nullptr;
+  a.ldx = ldx; a.ldy = ldy; a.N = N; a.Hi = Hi; a.Wi = Wi; a.Ho = Ho; a.Wo = Wo; a.C = C;
+  a.CV = (C + vec - 1) / vec; a.mode = PRO_NONE; a.align = align;
+  a.sh = host_scale(Hi, Ho, align); a.sw = host_scale(Wi, Wo, align);
+  return 0;
+}
+
+}  // namespace seg
+
+extern "C" int seg_bilinear_fwd(int dtype, const void* x, long ldx, int N, int Hi, int Wi, int C,
+                                int pro_mode, const float* pro_scale, const float* pro_shift,
+                                const float* chan_mul, void* y, long ldy, int Ho, int Wo,
+                                int align_corners, void* stream) {
+  using namespace seg;
+  ResizeArgs a;
+  if (fill_args(a, dtype, x, ldx, N, Hi, Wi, C, y, ldy, Ho, Wo, align_corners, true)) return 1;
+  SEG_REQUIRE(((pro_mode & PRO_AFFINE) == 0) || (pro_scale && pro_shift),
+              "bilinear_fwd: missing scale/shift");
+  a.mode = pro_mode; a.scale = pro_scale; a.shift = pro_shift; a.chan_mul = chan_mul;
+  const int grid = rs_grid((long)N * Ho * Wo * a.CV);
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL((bilinear_fwd_kernel<bf16_t>), dim3(grid), dim3(RS_THREADS), 0,
+                       (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL((bilinear_fwd_kernel<float>), dim3(grid), dim3(RS_THREADS), 0,
+                       (hipStream_t)stream, a);
+  return check_launch("bilinear_fwd");
+}
+
+// gx [N,Hi,Wi,C] (written) <- gy [N,Ho,Wo,C]; (Hi,Wi) is the forward INPUT size
+extern "C" int seg_bilinear_bwd(int dtype, void* gx, long ldgx, int N, int Hi, int Wi, int C,
+                                const void* gy, long ldgy, int Ho, int Wo, int align_corners,
+                                void* stream) {
+  using namespace seg;
+  ResizeArgs a;
+  if (fill_args(a, dtype, gx, ldgx, N, Hi, Wi, C, const_cast<void*>(gy), ldgy, Ho, Wo,
+                align_corners, true))
+    return 1;
+  const int grid = rs_grid((long)N * Hi * Wi * a.CV);
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL((bilinear_bwd_kernel<bf16_t>), dim3(grid), dim3(RS_THREADS), 0,
+                       (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL((bilinear_bwd_kernel<float>), dim3(grid), dim3(RS_THREADS), 0,
+                       (hipStream_t)stream, a);
+  return check_launch("bilinear_bwd");
+}
+
+// x: NHWC T with C valid channels and row pitch ldx >= roundup(C, VEC); out: NCHW fp32
+extern "C" int seg_upsample_to_nchw(int dtype, const void* x, long ldx, int N, int Hi, int Wi,
+                                    int C, float* out, int Ho, int Wo, int align_corners,
+                                    void* stream) {
+  using namespace seg;
+  ResizeArgs a;
+  if (fill_args(a, dtype, x, ldx, N, Hi, Wi, C, nullptr, 0, Ho, Wo, align_corners, false)) return 1;
+  SEG_REQUIRE(ldx >= (long)a.CV * (dtype == DT_BF16 ? 8 : 4), "upsample_to_nchw: ldx too small");
+  const int grid = rs_grid((long)N * Ho * Wo);
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL((upsample_to_nchw_kernel<bf16_t>), dim3(grid), dim3(RS_THREADS), 0,
+                       (hipStream_t)stream, a, out);
+  else
+    hipLaunchKernelGGL((upsample_to_nchw_kernel<float>), dim3(grid), dim3(RS_THREADS), 0,
+                       (hipStream_t)stream, a, out);
+  return check_launch("upsample_to_nchw");
+}
+
+extern "C" int seg_upsample_to_nchw_bwd(int dtype, void* gx, long ldgx, int N, int Hi, int Wi,
+                                        int C, const float* gy, int Ho, int Wo, int align_corners,
+                                        void* stream) {
+  using namespace seg;
+  ResizeArgs a;
+  if (fill_args(a, dtype, gx, ldgx, N, Hi, Wi, C, nullptr, 0, Ho, Wo, align_corners, false))
+    return 1;
+  SEG_REQUIRE(ldgx >= (long)a.CV * (dtype == DT_BF16 ? 8 : 4), "upsample_to_nchw_bwd: ld small");
+  a.CV = (int)(ldgx / (dtype == DT_BF16 ? 8 : 4));  // zero-fill every padded channel of gx
+  const int grid = rs_grid((long)N * Hi * Wi);
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL((upsample_to_nchw_bwd_kernel<bf16_t>), dim3(grid), dim3(RS_THREADS), 0,
+                       (hipStream_t)stream, a, gy);
+  else
+    hipLaunchKernelGGL((upsample_to_nchw_bwd_kernel<float>), dim3(grid), dim3(RS_THREADS), 0,
+                       (hipStream_t)stream, a, gy);
+  return check_launch("upsample_to_nchw_bwd");
+}
+
+extern "C" int seg_nchw_to_nhwc_pad(int dtype, const float* x, int N, int Cin, int H, int W,
+                                    void* y, void* stream) {
+  using namespace seg;
+  const int vec = dtype == DT_BF16 ? 8 : 4;
+  SEG_REQUIRE(dtype == DT_F32 || dtype == DT_BF16, "nchw_to_nhwc_pad: bad dtype %d", dtype);
+  SEG_REQUIRE(Cin >= 1 && Cin <= vec, "nchw_to_nhwc_pad: Cin=%d must be <= %d", Cin, vec);
+  const long HW = (long)H * W;
+  const int grid = rs_grid((long)N * HW);
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL((nchw_to_nhwc_pad_kernel<bf16_t>), dim3(grid), dim3(RS_THREADS), 0,
+                       (hipStream_t)stream, x, reinterpret_cast<bf16_t*>(y), N, Cin, HW);
+  else
+    hipLaunchKernelGGL((nchw_to_nhwc_pad_kernel<float>), dim3(grid), dim3(RS_THREADS), 0,
+                       (hipStream_t)stream, x, reinterpret_cast<float*>(y), N, Cin, HW);
+  return check_launch("nchw_to_nhwc_pad");
+}

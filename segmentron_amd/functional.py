@@ -1,0 +1,422 @@
+"""Autograd layer over the HIP kernels: "deferred-BatchNorm" activations.
+
+The reference runs Conv -> BN -> ReLU as three separate nn.Modules ("No fused
+ops exist in the reference").  Here a convolution writes its RAW output once, its epilogue emits
+the BatchNorm statistics, and the normalisation (+ReLU) is applied lazily inside whatever kernel
+consumes the tensor next (``Act`` = raw NHWC tensor + pending per-channel affine + pending ReLU).
+In backward each consumer turns the gradient w.r.t. its activated input into the gradient w.r.t.
+the producer's raw output with the full BatchNorm backward formula, so multiple consumers of one
+deferred tensor sum correctly under plain torch autograd.
+
+Host code here is plumbing (allocation, weight packing, torch.autograd, torch.distributed);
+all arithmetic on activations is done by libsegmentron_hip.so.
+"""
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from . import hip_ops as K
+from .hip_ops import PRO_AFFINE, PRO_NONE, PRO_RELU
+
+
+# ----------------------------------------------------------------------------- state objects
+class BNState:
+    """One BatchNorm evaluated on one tensor in one forward pass."""
+    __slots__ = ("gamma", "beta", "mean", "invstd", "scale", "shift", "count", "training", "group")
+
+    def __init__(self, gamma, beta, mean, invstd, scale, shift, count, training, group=None):
+        self.gamma, self.beta = gamma, beta
+        self.mean, self.invstd, self.scale, self.shift = mean, invstd, scale, shift
+        self.count, self.training, self.group = count, training, group
+
+
+class Act:
+    """NHWC activation with a pending BatchNorm affine and/or ReLU."""
+    __slots__ = ("t", "bn", "relu")
+
+    def __init__(self, t, bn=None, relu=False):
+        self.t, self.bn, self.relu = t, bn, relu
+
+    @property
+    def pro(self):
+        mode = (PRO_AFFINE if self.bn is not None else PRO_NONE) | (PRO_RELU if self.relu else 0)
+        if self.bn is None:
+            return (mode, None, None)
+        return (mode, self.bn.scale, self.bn.shift)
+
+    @property
+    def params(self):
+        if self.bn is None:
+            return None, None
+        return self.bn.gamma, self.bn.beta
+
+    def with_relu(self):
+        return Act(self.t, self.bn, True)
+
+    @property
+    def shape(self):
+        return self.t.shape
+
+
+def _sync_group(bn):
+    if isinstance(bn, nn.SyncBatchNorm) and bn.training and dist.is_available() \
+            and dist.is_initialized() and dist.get_world_size() > 1:
+        return bn.process_group if bn.process_group is not None else dist.group.WORLD
+    return None
+
+
+def finish_bn(bn, partial, count):
+    """Turn conv-epilogue partials into a BNState (and update running stats like torch does).
+    bn: nn.BatchNorm2d / nn.SyncBatchNorm module — eps / momentum / training read NOW."""
+    use_batch = bn.training or bn.running_mean is None
+    if not use_batch:
+        scale, shift = K.bn_eval_affine(bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                        bn.eps)
+        invstd = mean = None
+        if torch.is_grad_enabled():
+            mean = bn.running_mean
+            invstd = torch.rsqrt(bn.running_var + bn.eps)
+        return BNState(bn.weight, bn.bias, mean, invstd, scale, shift, count, False)
+    if count <= 1 and _sync_group(bn) is None:
+        raise ValueError("Expected more than 1 value per channel when training, got count=%d"
+                         % count)
+    C = partial.shape[-1]
+    sums = K.colsum(partial.view(partial.shape[0], 2 * C))
+    group = _sync_group(bn)
+    cnt = float(count)
+    if group is not None:
+        # SyncBN statistics exchange: ONE all-reduce of 2C float64 sums over RCCL (torch's
+        # nn.SyncBatchNorm all_gathers (mean, invstd, count) per layer instead —
+        # torch/nn/modules/_functions.py:49,74).  Data-parallel shards are equal-sized
+        # (tools/train.py uses drop_last batches), so the global count needs no exchange.
+        dist.all_reduce(sums, group=group)
+        cnt = cnt * dist.get_world_size(group)
+    momentum = bn.momentum if bn.momentum is not None else 0.1
+    track = bn.training and bn.track_running_stats and bn.running_mean is not None
+    mean, invstd, scale, shift = K.bn_finalize(
+        sums, cnt, bn.weight, bn.bias, bn.eps, momentum,
+        bn.running_mean if track else None, bn.running_var if track else None)
+    if track and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked += 1
+    return BNState(bn.weight, bn.bias, mean, invstd, scale, shift, cnt, True, group)
+
+
+def bn_input_backward(g, x, bn, relu, chan_mul=None, inplace=False):
+    """g = dLoss/d(act(x)*chan_mul)  ->  (dLoss/dx_raw, dgamma, dbeta)."""
+    mode = (PRO_AFFINE if bn is not None else PRO_NONE) | (PRO_RELU if relu else 0)
+    if bn is None:
+        if not relu and chan_mul is None:
+            return g, None, None
+        dx = K.bn_bwd_apply(g, x, (mode, None, None), chan_mul=chan_mul, out=g if inplace else None)
+        return dx, None, None
+    pro = (mode, bn.scale, bn.shift)
+    sums = K.bn_bwd_reduce(g, x, pro, chan_mul)
+    if bn.group is not None:
+        dist.all_reduce(sums, group=bn.group)
+    dgamma, dbeta, c0, c1 = K.bn_bwd_finalize(sums, bn.count, bn.mean, bn.invstd, bn.gamma)
+    if not bn.training:
+        c0 = c1 = None
+    dx = K.bn_bwd_apply(g, x, pro, c0, c1, chan_mul, out=g if inplace else None)
+    if bn.group is not None:
+        # every rank holds the GLOBAL sums; DDP averages parameter grads over ranks, torch's
+        # SyncBatchNorm backward returns the LOCAL dgamma/dbeta — emulate by dividing.
+        ws = dist.get_world_size(bn.group)
+        dgamma, dbeta = dgamma / ws, dbeta / ws
+    return dx, dgamma, dbeta
+
+
+# ----------------------------------------------------------------------------- weight packing
+def pack_conv_weight(w, cx, dtype):
+    """[O, Cw, KH, KW] fp32 -> [O, KH*KW*cx] (`dtype`), input channels zero-padded to cx."""
+    O, Cw, KH, KW = w.shape
+    p = w.detach().permute(0, 2, 3, 1)
+    if cx != Cw:
+        p = torch.nn.functional.pad(p, (0, cx - Cw))
+    return p.reshape(O, KH * KW * cx).to(dtype).contiguous()
+
+
+def pack_conv_weight_dgrad(w, opad, dtype):
+    """-> [Cw, KH*KW*opad]: spatially flipped, in/out swapped, out channels padded to opad."""
+    O, Cw, KH, KW = w.shape
+    p = w.detach().flip(2, 3).permute(1, 2, 3, 0)
+    if opad != O:
+        p = torch.nn.functional.pad(p, (0, opad - O))
+    return p.reshape(Cw, KH * KW * opad).to(dtype).contiguous()
+
+
+def _round_up(v, m):
+    return (v + m - 1) // m * m
+
+
+class ConvSpec:
+    """Non-tensor arguments of one fused conv call (also carries the statistics partials out)."""
+
+    def __init__(self, act, stride=1, pad=0, dil=1, out=None, want_stats=True):
+        self.bn_in, self.relu = act.bn, act.relu
+        self.pro = act.pro
+        self.stride, self.pad, self.dil = stride, pad, dil
+        self.out, self.want_stats = out, want_stats
+        self.partial = None
+
+
+class _ConvFn(torch.autograd.Function):
+    """nn.Conv2d (groups=1) on a deferred activation: implicit GEMM on MFMA."""
+
+    @staticmethod
+    def forward(ctx, x, in_gamma, in_beta, weight, bias, spec):
+        O, Cw, KH, KW = weight.shape
+        wp = pack_conv_weight(weight, x.shape[-1], x.dtype)
+        y, spec.partial = K.conv_gemm(x, wp, O, KH, KW, spec.stride, spec.pad, spec.dil, spec.pro,
+                                      bias, spec.out, spec.want_stats)
+        ctx.spec = spec
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        s = ctx.spec
+        O, Cw, KH, KW = weight.shape
+        vec = K.vec_of(x.dtype)
+        N, Ho, Wo, _ = dy.shape
+        if O % vec != 0 or K.nhwc(dy)[4] % vec != 0:  # ragged classifier output (O = 19)
+            dyp = torch.zeros((N, Ho, Wo, _round_up(O, vec)), dtype=dy.dtype, device=dy.device)
+            dyp[..., :O] = dy
+            dy_full, dy = dyp, dyp[..., :O]
+        else:
+            dy_full = dy
+        Cx = x.shape[-1]
+        dWp = K.conv_wgrad(x, dy, O, KH, KW, s.stride, s.pad, s.dil, s.pro)
+        dW = dWp.view(O, KH, KW, Cx)[..., :Cw].permute(0, 3, 1, 2).contiguous()
+        dbias = None
+        if ctx.has_bias:
+            dbias = K.bn_bwd_reduce(dy_full, dy_full, (PRO_NONE, None, None))[:O].float()
+        dx = dgamma = dbeta = None
+        if ctx.needs_input_grad[0]:
+            Op = dy_full.shape[-1]
+            wt = pack_conv_weight_dgrad(weight, Op, x.dtype)
+            if s.stride == 1:
+                g, _ = K.conv_gemm(dy_full, wt, Cw, KH, KW, 1, s.dil * (KH - 1) - s.pad, s.dil)
+            elif KH == 1 and KW == 1 and s.pad == 0:
+                g, _ = K.conv_gemm(dy_full, wt, Cw, 1, 1, 1, 0, 1,
+                                   scatter=(x.shape[1], x.shape[2], s.stride))
+            else:
+                raise NotImplementedError("data gradient of a strided KxK convolution")
+            dx, dgamma, dbeta = bn_input_backward(g, x, s.bn_in, s.relu, inplace=True)
+        return dx, dgamma, dbeta, dW, dbias, None
+
+
+class _DwFn(torch.autograd.Function):
+    """nn.Conv2d(groups=C, 3x3, padding=dilation) on a deferred activation."""
+
+    @staticmethod
+    def forward(ctx, x, in_gamma, in_beta, weight, spec):
+        C = weight.shape[0]
+        w9c = weight.detach().reshape(C, 9).t().contiguous().float()
+        y, spec.partial = K.dwconv(x, w9c, spec.stride, spec.dil, spec.pro, spec.out,
+                                   spec.want_stats)
+        ctx.spec = spec
+        ctx.save_for_backward(x, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        s = ctx.spec
+        C = weight.shape[0]
+        if K.nhwc(dy)[4] % K.vec_of(dy.dtype) != 0:
+            dy = dy.contiguous()
+        dW9c = K.dwconv_wgrad(x, dy, s.stride, s.dil, s.pro)
+        dW = dW9c.t().reshape(C, 1, 3, 3).contiguous()
+        dx = dgamma = dbeta = None
+        if ctx.needs_input_grad[0]:
+            w9c = weight.detach().reshape(C, 9).t().contiguous().float()
+            g = K.dwconv_dgrad(dy, w9c, s.stride, s.dil, (x.shape[1], x.shape[2]))
+            dx, dgamma, dbeta = bn_input_backward(g, x, s.bn_in, s.relu, inplace=True)
+        return dx, dgamma, dbeta, dW, None
+
+
+class ApplySpec:
+    def __init__(self, a, r=None, chan_mul=None, post_relu=False, out=None):
+        self.bn_x, self.relu_x, self.pro_x = a.bn, a.relu, a.pro
+        if r is not None:
+            self.bn_r, self.relu_r, self.pro_r = r.bn, r.relu, r.pro
+        else:
+            self.bn_r, self.relu_r, self.pro_r = None, False, None
+        self.chan_mul, self.post_relu, self.out = chan_mul, post_relu, out
+
+
+class _ApplyFn(torch.autograd.Function):
+    """Materialise act(x)*chan_mul (+ act(r)): BN+ReLU write-out, residual add, Dropout2d."""
+
+    @staticmethod
+    def forward(ctx, x, gx, bx, r, gr, br, spec):
+        y = K.bn_apply(x, spec.pro_x, r, spec.pro_r, spec.chan_mul, spec.post_relu, spec.out)
+        ctx.spec = spec
+        ctx.has_r = r is not None
+        if spec.post_relu:
+            ctx.save_for_backward(x, r, y)
+        else:
+            ctx.save_for_backward(x, r)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        s = ctx.spec
+        if s.post_relu:
+            x, r, y = ctx.saved_tensors
+            g = K.bn_bwd_apply(g, y, (PRO_RELU, None, None))
+        else:
+            x, r = ctx.saved_tensors
+        dx, dgx, dbx = bn_input_backward(g, x, s.bn_x, s.relu_x, s.chan_mul, inplace=False)
+        dr = dgr = dbr = None
+        if ctx.has_r and ctx.needs_input_grad[3]:
+            dr, dgr, dbr = bn_input_backward(g, r, s.bn_r, s.relu_r, None, inplace=False)
+        return dx, dgx, dbx, dr, dgr, dbr, None
+
+
+class ResizeSpec:
+    def __init__(self, a, out_hw, chan_mul=None, align_corners=True, out=None):
+        self.bn, self.relu, self.pro = a.bn, a.relu, a.pro
+        self.out_hw, self.chan_mul, self.align, self.out = out_hw, chan_mul, align_corners, out
+
+
+class _BilinearFn(torch.autograd.Function):
+    """F.interpolate(mode='bilinear') of a deferred activation, NHWC -> NHWC (slice)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, spec):
+        y = K.bilinear(x, spec.out_hw, spec.pro, spec.chan_mul, spec.align, spec.out)
+        ctx.spec = spec
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        s = ctx.spec
+        N, Hi, Wi, C = x.shape
+        if Hi == 1 and Wi == 1:
+            # every output pixel copies the single input pixel: gradient = per-image column sum
+            ga = torch.stack([K.bn_bwd_reduce(g[n:n + 1], g[n:n + 1], (PRO_NONE, None, None))[:C]
+                              for n in range(N)]).to(x.dtype).view(N, 1, 1, C)
+        else:
+            ga = K.bilinear_bwd(g, (Hi, Wi), s.align)
+        dx, dgamma, dbeta = bn_input_backward(ga, x, s.bn, s.relu, s.chan_mul, inplace=True)
+        return dx, dgamma, dbeta, None
+
+
+class _LogitsFn(torch.autograd.Function):
+    """Model boundary: NHWC logits -> bilinear (align_corners=True) -> NCHW float32."""
+
+    @staticmethod
+    def forward(ctx, x, out_hw, align):
+        ctx.meta = (x.shape, x.dtype, K.nhwc(x)[4], align)
+        return K.upsample_to_nchw(x, x.shape[-1], out_hw, align)
+
+    @staticmethod
+    def backward(ctx, g):
+        shape, dtype, pitch, align = ctx.meta
+        N, Hi, Wi, C = shape
+        pitch = _round_up(C, K.vec_of(dtype))
+        gx = K.upsample_to_nchw_bwd(g, (Hi, Wi), dtype, pitch, align)
+        return gx[..., :C], None, None
+
+
+class _GapFn(torch.autograd.Function):
+    """nn.AdaptiveAvgPool2d((1,1)) of a materialised NHWC tensor -> [N,1,1,C]."""
+
+    @staticmethod
+    def forward(ctx, x):
+        N, H, W, C = x.shape
+        ctx.meta = (H, W)
+        s = torch.stack([K.bn_bwd_reduce(x[n:n + 1], x[n:n + 1], (PRO_NONE, None, None))[:C]
+                         for n in range(N)])
+        return (s / float(H * W)).to(x.dtype).view(N, 1, 1, C)
+
+    @staticmethod
+    def backward(ctx, g):
+        H, W = ctx.meta
+        gs = (g.float() / float(H * W)).to(g.dtype).contiguous()
+        return K.bilinear(gs, (H, W), None, None, True)
+
+
+class _CatFn(torch.autograd.Function):
+    """torch.cat(dim=channel) without a copy: producers already wrote their channel slices of
+    `buf`; backward hands each producer the matching slice VIEW of the gradient."""
+
+    @staticmethod
+    def forward(ctx, buf, *parts):
+        ctx.sizes = [p.shape[-1] for p in parts]
+        return buf.view(buf.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        outs, o = [], 0
+        for c in ctx.sizes:
+            outs.append(g[..., o:o + c])
+            o += c
+        return (None,) + tuple(outs)
+
+
+# ----------------------------------------------------------------------------- functional API
+def conv_bn(act, conv, bn=None, out=None):
+    """conv (nn.Conv2d, groups=1) [+ BatchNorm statistics].  Returns an Act whose BN (if any) and
+    ReLU are pending; caller sets ``.relu``."""
+    x = act.t
+    k = conv.kernel_size[0]
+    spec = ConvSpec(act, conv.stride[0], conv.padding[0], conv.dilation[0], out,
+                    want_stats=bn is not None and (bn.training or bn.running_mean is None))
+    g, b = act.params
+    y = _ConvFn.apply(x, g, b, conv.weight, conv.bias, spec)
+    if bn is None:
+        return Act(y)
+    N, Ho, Wo, _ = y.shape
+    return Act(y, finish_bn(bn, spec.partial, N * Ho * Wo))
+
+
+def dwconv_bn(act, conv, bn, out=None):
+    spec = ConvSpec(act, conv.stride[0], conv.padding[0], conv.dilation[0], out,
+                    want_stats=bn.training or bn.running_mean is None)
+    assert conv.padding[0] == conv.dilation[0] and conv.kernel_size[0] == 3
+    g, b = act.params
+    y = _DwFn.apply(act.t, g, b, conv.weight, spec)
+    N, Ho, Wo, _ = y.shape
+    return Act(y, finish_bn(bn, spec.partial, N * Ho * Wo))
+
+
+def materialize(act, residual=None, chan_mul=None, post_relu=False, out=None):
+    """-> plain NHWC tensor = act(x)*chan_mul (+ act(residual))."""
+    if act.bn is None and not act.relu and residual is None and chan_mul is None and out is None \
+            and not post_relu:
+        return act.t
+    spec = ApplySpec(act, residual, chan_mul, post_relu, out)
+    gx, bx = act.params
+    if residual is None:
+        return _ApplyFn.apply(act.t, gx, bx, None, None, None, spec)
+    gr, br = residual.params
+    return _ApplyFn.apply(act.t, gx, bx, residual.t, gr, br, spec)
+
+
+def bilinear(act, out_hw, chan_mul=None, align_corners=True, out=None):
+    spec = ResizeSpec(act, tuple(out_hw), chan_mul, align_corners, out)
+    g, b = act.params
+    return _BilinearFn.apply(act.t, g, b, spec)
+
+
+def logits_to_nchw(x, out_hw, align_corners=True):
+    return _LogitsFn.apply(x, tuple(out_hw), align_corners)
+
+
+def global_avg_pool(x):
+    return _GapFn.apply(x)
+
+
+def concat_alias(buf, parts):
+    return _CatFn.apply(buf, *parts)
+
+
+def image_to_nhwc(x, dtype):
+    """NCHW float image -> channel-padded NHWC in the compute dtype (no gradient)."""
+    return K.nchw_to_nhwc_pad(x, dtype)

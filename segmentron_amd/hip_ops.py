@@ -1,0 +1,272 @@
+"""Thin tensor-level wrappers over the C-ABI (include/segmentron_hip.h).
+
+Everything here takes raw ``torch`` CUDA(HIP) tensors purely as device-memory handles — NHWC views
+``[N, H, W, C]`` whose channel dimension may be a slice of a wider buffer — and launches on the
+current HIP stream.  No autograd, no fallbacks: a CPU tensor raises.
+"""
+import torch
+
+from ._lib import LIB
+
+PRO_NONE, PRO_RELU, PRO_AFFINE, PRO_AFFINE_RELU = 0, 1, 2, 3
+_DT = {torch.float32: 0, torch.bfloat16: 1}
+
+
+def vec_of(dtype):
+    return 8 if dtype == torch.bfloat16 else 4
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def nhwc(t):
+    """-> (N, H, W, C, ld) of an NHWC view; checks it is addressable as rows with pitch ld."""
+    if not t.is_cuda:
+        raise RuntimeError("segmentron_amd ops need HIP device tensors (no CPU fallback)")
+    if t.dim() != 4:
+        raise RuntimeError("expected NHWC 4-d tensor, got %s" % (tuple(t.shape),))
+    N, H, W, C = t.shape
+    ld = t.stride(2) if W > 1 or H > 1 or N > 1 else max(t.stride(2), C)
+    ok = t.stride(3) == 1 or C == 1
+    if W > 1:
+        ok = ok and t.stride(2) >= C
+    if H > 1:
+        ok = ok and t.stride(1) == W * ld
+    if N > 1:
+        ok = ok and t.stride(0) == H * W * ld
+    if not ok:
+        raise RuntimeError("tensor is not a dense-row NHWC view: shape %s strides %s"
+                           % (tuple(t.shape), t.stride()))
+    return N, H, W, C, ld
+
+
+def _pro(pro):
+    if pro is None:
+        return PRO_NONE, None, None
+    return pro
+
+
+def new_act(N, H, W, C, dtype, device, pitch=None):
+    """Allocate an NHWC activation [N,H,W,C] (optionally as the leading slice of pitch channels)."""
+    if pitch is None or pitch == C:
+        return torch.empty((N, H, W, C), dtype=dtype, device=device)
+    return torch.empty((N, H, W, pitch), dtype=dtype, device=device)[..., :C]
+
+
+# ----------------------------------------------------------------------------- conv (GEMM)
+def conv_out_size(Hi, k, stride, pad, dil):
+    return (Hi + 2 * pad - dil * (k - 1) - 1) // stride + 1
+
+
+def conv_gemm(x, w_packed, O, KH, KW, stride, pad, dil, pro=None, bias=None, out=None,
+              want_stats=False, scatter=None):
+    """x NHWC; w_packed [O, KH*KW*C] in x.dtype.  Returns (y, stat_partial|None).
+    scatter=(out_H, out_W, s): write output pixel (ho,wo) at (ho*s, wo*s) of a zero-filled
+    [N,out_H,out_W,O] tensor (data gradient of a strided 1x1 conv)."""
+    N, Hi, Wi, C, ldx = nhwc(x)
+    Ho, Wo = conv_out_size(Hi, KH, stride, pad, dil), conv_out_size(Wi, KW, stride, pad, dil)
+    mode, ps, pt = _pro(pro)
+    if scatter is None:
+        oH, oW, os_ = Ho, Wo, 1
+        if out is None:
+            out = torch.empty((N, Ho, Wo, O), dtype=x.dtype, device=x.device)
+    else:
+        oH, oW, os_ = scatter
+        if out is None:
+            out = torch.zeros((N, oH, oW, O), dtype=x.dtype, device=x.device)
+    ldy = nhwc(out)[4]
+    partial = None
+    if want_stats:
+        tm = LIB.query("seg_conv_gemm_tiles_m", N, Ho, Wo)
+        partial = torch.empty((tm, 2, O), dtype=torch.float32, device=x.device)
+    assert w_packed.dtype == x.dtype and w_packed.is_contiguous()
+    LIB.call("seg_conv_gemm_fwd", _DT[x.dtype], _p(x), ldx, N, Hi, Wi, C, _p(w_packed), O, KH, KW,
+             stride, pad, dil, mode, _p(ps), _p(pt), _p(bias), _p(out), ldy, Ho, Wo, oH, oW, os_,
+             _p(partial), _stream())
+    return out, partial
+
+
+def colsum(partial2d, f64=True):
+    """partial2d: fp32 [R, L] -> [L] (float64 or float32)."""
+    R, L = partial2d.shape
+    dev = partial2d.device
+    out = torch.empty(L, dtype=torch.float64 if f64 else torch.float32, device=dev)
+    ws = torch.empty(64 * L, dtype=torch.float64, device=dev) if R > 128 else None
+    LIB.call("seg_colsum", _p(partial2d), R, L, _p(out) if f64 else 0, 0 if f64 else _p(out),
+             _p(ws), _stream())
+    return out
+
+
+def conv_wgrad(x, dy, O, KH, KW, stride, pad, dil, pro=None):
+    """-> dW fp32 [O, KH*KW*C]."""
+    N, Hi, Wi, C, ldx = nhwc(x)
+    Nd, Ho, Wo, Od, lddy = nhwc(dy)
+    assert Nd == N and Od == O
+    mode, ps, pt = _pro(pro)
+    K = KH * KW * C
+    splits = LIB.query("seg_conv_gemm_wgrad_splits", _DT[x.dtype], N, Ho, Wo, O, K)
+    partial = torch.empty((splits, O * K), dtype=torch.float32, device=x.device)
+    LIB.call("seg_conv_gemm_wgrad", _DT[x.dtype], _p(x), ldx, N, Hi, Wi, C, _p(dy), lddy, Ho, Wo,
+             O, KH, KW, stride, pad, dil, mode, _p(ps), _p(pt), _p(partial), splits, _stream())
+    if splits == 1:
+        return partial.view(O, K)
+    return colsum(partial, f64=False).view(O, K)
+
+
+# ----------------------------------------------------------------------------- depthwise
+def dwconv(x, w9c, stride, dil, pro=None, out=None, want_stats=False):
+    N, Hi, Wi, C, ldx = nhwc(x)
+    Ho, Wo = conv_out_size(Hi, 3, stride, dil, dil), conv_out_size(Wi, 3, stride, dil, dil)
+    mode, ps, pt = _pro(pro)
+    if out is None:
+        out = torch.empty((N, Ho, Wo, C), dtype=x.dtype, device=x.device)
+    ldy = nhwc(out)[4]
+    gy = LIB.query("seg_dwconv_grid_y", _DT[x.dtype], C, N, Ho, Wo)
+    partial = torch.empty((gy, 2, C), dtype=torch.float32, device=x.device) if want_stats else None
+    LIB.call("seg_dwconv3x3", _DT[x.dtype], 0, _p(x), ldx, N, Hi, Wi, C, _p(w9c), stride, dil,
+             mode, _p(ps), _p(pt), _p(out), ldy, Ho, Wo, _p(partial), gy, _stream())
+    return out, partial
+
+
+def dwconv_dgrad(dy, w9c, stride, dil, in_hw):
+    N, Ho, Wo, C, lddy = nhwc(dy)
+    Hi, Wi = in_hw
+    dx = torch.empty((N, Hi, Wi, C), dtype=dy.dtype, device=dy.device)
+    gy = LIB.query("seg_dwconv_grid_y", _DT[dy.dtype], C, N, Hi, Wi)
+    LIB.call("seg_dwconv3x3", _DT[dy.dtype], 1, _p(dy), lddy, N, Ho, Wo, C, _p(w9c), stride, dil,
+             PRO_NONE, 0, 0, _p(dx), C, Hi, Wi, 0, gy, _stream())
+    return dx
+
+
+def dwconv_wgrad(x, dy, stride, dil, pro=None):
+    """-> fp32 [9, C]."""
+    N, Hi, Wi, C, ldx = nhwc(x)
+    _, Ho, Wo, _, lddy = nhwc(dy)
+    mode, ps, pt = _pro(pro)
+    gy = LIB.query("seg_dwconv_grid_y", _DT[x.dtype], C, N, Ho, Wo)
+    partial = torch.empty((gy, 9 * C), dtype=torch.float32, device=x.device)
+    LIB.call("seg_dwconv3x3_wgrad", _DT[x.dtype], _p(x), ldx, N, Hi, Wi, C, _p(dy), lddy, Ho, Wo,
+             stride, dil, mode, _p(ps), _p(pt), _p(partial), gy, _stream())
+    return colsum(partial, f64=False).view(9, C)
+
+
+# ----------------------------------------------------------------------------- batch norm
+def bn_finalize(sums, count, gamma, beta, eps, momentum, running_mean, running_var):
+    C = sums.numel() // 2
+    dev = sums.device
+    out = torch.empty((4, C), dtype=torch.float32, device=dev)
+    LIB.call("seg_bn_finalize", _p(sums), float(count), _p(gamma), _p(beta), float(eps),
+             float(momentum), _p(running_mean), _p(running_var), _p(out[0]), _p(out[1]),
+             _p(out[2]), _p(out[3]), C, _stream())
+    return out[0], out[1], out[2], out[3]  # mean, invstd, scale, shift
+
+
+def bn_eval_affine(gamma, beta, rm, rv, eps):
+    C = rm.numel()
+    out = torch.empty((2, C), dtype=torch.float32, device=rm.device)
+    LIB.call("seg_bn_eval_affine", _p(gamma), _p(beta), _p(rm), _p(rv), float(eps), _p(out[0]),
+             _p(out[1]), C, _stream())
+    return out[0], out[1]
+
+
+def bn_apply(x, pro_x=None, r=None, pro_r=None, chan_mul=None, post_relu=False, out=None):
+    N, H, W, C, ldx = nhwc(x)
+    mx, sx, tx = _pro(pro_x)
+    mr, sr, tr = _pro(pro_r)
+    if out is None:
+        out = torch.empty((N, H, W, C), dtype=x.dtype, device=x.device)
+    ldy = nhwc(out)[4]
+    ldr = nhwc(r)[4] if r is not None else 0
+    LIB.call("seg_bn_apply", _DT[x.dtype], _p(x), ldx, mx, _p(sx), _p(tx), _p(r), ldr, mr, _p(sr),
+             _p(tr), _p(chan_mul), H * W, int(post_relu), _p(out), ldy, N * H * W, C, _stream())
+    return out
+
+
+def bn_bwd_reduce(g, x, pro, chan_mul=None):
+    """-> float64 [2C]: (sum g', sum g'*x)."""
+    N, H, W, C, ldg = nhwc(g)
+    ldx = nhwc(x)[4]
+    mode, s, t = _pro(pro)
+    M = N * H * W
+    gy = LIB.query("seg_bn_bwd_grid_y", _DT[g.dtype], C, M)
+    partial = torch.empty((gy, 2 * C), dtype=torch.float32, device=g.device)
+    LIB.call("seg_bn_bwd_reduce", _DT[g.dtype], _p(g), ldg, _p(x), ldx, mode, _p(s), _p(t),
+             _p(chan_mul), H * W, M, C, _p(partial), gy, _stream())
+    return colsum(partial, f64=True)
+
+
+def bn_bwd_finalize(sums, count, mean, invstd, gamma):
+    C = mean.numel()
+    out = torch.empty((4, C), dtype=torch.float32, device=mean.device)
+    LIB.call("seg_bn_bwd_finalize", _p(sums), float(count), _p(mean), _p(invstd), _p(gamma),
+             _p(out[0]), _p(out[1]), _p(out[2]), _p(out[3]), C, _stream())
+    return out[0], out[1], out[2], out[3]  # dgamma, dbeta, c0, c1
+
+
+def bn_bwd_apply(g, x, pro, c0=None, c1=None, chan_mul=None, out=None):
+    N, H, W, C, ldg = nhwc(g)
+    ldx = nhwc(x)[4]
+    mode, s, t = _pro(pro)
+    if out is None:
+        out = torch.empty((N, H, W, C), dtype=g.dtype, device=g.device)
+    lddx = nhwc(out)[4]
+    LIB.call("seg_bn_bwd_apply", _DT[g.dtype], _p(g), ldg, _p(x), ldx, mode, _p(s), _p(t), _p(c0),
+             _p(c1), _p(chan_mul), H * W, _p(out), lddx, N * H * W, C, _stream())
+    return out
+
+
+# ----------------------------------------------------------------------------- resize
+def bilinear(x, out_hw, pro=None, chan_mul=None, align_corners=True, out=None):
+    N, Hi, Wi, C, ldx = nhwc(x)
+    Ho, Wo = out_hw
+    mode, s, t = _pro(pro)
+    if out is None:
+        out = torch.empty((N, Ho, Wo, C), dtype=x.dtype, device=x.device)
+    ldy = nhwc(out)[4]
+    LIB.call("seg_bilinear_fwd", _DT[x.dtype], _p(x), ldx, N, Hi, Wi, C, mode, _p(s), _p(t),
+             _p(chan_mul), _p(out), ldy, Ho, Wo, int(align_corners), _stream())
+    return out
+
+
+def bilinear_bwd(gy, in_hw, align_corners=True):
+    N, Ho, Wo, C, ldgy = nhwc(gy)
+    Hi, Wi = in_hw
+    gx = torch.empty((N, Hi, Wi, C), dtype=gy.dtype, device=gy.device)
+    LIB.call("seg_bilinear_bwd", _DT[gy.dtype], _p(gx), C, N, Hi, Wi, C, _p(gy), ldgy, Ho, Wo,
+             int(align_corners), _stream())
+    return gx
+
+
+def upsample_to_nchw(x, C, out_hw, align_corners=True):
+    """x: NHWC view whose first C channels are valid -> float32 NCHW [N,C,Ho,Wo]."""
+    N, Hi, Wi, _, ldx = nhwc(x)
+    Ho, Wo = out_hw
+    out = torch.empty((N, C, Ho, Wo), dtype=torch.float32, device=x.device)
+    LIB.call("seg_upsample_to_nchw", _DT[x.dtype], _p(x), ldx, N, Hi, Wi, C, _p(out), Ho, Wo,
+             int(align_corners), _stream())
+    return out
+
+
+def upsample_to_nchw_bwd(gy, in_hw, dtype, pitch, align_corners=True):
+    """gy float32 NCHW -> NHWC [N,Hi,Wi,pitch] of `dtype` (channels >= C are zero)."""
+    N, C, Ho, Wo = gy.shape
+    Hi, Wi = in_hw
+    gy = gy.contiguous()
+    gx = torch.empty((N, Hi, Wi, pitch), dtype=dtype, device=gy.device)
+    LIB.call("seg_upsample_to_nchw_bwd", _DT[dtype], _p(gx), pitch, N, Hi, Wi, C, _p(gy), Ho, Wo,
+             int(align_corners), _stream())
+    return gx
+
+
+def nchw_to_nhwc_pad(x, dtype):
+    """float32 NCHW image (C <= 16B/elem) -> NHWC [N,H,W,VEC] zero-padded."""
+    N, Cin, H, W = x.shape
+    x = x.contiguous().float()
+    y = torch.empty((N, H, W, vec_of(dtype)), dtype=dtype, device=x.device)
+    LIB.call("seg_nchw_to_nhwc_pad", _DT[dtype], _p(x), N, Cin, H, W, _p(y), _stream())
+    return y

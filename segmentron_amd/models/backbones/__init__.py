@@ -1,0 +1,2 @@
+from .build import BACKBONE_REGISTRY, get_segmentation_backbone  # noqa: F401
+from .xception import *  # noqa: F401,F403

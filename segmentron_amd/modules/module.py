@@ -1,0 +1,74 @@
+"""Composite blocks — interface of segmentron/modules/module.py:32-77 (_ASPP)."""
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+
+from .. import functional as F
+from ..config import cfg
+from .basic import SeparableConv2d
+
+__all__ = ["_ASPP"]
+
+
+class _ASPP(nn.Module):
+    """Atrous spatial pyramid pooling: image-pooling branch, 1x1 branch, three dilated separable
+    branches -> concat(1280) -> 1x1 -> BN -> ReLU -> Dropout2d (module.py:32-77).
+
+    MI355X form: c4 is materialised once (its BN+ReLU is shared by five consumers), every branch
+    writes straight into its channel slice of one [N,H,W,1280] buffer (no torch.cat copy), the
+    projection's BN+ReLU and the Dropout2d channel mask are deferred to the consumer (the
+    decoder's bilinear upsample)."""
+
+    def __init__(self, in_channels=2048, out_channels=256):
+        super().__init__()
+        output_stride = cfg.MODEL.OUTPUT_STRIDE
+        if output_stride in (16, 32):
+            dilations = [6, 12, 18]
+        elif output_stride == 8:
+            dilations = [12, 24, 36]
+        else:
+            raise NotImplementedError
+        oc = out_channels
+        self.aspp0 = nn.Sequential(OrderedDict([
+            ("conv", nn.Conv2d(in_channels, oc, 1, bias=False)), ("bn", nn.BatchNorm2d(oc)),
+            ("relu", nn.ReLU(inplace=True))]))
+        self.aspp1 = SeparableConv2d(in_channels, oc, dilation=dilations[0], relu_first=False)
+        self.aspp2 = SeparableConv2d(in_channels, oc, dilation=dilations[1], relu_first=False)
+        self.aspp3 = SeparableConv2d(in_channels, oc, dilation=dilations[2], relu_first=False)
+        self.image_pooling = nn.Sequential(OrderedDict([
+            ("gap", nn.AdaptiveAvgPool2d((1, 1))),
+            ("conv", nn.Conv2d(in_channels, oc, 1, bias=False)), ("bn", nn.BatchNorm2d(oc)),
+            ("relu", nn.ReLU(inplace=True))]))
+        self.conv = nn.Conv2d(oc * 5, oc, 1, bias=False)
+        self.bn = nn.BatchNorm2d(oc)
+        self.relu = nn.ReLU(inplace=True)
+        self.dropout = nn.Dropout2d(p=0.1)
+        self.out_channels = oc
+
+    def forward(self, c4):
+        """c4: Act.  Returns (Act [N,H,W,256] with BN+ReLU pending, Dropout2d multiplier|None)."""
+        x = F.materialize(c4)
+        N, H, W, _ = x.shape
+        oc = self.out_channels
+        xa = F.Act(x)
+        buf = torch.empty((N, H, W, 5 * oc), dtype=x.dtype, device=x.device)
+        # image pooling: gap -> 1x1 -> BN (statistics over the batch) -> ReLU -> broadcast
+        pooled = F.conv_bn(F.Act(F.global_avg_pool(x)), self.image_pooling.conv,
+                           self.image_pooling.bn)
+        pooled.relu = True
+        parts = [F.bilinear(pooled, (H, W), out=buf[..., 0:oc])]
+        b0 = F.conv_bn(xa, self.aspp0.conv, self.aspp0.bn)
+        b0.relu = True
+        parts.append(F.materialize(b0, out=buf[..., oc:2 * oc]))
+        for i, branch in enumerate((self.aspp1, self.aspp2, self.aspp3)):
+            parts.append(F.materialize(branch(xa), out=buf[..., (2 + i) * oc:(3 + i) * oc]))
+        cat = F.concat_alias(buf, parts)
+        y = F.conv_bn(F.Act(cat), self.conv, self.bn)
+        y.relu = True
+        mul = None
+        p = self.dropout.p
+        if self.training and p > 0.0:
+            keep = torch.rand((N, oc), device=x.device) >= p
+            mul = keep.float() / (1.0 - p)
+        return y, mul

@@ -1,0 +1,50 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run through gpurun)")
+
+
+def pytest_collection_modifyitems(config, items):
+    import torch
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="no HIP device in this container")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return GOLDEN
+
+
+@pytest.fixture()
+def c3_cfg():
+    """Fresh cfg for DeepLabv3+ xception65 (values of configs/cityscapes_deeplabv3_plus.yaml —
+    the yaml itself lives in the reference tree, which is absent on the GPU box)."""
+    from segmentron_amd.config import cfg, reset_cfg
+    reset_cfg()
+    cfg.update_from_list(C3_OVERRIDES)
+    cfg.PHASE = "test"
+    cfg.check_and_freeze()
+    yield cfg
+    reset_cfg()
+
+
+C3_OVERRIDES = [
+    "DATASET.NAME", "cityscape", "DATASET.MEAN", "[0.5, 0.5, 0.5]", "DATASET.STD",
+    "[0.5, 0.5, 0.5]", "TRAIN.EPOCHS", "400", "TRAIN.BATCH_SIZE", "4", "TRAIN.CROP_SIZE", "769",
+    "TEST.BATCH_SIZE", "4", "TEST.CROP_SIZE", "(1025, 2049)", "SOLVER.LR", "0.02",
+    "MODEL.MODEL_NAME", "DeepLabV3_Plus", "MODEL.BACKBONE", "xception65",
+    "MODEL.BN_EPS_FOR_ENCODER", "1e-3", "TRAIN.BACKBONE_PRETRAINED", "False",
+]

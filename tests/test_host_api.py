@@ -1,0 +1,114 @@
+"""CPU: host-side mirror of the reference interface — cfg semantics, registries, module tree /
+state_dict schema, and the C-ABI library surface."""
+import ctypes
+import json
+import os
+import re
+
+import pytest
+import torch
+
+
+def test_state_dict_schema_equals_reference(c3_cfg, golden_dir):
+    import segmentron_amd
+    model = segmentron_amd.get_segmentation_model()
+    ref = json.load(open(os.path.join(golden_dir, "c3_state_keys.json")))
+    got = [(k, list(v.shape)) for k, v in model.state_dict().items()]
+    assert got == [(k, list(s)) for k, s in ref["keys"]]
+    assert sum(p.numel() for p in model.parameters()) == ref["n_params"] == 41054899
+    assert model.decoder == ["head"] and model.nclass == 19 and model.aux is False
+    assert model.backbone == "xception65"
+
+
+def test_bn_children_stay_batchnorm_and_convert_to_syncbn(c3_cfg):
+    import segmentron_amd
+    import torch.nn as nn
+    model = segmentron_amd.get_segmentation_model()
+    bns = [m for m in model.modules() if isinstance(m, nn.BatchNorm2d)]
+    assert len(bns) == 146 and sum(b.num_features for b in bns) == 101400  # SURVEY F11 census
+    # what solver/optimizer.py:8-11 does after construction must reach the kernels (F6)
+    for _, m in model.encoder.named_modules():
+        if isinstance(m, nn.BatchNorm2d):
+            m.eps = 1e-3
+    assert model.encoder.block4.sep_conv1.block.bn_depth.eps == 1e-3
+    sync = nn.SyncBatchNorm.convert_sync_batchnorm(model)
+    assert isinstance(sync.encoder.block4.sep_conv1.block.bn_depth, nn.SyncBatchNorm)
+    assert list(sync.state_dict().keys()) == list(model.state_dict().keys())
+
+
+def test_cfg_semantics():
+    from segmentron_amd.config import cfg, reset_cfg
+    reset_cfg()
+    cfg.update_from_list(["TEST.CROP_SIZE", "(1025, 2049)", "MODEL.MODEL_NAME", "DeepLabV3_Plus",
+                          "MODEL.BACKBONE", "xception65", "DATASET.NAME", "cityscape"])
+    assert cfg.TEST.CROP_SIZE == (1025, 2049)  # strings are literal_eval'ed
+    with pytest.raises(KeyError):
+        cfg.update_from_list(["MODEL.NO_SUCH_KEY", "1"])
+    with pytest.raises(ValueError):
+        cfg.update_from_list(["MODEL.BACKBONE"])
+    cfg.check_and_freeze()
+    assert "DANET" not in cfg.MODEL and "DEEPLABV3_PLUS" in cfg.MODEL and cfg.TIME_STAMP
+    with pytest.raises(AttributeError):
+        cfg.SEED = 3
+    reset_cfg()
+    assert cfg.SEED == 1024 and not cfg.is_immutable()
+
+
+def test_cfg_reads_reference_yaml_if_present():
+    path = "/root/reference/configs/cityscapes_deeplabv3_plus.yaml"
+    if not os.path.exists(path):
+        pytest.skip("reference tree not present")
+    from segmentron_amd.config import cfg, reset_cfg
+    reset_cfg()
+    cfg.update_from_file(path)
+    assert cfg.MODEL.BACKBONE == "xception65" and cfg.MODEL.BN_EPS_FOR_ENCODER == 1e-3
+    assert cfg.TEST.CROP_SIZE == (1025, 2049) and cfg.SOLVER.LR == 0.02
+    reset_cfg()
+
+
+def test_registries():
+    from segmentron_amd.models.model_zoo import MODEL_REGISTRY
+    from segmentron_amd.models.backbones import BACKBONE_REGISTRY
+    assert "DeepLabV3_Plus" in MODEL_REGISTRY.get_list()
+    assert "xception65" in BACKBONE_REGISTRY.get_list()
+    with pytest.raises(KeyError):
+        MODEL_REGISTRY.get("deeplabv3_plus")  # lookup is case-sensitive (model_zoo.py:22)
+    with pytest.raises(AssertionError):
+        MODEL_REGISTRY.register(name="DeepLabV3_Plus")(object)
+
+
+def test_segmentron_alias_package(c3_cfg):
+    from segmentron.config import cfg as c2
+    from segmentron.models.model_zoo import get_segmentation_model, MODEL_REGISTRY  # noqa: F401
+    from segmentron.models.backbones import get_segmentation_backbone  # noqa: F401
+    from segmentron.modules import SeparableConv2d, _ASPP, _ConvBNReLU, get_norm  # noqa: F401
+    assert c2 is c3_cfg
+
+
+def test_abi_library_exports_every_declared_symbol():
+    from segmentron_amd import _lib
+    protos = _lib.parse_header()
+    assert len(protos) >= 20
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("libsegmentron_hip.so not built")
+    dll = ctypes.CDLL(_lib.LIB_PATH)
+    for name in protos:
+        assert hasattr(dll, name), name
+    # and nothing exported that the header does not declare
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True,
+                         text=True).stdout
+    exported = set(re.findall(r" T (seg_\w+)", out))
+    assert exported == set(protos), exported ^ set(protos)
+    _lib.LIB.load()
+    assert _lib.LIB.query("seg_version") >= 1
+    assert _lib.LIB.query("seg_conv_gemm_tiles_m", 2, 65, 129) == (2 * 65 * 129 + 127) // 128
+
+
+def test_product_fails_loudly_without_a_device(c3_cfg):
+    import segmentron_amd
+    if torch.cuda.is_available():
+        pytest.skip("device present")
+    model = segmentron_amd.get_segmentation_model().eval()
+    with pytest.raises(RuntimeError):
+        model(torch.zeros(1, 3, 33, 33))
