@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""bench.py — images/sec, forward+backward, DeepLabv3+ xception65 @1025x2049 on N MI355X.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One step = what tools/train.py:135-146 does per iteration on one batch: model(images) ->
+cross-entropy (ignore -1) -> backward (+ DDP gradient all-reduce and SyncBN statistics
+all-reduces when N > 1) -> SGD step, on BASELINE.json configs[2]: batch 2 per GPU, synthetic
+`randn(2,3,1025,2049)` images and `randint(0,19)` labels with 5 % ignore, random
+init weights, bf16 compute path (fp32 accumulation / statistics / master weights / logits).
+Inputs are resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
+
+roofline: the dominant kernel is the MFMA implicit-GEMM `conv_gemm_fwd_kernel` (all 1x1 / dense
+convolutions forward + all their data gradients).  `achieved` = algorithmic FLOPs
+(2 * output pixels * K * O per launch — SURVEY.md §8d counts conv MACs only) summed over its
+launches inside the timed region / summed launch durations measured with HIP events on the
+launch stream.  `traffic` is filled from profiles/ (rocprofv3 PMC pass) when available.
+
+cpu_baseline: the CPU oracle (oracle/torch_ref.py — bit-identical to the reference's module graph
+on CPU, see oracle/gen_golden.py; the reference tree itself is not on the GPU box) timed on the
+host cores of rank 0 on a bounded sample (same network, same train step, batch 2 at 385x769,
+1 warm-up + 1 timed) and scaled by the pixel ratio to 1025x2049-equivalent images/sec.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+H, W, BATCH = 1025, 2049, 2
+FLOP_FWD_BWD_PER_IMAGE = 2.50935e12   # conv FLOPs, 3x fwd - first-layer dgrad
+MFMA_BF16_PEAK = 2.5e15               # MI355X dense bf16 (MI355X_MICROARCH.md)
+
+C3 = ["DATASET.NAME", "cityscape", "TRAIN.BATCH_SIZE", str(BATCH), "TRAIN.CROP_SIZE", "769",
+      "TEST.CROP_SIZE", "(1025, 2049)", "SOLVER.LR", "0.02", "MODEL.MODEL_NAME", "DeepLabV3_Plus",
+      "MODEL.BACKBONE", "xception65", "MODEL.BN_EPS_FOR_ENCODER", "1e-3",
+      "TRAIN.BACKBONE_PRETRAINED", "False"]
+
+
+class GemmTimer:
+    """HIP-event pairs around every launch of the dominant kernel (on the launch stream)."""
+
+    def __init__(self):
+        from segmentron_amd import hip_ops
+        self.K = hip_ops
+        self.orig = hip_ops.conv_gemm
+        self.events, self.flops, self.active = [], 0.0, False
+        hip_ops.conv_gemm = self._wrapped
+
+    def _wrapped(self, x, w_packed, O, KH, KW, stride, pad, dil, *a, **kw):
+        if not self.active:
+            return self.orig(x, w_packed, O, KH, KW, stride, pad, dil, *a, **kw)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        y, p = self.orig(x, w_packed, O, KH, KW, stride, pad, dil, *a, **kw)
+        e1.record()
+        n, hi, wi, c = x.shape
+        ho = self.K.conv_out_size(hi, KH, stride, pad, dil)
+        wo = self.K.conv_out_size(wi, KW, stride, pad, dil)
+        self.flops += 2.0 * n * ho * wo * KH * KW * c * O
+        self.events.append((e0, e1))
+        return y, p
+
+    def result(self):
+        ms = sum(a.elapsed_time(b) for a, b in self.events)
+        return self.flops, ms * 1e-3, len(self.events)
+
+
+def cpu_baseline():
+    from oracle import synth, torch_ref
+    import segmentron_amd
+    h, w = 385, 769
+    torch.set_num_threads(os.cpu_count())
+    model = segmentron_amd.get_segmentation_model()
+    sd = synth.synth_like(model.state_dict(), seed=0)
+    x = synth.synth_images(BATCH, h, w, seed=0)
+    y = synth.synth_targets(BATCH, h, w, seed=0)
+    times = []
+    for _ in range(2):
+        osd = torch_ref.clone_state(sd, requires_grad=True)
+        net = torch_ref.OracleNet(osd, training=True, eps_encoder=1e-3)
+        t0 = time.perf_counter()
+        loss = torch_ref.mix_softmax_ce(net.deeplabv3_plus_xception65(x), y)
+        loss.backward()
+        times.append(time.perf_counter() - t0)
+    ratio = (h * w) / float(H * W)
+    return {"value": BATCH * ratio / times[-1], "unit": "images/sec (1025x2049-equivalent)",
+            "cores": os.cpu_count(), "kind": "port",
+            "sample": "oracle (torch CPU fp32 restatement of the reference graph) train fwd+bwd, "
+                      "batch 2 @385x769, 1 warm-up + 1 timed (%.1f s), scaled by pixel ratio %.4f"
+                      % (times[-1], ratio)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--height", type=int, default=H)
+    ap.add_argument("--width", type=int, default=W)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", init_method="env://", device_id=dev)
+
+    import segmentron_amd
+    from segmentron_amd.config import cfg, reset_cfg
+    reset_cfg()
+    cfg.update_from_list(C3)
+    cfg.PHASE = "train"
+    cfg.check_and_freeze()
+    segmentron_amd.set_compute_dtype(args.dtype)
+    torch.manual_seed(0)
+    model = segmentron_amd.get_segmentation_model()
+    for _, m in model.encoder.named_modules():  # solver/optimizer.py:18-20
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.eps = cfg.MODEL.BN_EPS_FOR_ENCODER
+    model = model.to(dev).train()
+    if world > 1:
+        model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)  # tools/train.py:76
+        model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local],
+                                                          output_device=local)
+    params = [{"params": model.parameters(), "lr": cfg.SOLVER.LR}]
+    opt = torch.optim.SGD(params, lr=cfg.SOLVER.LR, momentum=cfg.SOLVER.MOMENTUM,
+                          weight_decay=cfg.SOLVER.WEIGHT_DECAY)
+
+    g = torch.Generator().manual_seed(rank)
+    images = torch.randn(BATCH, 3, args.height, args.width, generator=g).to(dev)
+    targets = torch.randint(0, 19, (BATCH, args.height, args.width), generator=g)
+    targets[torch.rand(BATCH, args.height, args.width, generator=g) < 0.05] = -1
+    targets = targets.to(dev)
+
+    def step():
+        out = model(images)
+        loss = torch.nn.functional.cross_entropy(out[0], targets, ignore_index=-1)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        return loss
+
+    timer = GemmTimer()
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    timer.active = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    timer.active = False
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        value = world * BATCH * args.steps / elapsed
+        flops, secs, launches = timer.result()
+        achieved = flops / secs / 1e12 if secs > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get("conv_gemm_fwd_bytes_per_launch")
+        full = (args.height, args.width) == (H, W)
+        line = {
+            "metric": "images/sec fwd+bwd DeepLabv3+_xception65 @1025x2049",
+            "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "DeepLabv3+_xception65 train step (fwd + CE loss + bwd + SGD) "
+                                   "@%dx%d, batch %d/GPU (BASELINE.json configs[2])"
+                                   % (args.height, args.width, BATCH),
+                       "global_batch": world * BATCH, "bn": "SyncBN" if world > 1 else "BN",
+                       "parallelism": "dp%d" % world, "full_size": full,
+                       "loss": float(loss.item())},
+            "model_flop_fraction_of_bf16_mfma_peak":
+                value / world * FLOP_FWD_BWD_PER_IMAGE / MFMA_BF16_PEAK if full else None,
+            "roofline": {"bound": "mfma", "kernel": "conv_gemm_fwd_kernel<%s>" % args.dtype,
+                         "achieved": achieved, "peak": MFMA_BF16_PEAK / 1e12 if
+                         args.dtype == "bf16" else 157.3, "unit": "TFLOP/s",
+                         "frac": achieved / (MFMA_BF16_PEAK / 1e12 if args.dtype == "bf16"
+                                             else 157.3),
+                         "traffic": traffic, "launches_per_step": launches / max(args.steps, 1),
+                         "kernel_ms_per_step": secs * 1e3 / max(args.steps, 1)},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

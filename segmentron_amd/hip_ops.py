@@ -31,13 +31,20 @@ def nhwc(t):
     if t.dim() != 4:
         raise RuntimeError("expected NHWC 4-d tensor, got %s" % (tuple(t.shape),))
     N, H, W, C = t.shape
-    ld = t.stride(2) if W > 1 or H > 1 or N > 1 else max(t.stride(2), C)
-    ok = t.stride(3) == 1 or C == 1
+    # torch leaves arbitrary strides on size-1 dims: derive the row pitch from the innermost
+    # dimension that actually has extent
     if W > 1:
-        ok = ok and t.stride(2) >= C
-    if H > 1:
+        ld = t.stride(2)
+    elif H > 1:
+        ld = t.stride(1)
+    elif N > 1:
+        ld = t.stride(0)
+    else:
+        ld = C
+    ok = (t.stride(3) == 1 or C == 1) and ld >= C
+    if W > 1 and H > 1:
         ok = ok and t.stride(1) == W * ld
-    if N > 1:
+    if N > 1 and (H > 1 or W > 1):
         ok = ok and t.stride(0) == H * W * ld
     if not ok:
         raise RuntimeError("tensor is not a dense-row NHWC view: shape %s strides %s"

@@ -1,0 +1,47 @@
+"""Helpers for the GPU parity tests: NCHW CPU float <-> NHWC device tensors, error metrics."""
+import torch
+
+DEV = "cuda"
+
+
+def rnd(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(shape, generator=g) * scale
+
+
+def quant(x, dtype):
+    """Round a CPU fp32 tensor to what `dtype` can hold (identity for fp32)."""
+    return x.to(dtype).float()
+
+
+def to_dev_nhwc(x_nchw, dtype, pitch=None, off=0):
+    """CPU NCHW float -> device NHWC [N,H,W,C] (optionally a channel slice of a wider buffer
+    filled with NaN to catch out-of-slice reads)."""
+    n, c, h, w = x_nchw.shape
+    t = x_nchw.permute(0, 2, 3, 1).contiguous().to(dtype)
+    if pitch is None:
+        return t.to(DEV)
+    buf = torch.full((n, h, w, pitch), float("nan"), dtype=dtype)
+    buf[..., off:off + c] = t
+    return buf.to(DEV)[..., off:off + c]
+
+
+def to_cpu_nchw(t_nhwc):
+    return t_nhwc.detach().float().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+def tol(dtype):
+    """(rtol on max-normalised error, elementwise bf16 ulp factor)"""
+    return 2e-5 if dtype == torch.float32 else 6e-3
+
+
+def assert_close(got, ref, dtype, what="", scale=None, fac=1.0):
+    got, ref = got.double(), ref.double()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    assert torch.isfinite(got).all(), what + ": non-finite values"
+    s = ref.abs().max().item() if scale is None else scale
+    s = max(s, 1e-12)
+    err = (got - ref).abs().max().item() / s
+    assert err <= tol(dtype) * fac, "%s: max-normalised error %.3e > %.3e" % (what, err,
+                                                                                tol(dtype) * fac)
+    return err

@@ -1,0 +1,311 @@
+"""GPU parity, per op: every C-ABI kernel vs torch CPU float32/float64 functional ops on the same
+seeded inputs (the reference delegates exactly these ops to torch — SURVEY.md §8c).
+fp32 path: 2e-5 of the output scale (fp32 accumulation-order noise; the model-level bar is 1e-3).
+bf16 path: inputs are rounded to bf16 first, so the only error is the final bf16 rounding of the
+output (2^-8) plus accumulation order: 6e-3 of the output scale."""
+import pytest
+import torch
+import torch.nn.functional as TF
+
+from _util import DEV, assert_close, quant, rnd, to_cpu_nchw, to_dev_nhwc
+
+pytestmark = pytest.mark.gpu
+DTYPES = [torch.float32, torch.bfloat16]
+IDS = ["fp32", "bf16"]
+
+
+def K():
+    from segmentron_amd import hip_ops
+    return hip_ops
+
+
+def F():
+    from segmentron_amd import functional
+    return functional
+
+
+def _act_ref(x, mode, scale, shift):
+    if mode & 2:
+        x = x * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    if mode & 1:
+        x = torch.relu(x)
+    return x
+
+
+def _pro(mode, c, seed):
+    if not (mode & 2):
+        return (mode, None, None), None, None
+    s = torch.rand(c, generator=torch.Generator().manual_seed(seed)) + 0.5
+    t = rnd((c,), seed + 1, 0.3)
+    return (mode, s.to(DEV), t.to(DEV)), s, t
+
+
+# ------------------------------------------------------------------------------ conv GEMM fwd
+CONV_CASES = [
+    # N, H, W, C, O, k, stride, pad, dil, mode, bias, slice
+    (2, 9, 13, 72, 40, 1, 1, 0, 1, 3, False, False),
+    (2, 17, 17, 728, 728, 1, 1, 0, 1, 2, False, False),   # the dominant xception shape
+    (1, 12, 20, 256, 19, 1, 1, 0, 1, 3, True, True),      # classifier: ragged O, bias, pitch
+    (2, 11, 15, 64, 128, 1, 2, 0, 1, 1, False, False),    # strided shortcut
+    (2, 13, 11, 32, 64, 3, 1, 1, 1, 3, False, False),     # xception conv2
+    (2, 13, 11, 8, 32, 3, 2, 1, 1, 0, False, False),      # stem on channel-padded input
+    (1, 10, 14, 16, 24, 3, 1, 2, 2, 2, False, True),      # dilated dense
+    (2, 1, 1, 2048, 256, 1, 1, 0, 1, 0, False, False),    # ASPP image-pooling (M = batch)
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_gemm_fwd(case, dtype):
+    N, H, W, C, O, k, stride, pad, dil, mode, bias, sl = case
+    x = quant(rnd((N, C, H, W), 1), dtype)
+    w = quant(rnd((O, C, k, k), 2, (2.0 / (C * k * k)) ** 0.5), dtype)
+    b = rnd((O,), 3, 0.5) if bias else None
+    pro, s, t = _pro(mode, C, 4)
+    xa = _act_ref(x, mode, s, t)
+    if dtype == torch.bfloat16:
+        xa = quant(xa, dtype)  # the kernel stages the activated operand in bf16
+    ref = TF.conv2d(xa.double(), w.double(), None if b is None else b.double(), stride, pad, dil)
+    xd = to_dev_nhwc(x, dtype, pitch=C + 16 if sl else None, off=8 if sl else 0)
+    wp = F().pack_conv_weight(w.to(DEV), C, dtype)
+    Ho, Wo = ref.shape[2:]
+    out = None
+    if sl:
+        vec = 8 if dtype == torch.bfloat16 else 4
+        pitch = (O + 2 * vec - 1) // vec * vec + vec
+        out = torch.full((N, Ho, Wo, pitch), float("nan"), dtype=dtype, device=DEV)[..., vec:vec + O]
+    y, partial = K().conv_gemm(xd, wp, O, k, k, stride, pad, dil, pro,
+                               None if b is None else b.to(DEV), out, want_stats=not bias)
+    got = to_cpu_nchw(y)
+    assert_close(got, ref, dtype, "conv y")
+    if partial is not None:
+        nb = ref - (0 if b is None else b.view(1, -1, 1, 1).double())
+        sums = K().colsum(partial.view(partial.shape[0], -1)).cpu()
+        assert_close(sums[:O], nb.sum((0, 2, 3)), torch.float32, "conv sum",
+                     scale=nb.abs().sum((0, 2, 3)).max().item(), fac=5)
+        assert_close(sums[O:], (nb * nb).sum((0, 2, 3)), torch.float32, "conv sumsq", fac=5)
+    if sl:  # nothing outside the slice was touched
+        full = y.as_strided((N, Ho, Wo, pitch), y.stride(), y.storage_offset() - vec)
+        assert torch.isnan(full[..., :vec].float()).all() and torch.isnan(full[..., vec + O:].float()).all()
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+def test_conv_gemm_scatter_is_strided_dgrad(dtype):
+    """data gradient of a stride-2 1x1 conv = GEMM with transposed weights + strided scatter"""
+    N, H, W, C, O = 2, 11, 15, 64, 128
+    x = rnd((N, C, H, W), 1).requires_grad_()
+    w = quant(rnd((O, C, 1, 1), 2, 0.1), dtype)
+    y = TF.conv2d(x, w, None, 2)
+    dy = quant(rnd(tuple(y.shape), 3), dtype)
+    y.backward(dy)
+    wt = F().pack_conv_weight_dgrad(w.to(DEV), O, dtype)
+    g, _ = K().conv_gemm(to_dev_nhwc(dy, dtype), wt, C, 1, 1, 1, 0, 1, scatter=(H, W, 2))
+    assert_close(to_cpu_nchw(g), x.grad, dtype, "strided dgrad")
+
+
+# ------------------------------------------------------------------------------ conv wgrad
+WGRAD_CASES = [
+    (2, 17, 17, 728, 728, 1, 1, 0, 1, 3),
+    (2, 40, 40, 64, 128, 1, 1, 0, 1, 2),     # several pixel splits
+    (2, 11, 15, 64, 128, 1, 2, 0, 1, 1),
+    (2, 13, 11, 32, 64, 3, 1, 1, 1, 3),
+    (2, 13, 11, 8, 32, 3, 2, 1, 1, 0),
+    (1, 12, 20, 256, 19, 1, 1, 0, 1, 3),     # ragged dy channels
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+@pytest.mark.parametrize("case", WGRAD_CASES)
+def test_conv_gemm_wgrad(case, dtype):
+    N, H, W, C, O, k, stride, pad, dil, mode = case
+    x = quant(rnd((N, C, H, W), 1), dtype)
+    pro, s, t = _pro(mode, C, 4)
+    xa = _act_ref(x, mode, s, t)
+    if dtype == torch.bfloat16:
+        xa = quant(xa, dtype)
+    w = torch.zeros((O, C, k, k), dtype=torch.float64, requires_grad=True)
+    y = TF.conv2d(xa.double(), w, None, stride, pad, dil)
+    dy = quant(rnd(tuple(y.shape), 3), dtype)
+    y.backward(dy.double())
+    vec = 8 if dtype == torch.bfloat16 else 4
+    pitch = (O + vec - 1) // vec * vec
+    dyd = to_dev_nhwc(dy, dtype, pitch=pitch if pitch != O else None)
+    dW = K().conv_wgrad(to_dev_nhwc(x, dtype), dyd, O, k, k, stride, pad, dil, pro)
+    got = dW.view(O, k, k, C).permute(0, 3, 1, 2).cpu()
+    # bf16: an fp32 fma-vs-mul+add difference in the prologue can flip a bf16 rounding of a
+    # single staged element (2^-8 of that element) -> allow 4e-4 of the dW scale
+    assert_close(got, w.grad, torch.float32, "dW", fac=20)
+
+
+# ------------------------------------------------------------------------------ depthwise
+DW_CASES = [
+    # N, H, W, C, stride, dil, mode
+    (2, 17, 17, 728, 1, 1, 3),
+    (2, 17, 19, 728, 1, 1, 1),
+    (2, 21, 25, 128, 2, 1, 3),
+    (1, 23, 29, 1024, 1, 2, 2),
+    (2, 33, 37, 64, 1, 6, 3),
+    (1, 16, 40, 304, 1, 1, 0),
+    (1, 20, 24, 2048, 1, 12, 0),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+@pytest.mark.parametrize("case", DW_CASES)
+def test_dwconv_fwd_dgrad_wgrad(case, dtype):
+    N, H, W, C, stride, dil, mode = case
+    x = quant(rnd((N, C, H, W), 1), dtype)
+    w = rnd((C, 1, 3, 3), 2, 0.4)
+    pro, s, t = _pro(mode, C, 4)
+    xa = _act_ref(x, mode, s, t).double().requires_grad_()
+    wd = w.double().requires_grad_()
+    ref = TF.conv2d(xa, wd, None, stride, dil, dil, groups=C)
+    w9c = w.view(C, 9).t().contiguous().to(DEV)
+    y, partial = K().dwconv(to_dev_nhwc(x, dtype), w9c, stride, dil, pro, want_stats=True)
+    assert_close(to_cpu_nchw(y), ref.detach(), dtype, "dw y")
+    sums = K().colsum(partial.view(partial.shape[0], -1)).cpu()
+    r = ref.detach()
+    assert_close(sums[:C], r.sum((0, 2, 3)), torch.float32, "dw sum",
+                 scale=r.abs().sum((0, 2, 3)).max().item(), fac=5)
+    assert_close(sums[C:], (r * r).sum((0, 2, 3)), torch.float32, "dw sumsq", fac=5)
+    dy = quant(rnd(tuple(ref.shape), 3), dtype)
+    ref.backward(dy.double())
+    dyd = to_dev_nhwc(dy, dtype)
+    g = K().dwconv_dgrad(dyd, w9c, stride, dil, (H, W))
+    assert_close(to_cpu_nchw(g), xa.grad, dtype, "dw dgrad")
+    dW = K().dwconv_wgrad(to_dev_nhwc(x, dtype), dyd, stride, dil, pro)
+    assert_close(dW.t().reshape(C, 1, 3, 3).cpu(), wd.grad, torch.float32, "dw wgrad", fac=20)
+
+
+# ------------------------------------------------------------------------------ batch norm
+@pytest.mark.parametrize("rows", [3, 130, 5000])
+def test_colsum(rows):
+    p = rnd((rows, 77), 1)
+    out = K().colsum(p.to(DEV)).cpu()
+    assert_close(out, p.double().sum(0), torch.float32, "colsum f64", scale=p.abs().sum(0).max().item())
+    out32 = K().colsum(p.to(DEV), f64=False).cpu()
+    assert out32.dtype == torch.float32
+    assert_close(out32, p.double().sum(0), torch.float32, "colsum f32", scale=p.abs().sum(0).max().item())
+
+
+def test_bn_finalize_matches_torch_batch_norm():
+    N, C, H, W = 2, 96, 9, 11
+    x = rnd((N, C, H, W), 1) * 2 + 0.7
+    gamma, beta = torch.rand(C) + 0.5, rnd((C,), 3, 0.2)
+    rm, rv = rnd((C,), 4, 0.1), torch.rand(C) + 0.5
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    y_ref = TF.batch_norm(x, rm_ref, rv_ref, gamma, beta, True, 0.1, 1e-3)
+    sums = torch.cat([x.double().sum((0, 2, 3)), (x.double() ** 2).sum((0, 2, 3))]).to(DEV)
+    rmd, rvd = rm.to(DEV), rv.to(DEV)
+    mean, invstd, scale, shift = K().bn_finalize(sums, N * H * W, gamma.to(DEV), beta.to(DEV), 1e-3,
+                                                 0.1, rmd, rvd)
+    y = x * scale.cpu().view(1, -1, 1, 1) + shift.cpu().view(1, -1, 1, 1)
+    assert_close(y, y_ref, torch.float32, "bn y")
+    assert_close(rmd.cpu(), rm_ref, torch.float32, "running_mean")
+    assert_close(rvd.cpu(), rv_ref, torch.float32, "running_var")
+    es, et = K().bn_eval_affine(gamma.to(DEV), beta.to(DEV), rmd, rvd, 1e-3)
+    ye = TF.batch_norm(x, rm_ref, rv_ref, gamma, beta, False, 0.1, 1e-3)
+    assert_close(x * es.cpu().view(1, -1, 1, 1) + et.cpu().view(1, -1, 1, 1), ye, torch.float32, "bn eval")
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+def test_bn_apply_residual_and_channel_mask(dtype):
+    N, C, H, W = 2, 72, 7, 9
+    x, r = quant(rnd((N, C, H, W), 1), dtype), quant(rnd((N, C, H, W), 2), dtype)
+    px, sx, tx = _pro(3, C, 5)
+    pr, sr, tr = _pro(2, C, 7)
+    mul = (torch.rand(N, C) > 0.3).float() / 0.7
+    ref = _act_ref(x, 3, sx, tx) * mul.view(N, C, 1, 1) + _act_ref(r, 2, sr, tr)
+    out = torch.full((N, H, W, C + 16), float("nan"), dtype=dtype, device=DEV)[..., 8:8 + C]
+    y = K().bn_apply(to_dev_nhwc(x, dtype), px, to_dev_nhwc(r, dtype, pitch=C + 8), pr,
+                     mul.to(DEV), False, out)
+    assert_close(to_cpu_nchw(y), ref, dtype, "bn_apply")
+    y2 = K().bn_apply(to_dev_nhwc(x, dtype), px, to_dev_nhwc(r, dtype), pr, None, True)
+    assert_close(to_cpu_nchw(y2), torch.relu(_act_ref(x, 3, sx, tx) + _act_ref(r, 2, sr, tr)), dtype,
+                 "bn_apply post_relu")
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+@pytest.mark.parametrize("relu", [False, True])
+def test_bn_backward_matches_autograd(dtype, relu):
+    """relu(BN_train(x)) * mask consumed with gradient g: dx, dgamma, dbeta vs torch autograd"""
+    N, C, H, W = 2, 104, 9, 11
+    x = quant(rnd((N, C, H, W), 1) * 1.5 + 0.3, dtype)
+    gamma, beta = (torch.rand(C) + 0.5).requires_grad_(), rnd((C,), 3, 0.2).requires_grad_()
+    xr = x.double().requires_grad_()
+    y = TF.batch_norm(xr, None, None, gamma.double(), beta.double(), True, 0.1, 1e-5)
+    if relu:
+        y = torch.relu(y)
+    mul = (torch.rand(N, C) > 0.3).double() / 0.7
+    g = quant(rnd((N, C, H, W), 5), dtype)
+    (y * mul.view(N, C, 1, 1)).backward(g.double())
+    sums = torch.cat([x.double().sum((0, 2, 3)), (x.double() ** 2).sum((0, 2, 3))]).to(DEV)
+    gd, bd = gamma.detach().to(DEV), beta.detach().to(DEV)
+    mean, invstd, scale, shift = K().bn_finalize(sums, N * H * W, gd, bd, 1e-5, 0.1, None, None)
+    Fm = F()
+    bn = Fm.BNState(gd, bd, mean, invstd, scale, shift, float(N * H * W), True)
+    dx, dgamma, dbeta = Fm.bn_input_backward(to_dev_nhwc(g, dtype), to_dev_nhwc(x, dtype), bn, relu,
+                                             mul.float().to(DEV))
+    assert_close(to_cpu_nchw(dx), xr.grad, dtype, "bn dx", fac=3)
+    assert_close(dgamma.cpu(), gamma.grad, torch.float32, "dgamma", fac=20)
+    assert_close(dbeta.cpu(), beta.grad, torch.float32, "dbeta", fac=20)
+
+
+# ------------------------------------------------------------------------------ resize
+RESIZE_CASES = [(5, 9, 17, 33, True), (17, 33, 65, 129, True), (9, 13, 20, 31, False),
+                (1, 1, 5, 9, True), (12, 10, 7, 5, True)]
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+@pytest.mark.parametrize("case", RESIZE_CASES)
+def test_bilinear_fwd_bwd(case, dtype):
+    Hi, Wi, Ho, Wo, ac = case
+    N, C = 2, 40
+    x = quant(rnd((N, C, Hi, Wi), 1), dtype)
+    pro, s, t = _pro(3, C, 4)
+    xa = _act_ref(x, 3, s, t).double().requires_grad_()
+    ref = TF.interpolate(xa, size=(Ho, Wo), mode="bilinear", align_corners=ac)
+    y = K().bilinear(to_dev_nhwc(x, dtype), (Ho, Wo), pro, None, ac)
+    assert_close(to_cpu_nchw(y), ref.detach(), dtype, "bilinear fwd")
+    g = quant(rnd(tuple(ref.shape), 2), dtype)
+    ref.backward(g.double())
+    if Hi > 1:
+        gx = K().bilinear_bwd(to_dev_nhwc(g, dtype, pitch=C + 8), (Hi, Wi), ac)
+        assert_close(to_cpu_nchw(gx), xa.grad, dtype, "bilinear bwd")
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+def test_logits_upsample_to_nchw_fwd_bwd(dtype):
+    N, C, Hi, Wi, Ho, Wo = 2, 19, 9, 17, 33, 65
+    x = quant(rnd((N, C, Hi, Wi), 1), dtype).double().requires_grad_()
+    ref = TF.interpolate(x, size=(Ho, Wo), mode="bilinear", align_corners=True)
+    xd = to_dev_nhwc(x.detach().float(), dtype, pitch=32)
+    y = K().upsample_to_nchw(xd, C, (Ho, Wo), True)
+    assert y.dtype == torch.float32 and tuple(y.shape) == (N, C, Ho, Wo)
+    assert_close(y.cpu(), ref.detach(), torch.float32, "logits up", fac=3)
+    g = rnd(tuple(ref.shape), 2)
+    ref.backward(g.double())
+    vec = 8 if dtype == torch.bfloat16 else 4
+    pitch = (C + vec - 1) // vec * vec
+    gx = K().upsample_to_nchw_bwd(g.to(DEV), (Hi, Wi), dtype, pitch, True)
+    assert_close(to_cpu_nchw(gx[..., :C]), x.grad, dtype, "logits up bwd")
+    assert (gx[..., C:].float() == 0).all()
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+def test_image_to_nhwc_pad(dtype):
+    x = rnd((2, 3, 9, 11), 1)
+    y = K().nchw_to_nhwc_pad(x.to(DEV), dtype)
+    vec = 8 if dtype == torch.bfloat16 else 4
+    assert tuple(y.shape) == (2, 9, 11, vec)
+    assert_close(to_cpu_nchw(y)[:, :3], quant(x, dtype), dtype, "image")
+    assert (y[..., 3:].float() == 0).all()
+
+
+def test_errors_are_reported_not_fatal():
+    x = torch.zeros((1, 4, 4, 6), device=DEV)  # C=6 is not a multiple of the 16-byte vector
+    w = torch.zeros((8, 6), device=DEV)
+    with pytest.raises(RuntimeError, match="multiples"):
+        K().conv_gemm(x, w, 8, 1, 1, 1, 0, 1)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        K().bn_apply(torch.zeros(1, 2, 2, 8))
