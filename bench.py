@@ -20,8 +20,8 @@ launch stream.  `traffic` is filled from profiles/ (rocprofv3 PMC pass) when ava
 
 cpu_baseline: the CPU oracle (oracle/torch_ref.py — bit-identical to the reference's module graph
 on CPU, see oracle/gen_golden.py; the reference tree itself is not on the GPU box) timed on the
-host cores of rank 0 on a bounded sample (same network, same train step, batch 2 at 385x769,
-1 warm-up + 1 timed) and scaled by the pixel ratio to 1025x2049-equivalent images/sec.
+host cores of rank 0 on a bounded sample (same network, same train step, batch 2 at 257x513,
+1 warm-up + 1 timed, <= 32 threads) and scaled by the pixel ratio to 1025x2049-equivalent images/sec.
 """
 import argparse
 import json
@@ -77,8 +77,9 @@ class GemmTimer:
 def cpu_baseline():
     from oracle import synth, torch_ref
     import segmentron_amd
-    h, w = 385, 769
-    torch.set_num_threads(os.cpu_count())
+    h, w = 257, 513
+    threads = min(32, os.cpu_count() or 1)  # oneDNN collapses when oversubscribed (256-core host)
+    torch.set_num_threads(threads)
     model = segmentron_amd.get_segmentation_model()
     sd = synth.synth_like(model.state_dict(), seed=0)
     x = synth.synth_images(BATCH, h, w, seed=0)
@@ -93,9 +94,9 @@ def cpu_baseline():
         times.append(time.perf_counter() - t0)
     ratio = (h * w) / float(H * W)
     return {"value": BATCH * ratio / times[-1], "unit": "images/sec (1025x2049-equivalent)",
-            "cores": os.cpu_count(), "kind": "port",
+            "cores": threads, "host_cores": os.cpu_count(), "kind": "port",
             "sample": "oracle (torch CPU fp32 restatement of the reference graph) train fwd+bwd, "
-                      "batch 2 @385x769, 1 warm-up + 1 timed (%.1f s), scaled by pixel ratio %.4f"
+                      "batch 2 @257x513, 1 warm-up + 1 timed (%.1f s), scaled by pixel ratio %.4f"
                       % (times[-1], ratio)}
 
 

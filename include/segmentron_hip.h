@@ -86,6 +86,12 @@ int seg_colsum(const float* in, long R, int L, double* out_d, float* out_f, doub
 int seg_bn_finalize(const double* sums, double count, const float* gamma, const float* beta,
                     float eps, float momentum, float* running_mean, float* running_var,
                     float* mean, float* invstd, float* scale, float* shift, int C, void* stream);
+/* Single-process BatchNorm: the same directly from the [R][2][C] fp32 partial rows the conv /
+ * reduce kernels emit (column sum fused in, fp64).  ws: >= 128*C doubles, used when R > 1024. */
+int seg_bn_finalize_p(const float* partial, long R, double count, const float* gamma,
+                      const float* beta, float eps, float momentum, float* running_mean,
+                      float* running_var, float* mean, float* invstd, float* scale, float* shift,
+                      int C, double* ws, void* stream);
 /* eval mode: scale/shift from running statistics. */
 int seg_bn_eval_affine(const float* gamma, const float* beta, const float* rm, const float* rv,
                        float eps, float* scale, float* shift, int C, void* stream);
@@ -107,6 +113,9 @@ int seg_bn_bwd_reduce(int dtype, const void* g, long ldg, const void* x, long ld
 int seg_bn_bwd_finalize(const double* sums, double count, const float* mean, const float* invstd,
                         const float* gamma, float* dgamma, float* dbeta, float* c0, float* c1,
                         int C, void* stream);
+int seg_bn_bwd_finalize_p(const float* partial, long R, double count, const float* mean,
+                          const float* invstd, const float* gamma, float* dgamma, float* dbeta,
+                          float* c0, float* c1, int C, double* ws, void* stream);
 int seg_bn_bwd_apply(int dtype, const void* g, long ldg, const void* x, long ldx, int mode,
                      const float* scale, const float* shift, const float* c0, const float* c1,
                      const float* chan_mul, long rows_per_n, void* dx, long lddx, long M, int C,

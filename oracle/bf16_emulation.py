@@ -1,0 +1,167 @@
+"""CPU emulation of the bf16 throughput path (TEST INFRASTRUCTURE ONLY).
+
+Why this exists: the randomly-initialised DeepLabv3+/xception65 used for parity (no released
+checkpoint is reachable) is a chaotic map — rounding only the conv WEIGHTS to bf16 in the CPU
+oracle moves its logits by L2-rel 0.2-0.6 (probe recorded in DESIGN.md §Numerics), so "bf16 logits
+vs fp32 logits" says nothing about kernel correctness.  This module restates the network with
+bf16 rounding applied at exactly the points where the HIP bf16 path rounds, so the HIP result can
+be compared at a tight tolerance; the distance between THIS and the fp32 oracle is the documented
+cost of bf16 on this model.
+
+Rounding points of the HIP bf16 path (segmentron_amd/csrc):
+  * input image -> bf16 (seg_nchw_to_nhwc_pad)
+  * 1x1 / dense conv (seg_conv_gemm_fwd): activation operand = bf16(act(raw)) staged in LDS,
+    weights bf16, fp32 MFMA accumulation, BN statistics from the fp32 accumulators, raw output
+    stored as bf16(acc [+ bias])
+  * depthwise (seg_dwconv3x3): operand act(raw) kept in fp32, weights fp32, fp32 accumulation,
+    statistics from fp32, output stored bf16
+  * BN finalize in fp64 -> fp32 scale/shift;  act(x) = relu(fma(x, scale, shift)) in fp32
+  * materialise / residual add / bilinear / global pool: fp32 math, bf16 store
+  * logits upsample: bf16 in, fp32 NCHW out
+"""
+import torch
+import torch.nn.functional as F
+
+
+def r16(x):
+    return x.to(torch.bfloat16).float()
+
+
+class _A:
+    """raw (bf16-representable, NCHW fp32) + pending fp32 scale/shift + pending relu"""
+    __slots__ = ("t", "s", "b", "relu")
+
+    def __init__(self, t, s=None, b=None, relu=False):
+        self.t, self.s, self.b, self.relu = t, s, b, relu
+
+    def val(self):
+        v = self.t
+        if self.s is not None:
+            v = torch.addcmul(self.b.view(1, -1, 1, 1), v, self.s.view(1, -1, 1, 1))
+        return torch.relu(v) if self.relu else v
+
+    def with_relu(self):
+        return _A(self.t, self.s, self.b, True)
+
+
+class Bf16EmuNet:
+    def __init__(self, sd, training=False, eps_encoder=1e-3, eps_decoder=1e-5, momentum=0.1,
+                 output_stride=16, accum64=False):
+        """accum64: run every convolution's accumulation in float64 (rounded once to fp32) with
+        the SAME bf16 rounding points — the distance between accum64=False and True is the
+        network's sensitivity to fp32 accumulation order, i.e. the floor below which two correct
+        implementations of the bf16 path cannot be expected to agree on this chaotic net."""
+        assert output_stride == 16
+        self.accum64 = accum64
+        self.sd, self.training = sd, training
+        self.eps_encoder, self.eps_decoder, self.momentum = eps_encoder, eps_decoder, momentum
+
+    def _eps(self, p):
+        return self.eps_encoder if p.startswith("encoder.") else self.eps_decoder
+
+    def _bn(self, y, p):
+        """y: fp32 accumulators -> (scale, shift) like seg_bn_finalize / seg_bn_eval_affine."""
+        sd = self.sd
+        g, b = sd[p + ".weight"], sd[p + ".bias"]
+        eps = self._eps(p)
+        if self.training:
+            n = y.numel() // y.shape[1]
+            yd = y.double()
+            mean = yd.sum((0, 2, 3)) / n
+            var = ((yd * yd).sum((0, 2, 3)) / n - mean * mean).clamp_min(0)
+            invstd = 1.0 / torch.sqrt(var + eps)
+            scale = (g.double() * invstd).float()
+            shift = (b.double() - mean * g.double() * invstd).float()
+            unb = var * n / (n - 1) if n > 1 else var
+            m = self.momentum
+            sd[p + ".running_mean"] = ((1 - m) * sd[p + ".running_mean"].double() + m * mean).float()
+            sd[p + ".running_var"] = ((1 - m) * sd[p + ".running_var"].double() + m * unb).float()
+            return scale, shift
+        invstd = 1.0 / torch.sqrt(sd[p + ".running_var"] + eps)
+        return g * invstd, b - sd[p + ".running_mean"] * g * invstd
+
+    def conv(self, a, p, bnp=None, stride=1, pad=0, dil=1):
+        w = r16(self.sd[p + ".weight"])
+        if self.accum64:
+            y = F.conv2d(r16(a.val()).double(), w.double(), None, stride, pad, dil).float()
+        else:
+            y = F.conv2d(r16(a.val()), w, None, stride, pad, dil)
+        bias = self.sd.get(p + ".bias")
+        if bnp is None:
+            return _A(r16(y if bias is None else y + bias.view(1, -1, 1, 1)))
+        s, b = self._bn(y, bnp)
+        return _A(r16(y), s, b)
+
+    def dw(self, a, p, bnp, stride, dil):
+        c = a.t.shape[1]
+        if self.accum64:
+            y = F.conv2d(a.val().double(), self.sd[p + ".weight"].double(), None, stride, dil, dil,
+                         groups=c).float()
+        else:
+            y = F.conv2d(a.val(), self.sd[p + ".weight"], None, stride, dil, dil, groups=c)
+        s, b = self._bn(y, bnp)
+        return _A(r16(y), s, b)
+
+    def sep(self, a, p, stride=1, dil=1, relu_first=True):
+        q = p + ".block."
+        if relu_first:
+            d = self.dw(a.with_relu(), q + "depthwise", q + "bn_depth", stride, dil)
+            return self.conv(d, q + "pointwise", q + "bn_point")
+        d = self.dw(a, q + "depthwise", q + "bn_depth", stride, dil)
+        d.relu = True
+        o = self.conv(d, q + "pointwise", q + "bn_point")
+        o.relu = True
+        return o
+
+    def block(self, a, p, stride=1, dil=1, skip="conv", relu_first=True, low=False):
+        s1 = self.sep(a, p + ".sep_conv1", 1, dil, relu_first)
+        s2 = self.sep(s1, p + ".sep_conv2", 1, dil, relu_first)
+        res = self.sep(s2, p + ".sep_conv3", stride, dil, relu_first)
+        if skip == "conv":
+            sh = self.conv(a, p + ".conv", p + ".bn", stride)
+            out = _A(r16(res.val() + sh.val()))
+        elif skip == "sum":
+            out = _A(r16(res.val() + a.val()))
+        else:
+            out = res
+        return (out, s2) if low else out
+
+    def forward(self, x):
+        size = x.shape[2:]
+        e = "encoder."
+        a = _A(r16(x))
+        a = self.conv(a, e + "conv1", e + "bn1", 2, 1)
+        a.relu = True
+        a = self.conv(a, e + "conv2", e + "bn2", 1, 1)
+        a.relu = True
+        a = self.block(a, e + "block1", 2)
+        a, c1 = self.block(a, e + "block2", 2, low=True)
+        a, _ = self.block(a, e + "block3", 2, low=True)
+        for i in range(4, 20):
+            a = self.block(a, e + "block%d" % i, skip="sum")
+        a = self.block(a, e + "block20")
+        c4 = self.block(a, e + "block21", dil=2, skip="none", relu_first=False)
+        # ASPP
+        h = "head.aspp."
+        xm = _A(r16(c4.val()))
+        H, W = xm.t.shape[2:]
+        pooled = _A(r16((xm.t.double().sum((2, 3), keepdim=True) / (H * W)).float()))
+        pa = self.conv(pooled, h + "image_pooling.conv", h + "image_pooling.bn")
+        pa.relu = True
+        parts = [r16(pa.val().expand(-1, -1, H, W))]
+        b0 = self.conv(xm, h + "aspp0.conv", h + "aspp0.bn")
+        b0.relu = True
+        parts.append(r16(b0.val()))
+        for i, d in enumerate((6, 12, 18)):
+            parts.append(r16(self.sep(xm, h + "aspp%d" % (i + 1), 1, d, False).val()))
+        y = self.conv(_A(torch.cat(parts, 1)), h + "conv", h + "bn")
+        y.relu = True
+        # decoder
+        up = r16(F.interpolate(y.val(), c1.t.shape[2:], mode="bilinear", align_corners=True))
+        low = self.conv(c1, "head.c1_block.conv", "head.c1_block.bn")
+        low.relu = True
+        a = _A(torch.cat([up, r16(low.val())], 1))
+        a = self.sep(a, "head.block.0", relu_first=False)
+        a = self.sep(a, "head.block.1", relu_first=False)
+        logits = self.conv(a, "head.block.2")
+        return F.interpolate(logits.t, size, mode="bilinear", align_corners=True)

@@ -101,31 +101,63 @@ struct ApplyArgs {
   long M; int C, CV;
   int mode_x, mode_r, post_relu;
   long rows_per_n;
+  int cvb_log2;
 };
+
+// Row-tile mapping shared by the element-wise kernels: a thread owns ONE 16-byte channel vector
+// (so its BatchNorm parameters live in registers for the whole kernel) and walks rows with a
+// grid stride; lanes run along the channel vectors of a row (coalesced NHWC), no divisions.
+template <int VEC>
+__device__ __forceinline__ void load_affine(int mode, const float* __restrict__ s,
+                                            const float* __restrict__ t, int c0, float* sc,
+                                            float* sh) {
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) {
+    sc[k] = (mode & PRO_AFFINE) ? s[c0 + k] : 1.f;
+    sh[k] = (mode & PRO_AFFINE) ? t[c0 + k] : 0.f;
+  }
+}
+template <int VEC>
+__device__ __forceinline__ void act_regs(float* f, int mode, const float* sc, const float* sh) {
+  if (mode & PRO_AFFINE) {
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) f[k] = fmaf(f[k], sc[k], sh[k]);
+  }
+  if (mode & PRO_RELU) {
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) f[k] = fmaxf(f[k], 0.f);
+  }
+}
 
 template <typename T>
 __global__ __launch_bounds__(EW_THREADS) void bn_apply_kernel(const ApplyArgs a) {
   constexpr int VEC = Vec<T>::N;
+  const int cvb = 1 << a.cvb_log2;
+  const int cx = threadIdx.x & (cvb - 1), sy = threadIdx.x >> a.cvb_log2;
+  const int rpb = EW_THREADS >> a.cvb_log2;
+  const int cv = blockIdx.x * cvb + cx;
+  if (cv >= a.CV) return;
+  const int c0 = cv * VEC;
   const T* __restrict__ X = reinterpret_cast<const T*>(a.x);
   const T* __restrict__ R = reinterpret_cast<const T*>(a.r);
   T* __restrict__ Y = reinterpret_cast<T*>(a.y);
-  const long total = a.M * a.CV;
-  for (long i = (long)blockIdx.x * EW_THREADS + threadIdx.x; i < total;
-       i += (long)gridDim.x * EW_THREADS) {
-    const long row = i / a.CV;
-    const int c0 = (int)(i - row * a.CV) * VEC;
+  float sx[VEC], tx[VEC], sr[VEC], tr[VEC];
+  load_affine<VEC>(a.mode_x, a.sx, a.tx, c0, sx, tx);
+  load_affine<VEC>(R ? a.mode_r : 0, a.sr, a.tr, c0, sr, tr);
+  const int M = (int)a.M, step = gridDim.y * rpb;
+  for (int row = blockIdx.y * rpb + sy; row < M; row += step) {
     float f[VEC];
-    Vec<T>::unpack(ldg16(X + row * a.ldx + c0), f);
-    apply_prologue<VEC>(f, a.mode_x, a.sx, a.tx, c0);
+    Vec<T>::unpack(ldg16(X + (long)row * a.ldx + c0), f);
+    act_regs<VEC>(f, a.mode_x, sx, tx);
     if (a.chan_mul) {
-      const float* m = a.chan_mul + (row / a.rows_per_n) * a.C + c0;
+      const float* m = a.chan_mul + (long)(row / (int)a.rows_per_n) * a.C + c0;
 #pragma unroll
       for (int k = 0; k < VEC; ++k) f[k] *= m[k];
     }
     if (R) {
       float g[VEC];
-      Vec<T>::unpack(ldg16(R + row * a.ldr + c0), g);
-      apply_prologue<VEC>(g, a.mode_r, a.sr, a.tr, c0);
+      Vec<T>::unpack(ldg16(R + (long)row * a.ldr + c0), g);
+      act_regs<VEC>(g, a.mode_r, sr, tr);
 #pragma unroll
       for (int k = 0; k < VEC; ++k) f[k] += g[k];
     }
@@ -133,7 +165,7 @@ __global__ __launch_bounds__(EW_THREADS) void bn_apply_kernel(const ApplyArgs a)
 #pragma unroll
       for (int k = 0; k < VEC; ++k) f[k] = fmaxf(f[k], 0.f);
     }
-    stg16(Y + row * a.ldy + c0, Vec<T>::pack(f));
+    stg16(Y + (long)row * a.ldy + c0, Vec<T>::pack(f));
   }
 }
 
@@ -150,20 +182,21 @@ struct BwdArgs {
 };
 
 template <typename T>
-__device__ __forceinline__ void masked_grad(const BwdArgs& a, const T* G, const T* X, long row,
-                                            int c0, float* g, float* x) {
+__device__ __forceinline__ void masked_grad(const BwdArgs& a, const T* G, const T* X, int row,
+                                            int c0, const float* sc, const float* sh, float* g,
+                                            float* x) {
   constexpr int VEC = Vec<T>::N;
-  Vec<T>::unpack(ldg16(G + row * a.ldg + c0), g);
-  Vec<T>::unpack(ldg16(X + row * a.ldx + c0), x);
+  Vec<T>::unpack(ldg16(G + (long)row * a.ldg + c0), g);
+  Vec<T>::unpack(ldg16(X + (long)row * a.ldx + c0), x);
   if (a.chan_mul) {
-    const float* m = a.chan_mul + (row / a.rows_per_n) * a.C + c0;
+    const float* m = a.chan_mul + (long)(row / (int)a.rows_per_n) * a.C + c0;
 #pragma unroll
     for (int k = 0; k < VEC; ++k) g[k] *= m[k];
   }
   if (a.mode & PRO_RELU) {
 #pragma unroll
     for (int k = 0; k < VEC; ++k) {
-      const float y = (a.mode & PRO_AFFINE) ? fmaf(x[k], a.scale[c0 + k], a.shift[c0 + k]) : x[k];
+      const float y = (a.mode & PRO_AFFINE) ? fmaf(x[k], sc[k], sh[k]) : x[k];
       g[k] = y > 0.f ? g[k] : 0.f;
     }
   }
@@ -185,9 +218,12 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_reduce_kernel(const BwdArgs
 #pragma unroll
   for (int k = 0; k < VEC; ++k) s1[k] = s2[k] = 0.f;
   if (cv < a.CV) {
-    for (long row = (long)blockIdx.y * spb + sy; row < a.M; row += (long)gridDim.y * spb) {
+    float sc[VEC], sh[VEC];
+    load_affine<VEC>(a.mode, a.scale, a.shift, c0, sc, sh);
+    const int M = (int)a.M, step = gridDim.y * spb;
+    for (int row = blockIdx.y * spb + sy; row < M; row += step) {
       float g[VEC], x[VEC];
-      masked_grad<T>(a, G, X, row, c0, g, x);
+      masked_grad<T>(a, G, X, row, c0, sc, sh, g, x);
 #pragma unroll
       for (int k = 0; k < VEC; ++k) {
         s1[k] += g[k];
@@ -235,25 +271,109 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ sums, double c
 template <typename T>
 __global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_kernel(const BwdArgs a) {
   constexpr int VEC = Vec<T>::N;
+  const int cvb = 1 << a.cvb_log2;
+  const int cx = threadIdx.x & (cvb - 1), sy = threadIdx.x >> a.cvb_log2;
+  const int rpb = EW_THREADS >> a.cvb_log2;
+  const int cv = blockIdx.x * cvb + cx;
+  if (cv >= a.CV) return;
+  const int c0 = cv * VEC;
   const T* __restrict__ G = reinterpret_cast<const T*>(a.g);
   const T* __restrict__ X = reinterpret_cast<const T*>(a.x);
   T* __restrict__ DX = reinterpret_cast<T*>(a.dx);
-  const long total = a.M * a.CV;
-  for (long i = (long)blockIdx.x * EW_THREADS + threadIdx.x; i < total;
-       i += (long)gridDim.x * EW_THREADS) {
-    const long row = i / a.CV;
-    const int c0 = (int)(i - row * a.CV) * VEC;
+  float sc[VEC], sh[VEC], k0[VEC], k1[VEC];
+  load_affine<VEC>(a.mode, a.scale, a.shift, c0, sc, sh);
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) {
+    k0[k] = a.c0 ? a.c0[c0 + k] : 0.f;
+    k1[k] = a.c0 ? a.c1[c0 + k] : 0.f;
+  }
+  const int M = (int)a.M, step = gridDim.y * rpb;
+  for (int row = blockIdx.y * rpb + sy; row < M; row += step) {
     float g[VEC], x[VEC];
-    masked_grad<T>(a, G, X, row, c0, g, x);
+    masked_grad<T>(a, G, X, row, c0, sc, sh, g, x);
     if (a.mode & PRO_AFFINE) {
 #pragma unroll
-      for (int k = 0; k < VEC; ++k) {
-        g[k] *= a.scale[c0 + k];
-        if (a.c0) g[k] = g[k] - a.c0[c0 + k] - a.c1[c0 + k] * x[k];
-      }
+      for (int k = 0; k < VEC; ++k) g[k] = g[k] * sc[k] - k0[k] - k1[k] * x[k];
     }
-    stg16(DX + row * a.lddx + c0, Vec<T>::pack(g));
+    stg16(DX + (long)row * a.lddx + c0, Vec<T>::pack(g));
   }
+}
+
+// ------------------------------------------------------------------ fused partials -> finalize
+// One launch instead of colsum + colsum_f64 + finalize (non-sync BatchNorm): a block owns 32
+// channels, its 8 row groups reduce the [R][2][C] partial rows in fp64 through LDS.
+template <typename TIN>
+__device__ __forceinline__ void reduce_two_columns(const TIN* __restrict__ part, int R, int C,
+                                                   int c, int ry, int cx, double (&red)[2][8][33],
+                                                   double& s0, double& s1) {
+  double a0 = 0.0, a1 = 0.0;
+  if (c < C) {
+    for (int r = ry; r < R; r += 8) {
+      a0 += (double)part[(long)r * 2 * C + c];
+      a1 += (double)part[(long)r * 2 * C + C + c];
+    }
+  }
+  red[0][ry][cx] = a0;
+  red[1][ry][cx] = a1;
+  __syncthreads();
+  s0 = s1 = 0.0;
+  if (ry == 0) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      s0 += red[0][k][cx];
+      s1 += red[1][k][cx];
+    }
+  }
+}
+
+template <typename TIN>
+__global__ __launch_bounds__(EW_THREADS) void bn_finalize_p_kernel(
+    const TIN* __restrict__ part, int R, double count, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float eps, float momentum, float* running_mean,
+    float* running_var, float* mean_o, float* invstd_o, float* scale_o, float* shift_o, int C) {
+  __shared__ double red[2][8][33];
+  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cx;
+  double sx, sxx;
+  reduce_two_columns<TIN>(part, R, C, c, ry, cx, red, sx, sxx);
+  if (ry != 0 || c >= C) return;
+  const double mean = sx / count;
+  double var = sxx / count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const double invstd = 1.0 / sqrt(var + (double)eps);
+  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  mean_o[c] = (float)mean;
+  invstd_o[c] = (float)invstd;
+  scale_o[c] = (float)((double)g * invstd);
+  shift_o[c] = (float)((double)b - mean * (double)g * invstd);
+  if (running_mean) {
+    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+    running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * mean);
+    running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unbiased);
+  }
+}
+
+template <typename TIN>
+__global__ __launch_bounds__(EW_THREADS) void bn_bwd_finalize_p_kernel(
+    const TIN* __restrict__ part, int R, double count, const float* __restrict__ mean,
+    const float* __restrict__ invstd, const float* __restrict__ gamma, float* dgamma, float* dbeta,
+    float* c0_o, float* c1_o, int C) {
+  __shared__ double red[2][8][33];
+  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cx;
+  double sg, sgx;
+  reduce_two_columns<TIN>(part, R, C, c, ry, cx, red, sg, sgx);
+  if (ry != 0 || c >= C) return;
+  const double mu = mean[c], is = invstd[c];
+  const double dg = (sgx - mu * sg) * is;
+  const double g = gamma ? (double)gamma[c] : 1.0;
+  const double s = g * is;
+  const double m1 = sg / count, m2 = dg / count;
+  const double c1 = s * m2 * is;
+  if (dgamma) dgamma[c] = (float)dg;
+  if (dbeta) dbeta[c] = (float)sg;
+  c1_o[c] = (float)c1;
+  c0_o[c] = (float)(s * m1 - c1 * mu);
 }
 
 static int pick_cvb_log2_ew(int CV) {
@@ -267,11 +387,17 @@ static int pick_cvb_log2_ew(int CV) {
   return best;
 }
 
-static int ew_grid(long total_vec) {
-  long g = (total_vec + EW_THREADS - 1) / EW_THREADS;
-  if (g > 4096) g = 4096;
-  if (g < 1) g = 1;
-  return (int)g;
+// 2-D launch geometry of the row-tile kernels: x over channel-vector blocks, y over row groups
+static dim3 ew_grid2(int CV, long M, int& cvb_log2) {
+  cvb_log2 = pick_cvb_log2_ew(CV);
+  const int gx = (CV + (1 << cvb_log2) - 1) >> cvb_log2;
+  const int rpb = EW_THREADS >> cvb_log2;
+  long gy = (M + (long)rpb * 4 - 1) / ((long)rpb * 4);  // >= 4 rows per thread
+  long cap = 4096 / gx;
+  if (cap < 1) cap = 1;
+  if (gy > cap) gy = cap;
+  if (gy < 1) gy = 1;
+  return dim3(gx, (unsigned)gy);
 }
 
 }  // namespace seg
@@ -340,12 +466,13 @@ extern "C" int seg_bn_apply(int dtype, const void* x, long ldx, int mode_x, cons
   a.ldx = ldx; a.ldr = ldr; a.ldy = ldy; a.M = M; a.C = C; a.CV = C / vec;
   a.mode_x = mode_x; a.mode_r = mode_r; a.post_relu = post_relu;
   a.rows_per_n = rows_per_n > 0 ? rows_per_n : 1;
-  const int grid = ew_grid(M * a.CV);
+  SEG_REQUIRE(M < (1L << 31), "bn_apply: M overflows int");
+  const dim3 grid = ew_grid2(a.CV, M, a.cvb_log2);
   if (dtype == DT_BF16)
-    hipLaunchKernelGGL((bn_apply_kernel<bf16_t>), dim3(grid), dim3(EW_THREADS), 0,
+    hipLaunchKernelGGL((bn_apply_kernel<bf16_t>), grid, dim3(EW_THREADS), 0,
                        (hipStream_t)stream, a);
   else
-    hipLaunchKernelGGL((bn_apply_kernel<float>), dim3(grid), dim3(EW_THREADS), 0,
+    hipLaunchKernelGGL((bn_apply_kernel<float>), grid, dim3(EW_THREADS), 0,
                        (hipStream_t)stream, a);
   return check_launch("bn_apply");
 }
@@ -418,13 +545,61 @@ extern "C" int seg_bn_bwd_apply(int dtype, const void* g, long ldg, const void* 
   a.g = g; a.x = x; a.dx = dx; a.scale = scale; a.shift = shift; a.c0 = c0; a.c1 = c1;
   a.chan_mul = chan_mul; a.rows_per_n = rows_per_n > 0 ? rows_per_n : 1;
   a.partial = nullptr; a.ldg = ldg; a.ldx = ldx; a.lddx = lddx; a.M = M; a.C = C; a.CV = C / vec;
-  a.mode = mode; a.cvb_log2 = 0;
-  const int grid = ew_grid(M * a.CV);
+  a.mode = mode;
+  SEG_REQUIRE(M < (1L << 31), "bn_bwd_apply: M overflows int");
+  const dim3 grid = ew_grid2(a.CV, M, a.cvb_log2);
   if (dtype == DT_BF16)
-    hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t>), dim3(grid), dim3(EW_THREADS), 0,
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t>), grid, dim3(EW_THREADS), 0,
                        (hipStream_t)stream, a);
   else
-    hipLaunchKernelGGL((bn_bwd_apply_kernel<float>), dim3(grid), dim3(EW_THREADS), 0,
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<float>), grid, dim3(EW_THREADS), 0,
                        (hipStream_t)stream, a);
   return check_launch("bn_bwd_apply");
+}
+
+// Fused (non-sync) variants: partial rows [R][2][C] fp32 straight from the conv / reduce kernels.
+// ws: >= 64*2*C doubles, only touched when R > 1024 (two-level reduction).
+extern "C" int seg_bn_finalize_p(const float* partial, long R, double count, const float* gamma,
+                                 const float* beta, float eps, float momentum,
+                                 float* running_mean, float* running_var, float* mean,
+                                 float* invstd, float* scale, float* shift, int C, double* ws,
+                                 void* stream) {
+  using namespace seg;
+  SEG_REQUIRE(count >= 1.0 && C >= 1 && R >= 1, "bn_finalize_p: bad count/C/R");
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((C + 31) / 32);
+  if (R <= 1024) {
+    hipLaunchKernelGGL((bn_finalize_p_kernel<float>), grid, dim3(EW_THREADS), 0, st, partial,
+                       (int)R, count, gamma, beta, eps, momentum, running_mean, running_var, mean,
+                       invstd, scale, shift, C);
+  } else {
+    SEG_REQUIRE(ws != nullptr, "bn_finalize_p: workspace required for R=%ld", R);
+    hipLaunchKernelGGL((colsum_kernel<double>), dim3((2 * C + 31) / 32, 64), dim3(EW_THREADS), 0,
+                       st, partial, R, 2 * C, ws);
+    hipLaunchKernelGGL((bn_finalize_p_kernel<double>), grid, dim3(EW_THREADS), 0, st, ws, 64,
+                       count, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd,
+                       scale, shift, C);
+  }
+  return check_launch("bn_finalize_p");
+}
+
+extern "C" int seg_bn_bwd_finalize_p(const float* partial, long R, double count,
+                                     const float* mean, const float* invstd, const float* gamma,
+                                     float* dgamma, float* dbeta, float* c0, float* c1, int C,
+                                     double* ws, void* stream) {
+  using namespace seg;
+  SEG_REQUIRE(count >= 1.0 && C >= 1 && R >= 1, "bn_bwd_finalize_p: bad count/C/R");
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((C + 31) / 32);
+  if (R <= 1024) {
+    hipLaunchKernelGGL((bn_bwd_finalize_p_kernel<float>), grid, dim3(EW_THREADS), 0, st, partial,
+                       (int)R, count, mean, invstd, gamma, dgamma, dbeta, c0, c1, C);
+  } else {
+    SEG_REQUIRE(ws != nullptr, "bn_bwd_finalize_p: workspace required for R=%ld", R);
+    hipLaunchKernelGGL((colsum_kernel<double>), dim3((2 * C + 31) / 32, 64), dim3(EW_THREADS), 0,
+                       st, partial, R, 2 * C, ws);
+    hipLaunchKernelGGL((bn_bwd_finalize_p_kernel<double>), grid, dim3(EW_THREADS), 0, st, ws, 64,
+                       count, mean, invstd, gamma, dgamma, dbeta, c0, c1, C);
+  }
+  return check_launch("bn_bwd_finalize_p");
 }

@@ -40,7 +40,22 @@ struct DwArgs {
   long strips;        // N * Ho * ceil(Wo / TW)
 };
 
-template <typename T, int MODE>
+template <int VEC>
+__device__ __forceinline__ void dw_act(float* f, int mode, const float* sc, const float* sh) {
+  if (mode & PRO_AFFINE) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) f[i] = fmaf(f[i], sc[i], sh[i]);
+  }
+  if (mode & PRO_RELU) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) f[i] = fmaxf(f[i], 0.f);
+  }
+}
+
+// FAST: stride 1, dilation 1 (59 of the 68 xception dw layers, and every stride-1 data
+// gradient through flipped taps): per input row the TW+2 needed vectors are loaded and
+// activated ONCE and reused by the three horizontal taps (18 loads / strip instead of 36).
+template <typename T, int MODE, bool FAST>
 __global__ __launch_bounds__(DW_THREADS) void dwconv_kernel(const DwArgs a) {
   constexpr int VEC = Vec<T>::N;
   extern __shared__ __attribute__((aligned(16))) float dw_smem[];
@@ -50,21 +65,28 @@ __global__ __launch_bounds__(DW_THREADS) void dwconv_kernel(const DwArgs a) {
   const int spb = DW_THREADS >> a.cvb_log2;  // strips per block iteration
   const int cv = blockIdx.x * cvb + cx;
   const bool cok = cv < a.CV;
-  const int c0 = cv * VEC;
+  const int c0 = cok ? cv * VEC : 0;
   const T* __restrict__ X = reinterpret_cast<const T*>(a.x);
   T* __restrict__ Y = reinterpret_cast<T*>(a.y);
   const int WQ = (a.Wo + DW_TW - 1) / DW_TW;
 
+  float sc[VEC], sh[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    sc[i] = (a.pro_mode & PRO_AFFINE) ? a.pro_scale[c0 + i] : 1.f;
+    sh[i] = (a.pro_mode & PRO_AFFINE) ? a.pro_shift[c0 + i] : 0.f;
+  }
   float ssum[VEC], ssq[VEC];
 #pragma unroll
   for (int i = 0; i < VEC; ++i) ssum[i] = ssq[i] = 0.f;
 
-  for (long s = (long)blockIdx.y * spb + sy; s < a.strips; s += (long)gridDim.y * spb) {
+  const int nstrips = (int)a.strips;
+  for (int s = blockIdx.y * spb + sy; s < nstrips; s += gridDim.y * spb) {
     if (!cok) continue;
-    const int wq = (int)(s % WQ);
-    const long t = s / WQ;
-    const int ho = (int)(t % a.Ho);
-    const int n = (int)(t / a.Ho);
+    const int wq = s % WQ;
+    const int t = s / WQ;
+    const int ho = t % a.Ho;
+    const int n = t / a.Ho;
     const int w0 = wq * DW_TW;
     float acc[DW_TW][VEC];
 #pragma unroll
@@ -72,42 +94,73 @@ __global__ __launch_bounds__(DW_THREADS) void dwconv_kernel(const DwArgs a) {
 #pragma unroll
       for (int i = 0; i < VEC; ++i) acc[j][i] = 0.f;
 
+    if (FAST) {
+#pragma unroll 1
+      for (int kh = 0; kh < 3; ++kh) {
+        const int hi = ho - 1 + kh;
+        if (hi < 0 || hi >= a.Hi) continue;
+        const long rowbase = ((long)n * a.Hi + hi) * a.Wi;
+        float v[DW_TW + 2][VEC];
 #pragma unroll
-    for (int kh = 0; kh < 3; ++kh) {
-      int hi;
-      if (MODE == MODE_FWD) {
-        hi = ho * a.stride - a.pad + kh * a.dil;
-      } else {
-        const int hn = ho + a.pad - kh * a.dil;
-        if (hn < 0 || (hn % a.stride) != 0) continue;
-        hi = hn / a.stride;
-      }
-      if (hi < 0 || hi >= a.Hi) continue;
-      const long rowbase = ((long)n * a.Hi + hi) * a.Wi;
-#pragma unroll
-      for (int kw = 0; kw < 3; ++kw) {
-        float wv[VEC];
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) wv[i] = a.w[(kh * 3 + kw) * a.C + c0 + i];
-#pragma unroll
-        for (int j = 0; j < DW_TW; ++j) {
-          const int wo = w0 + j;
-          int wi;
-          bool ok = wo < a.Wo;
-          if (MODE == MODE_FWD) {
-            wi = wo * a.stride - a.pad + kw * a.dil;
+        for (int q = 0; q < DW_TW + 2; ++q) {
+          const int wi = w0 - 1 + q;
+          if (wi >= 0 && wi < a.Wi) {
+            Vec<T>::unpack(ldg16(X + (rowbase + wi) * a.ldx + c0), v[q]);
+            dw_act<VEC>(v[q], a.pro_mode, sc, sh);
           } else {
-            const int wn = wo + a.pad - kw * a.dil;
-            ok = ok && wn >= 0 && (wn % a.stride) == 0;
-            wi = wn / a.stride;
-          }
-          ok = ok && wi >= 0 && wi < a.Wi;
-          if (ok) {
-            float f[VEC];
-            Vec<T>::unpack(ldg16(X + (rowbase + wi) * a.ldx + c0), f);
-            apply_prologue<VEC>(f, a.pro_mode, a.pro_scale, a.pro_shift, c0);
 #pragma unroll
-            for (int i = 0; i < VEC; ++i) acc[j][i] = fmaf(f[i], wv[i], acc[j][i]);
+            for (int i = 0; i < VEC; ++i) v[q][i] = 0.f;
+          }
+        }
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          float wv[VEC];
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) wv[i] = a.w[(kh * 3 + kw) * a.C + c0 + i];
+#pragma unroll
+          for (int j = 0; j < DW_TW; ++j)
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) acc[j][i] = fmaf(v[j + kw][i], wv[i], acc[j][i]);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+        int hi;
+        if (MODE == MODE_FWD) {
+          hi = ho * a.stride - a.pad + kh * a.dil;
+        } else {
+          const int hn = ho + a.pad - kh * a.dil;
+          if (hn < 0 || (hn % a.stride) != 0) continue;
+          hi = hn / a.stride;
+        }
+        if (hi < 0 || hi >= a.Hi) continue;
+        const long rowbase = ((long)n * a.Hi + hi) * a.Wi;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          float wv[VEC];
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) wv[i] = a.w[(kh * 3 + kw) * a.C + c0 + i];
+#pragma unroll
+          for (int j = 0; j < DW_TW; ++j) {
+            const int wo = w0 + j;
+            int wi;
+            bool ok = wo < a.Wo;
+            if (MODE == MODE_FWD) {
+              wi = wo * a.stride - a.pad + kw * a.dil;
+            } else {
+              const int wn = wo + a.pad - kw * a.dil;
+              ok = ok && wn >= 0 && (wn % a.stride) == 0;
+              wi = wn / a.stride;
+            }
+            ok = ok && wi >= 0 && wi < a.Wi;
+            if (ok) {
+              float f[VEC];
+              Vec<T>::unpack(ldg16(X + (rowbase + wi) * a.ldx + c0), f);
+              dw_act<VEC>(f, a.pro_mode, sc, sh);
+#pragma unroll
+              for (int i = 0; i < VEC; ++i) acc[j][i] = fmaf(f[i], wv[i], acc[j][i]);
+            }
           }
         }
       }
@@ -161,7 +214,7 @@ struct DwWgradArgs {
   long strips;
 };
 
-template <typename T>
+template <typename T, bool FAST>
 __global__ __launch_bounds__(DW_THREADS) void dwconv_wgrad_kernel(const DwWgradArgs a) {
   constexpr int VEC = Vec<T>::N;
   extern __shared__ __attribute__((aligned(16))) float dw_smem[];
@@ -171,23 +224,30 @@ __global__ __launch_bounds__(DW_THREADS) void dwconv_wgrad_kernel(const DwWgradA
   const int spb = DW_THREADS >> a.cvb_log2;
   const int cv = blockIdx.x * cvb + cx;
   const bool cok = cv < a.CV;
-  const int c0 = cv * VEC;
+  const int c0 = cok ? cv * VEC : 0;
   const T* __restrict__ X = reinterpret_cast<const T*>(a.x);
   const T* __restrict__ DY = reinterpret_cast<const T*>(a.dy);
   const int WQ = (a.Wo + DW_TW - 1) / DW_TW;
 
+  float sc[VEC], sh[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    sc[i] = (a.pro_mode & PRO_AFFINE) ? a.pro_scale[c0 + i] : 1.f;
+    sh[i] = (a.pro_mode & PRO_AFFINE) ? a.pro_shift[c0 + i] : 0.f;
+  }
   float acc[9][VEC];
 #pragma unroll
   for (int k = 0; k < 9; ++k)
 #pragma unroll
     for (int i = 0; i < VEC; ++i) acc[k][i] = 0.f;
 
-  for (long s = (long)blockIdx.y * spb + sy; s < a.strips; s += (long)gridDim.y * spb) {
+  const int nstrips = (int)a.strips;
+  for (int s = blockIdx.y * spb + sy; s < nstrips; s += gridDim.y * spb) {
     if (!cok) continue;
-    const int wq = (int)(s % WQ);
-    const long t = s / WQ;
-    const int ho = (int)(t % a.Ho);
-    const int n = (int)(t / a.Ho);
+    const int wq = s % WQ;
+    const int t = s / WQ;
+    const int ho = t % a.Ho;
+    const int n = t / a.Ho;
     const int w0 = wq * DW_TW;
     const long orow = ((long)n * a.Ho + ho) * a.Wo;
     float g[DW_TW][VEC];
@@ -200,22 +260,51 @@ __global__ __launch_bounds__(DW_THREADS) void dwconv_wgrad_kernel(const DwWgradA
         for (int i = 0; i < VEC; ++i) g[j][i] = 0.f;
       }
     }
+    if (FAST) {
 #pragma unroll
-    for (int kh = 0; kh < 3; ++kh) {
-      const int hi = ho * a.stride - a.pad + kh * a.dil;
-      if (hi < 0 || hi >= a.Hi) continue;
-      const long rowbase = ((long)n * a.Hi + hi) * a.Wi;
+      for (int kh = 0; kh < 3; ++kh) {
+        const int hi = ho - 1 + kh;
+        if (hi < 0 || hi >= a.Hi) continue;
+        const long rowbase = ((long)n * a.Hi + hi) * a.Wi;
+        float v[DW_TW + 2][VEC];
 #pragma unroll
-      for (int kw = 0; kw < 3; ++kw) {
+        for (int q = 0; q < DW_TW + 2; ++q) {
+          const int wi = w0 - 1 + q;
+          if (wi >= 0 && wi < a.Wi) {
+            Vec<T>::unpack(ldg16(X + (rowbase + wi) * a.ldx + c0), v[q]);
+            dw_act<VEC>(v[q], a.pro_mode, sc, sh);
+          } else {
 #pragma unroll
-        for (int j = 0; j < DW_TW; ++j) {
-          const int wi = (w0 + j) * a.stride - a.pad + kw * a.dil;
-          if (w0 + j < a.Wo && wi >= 0 && wi < a.Wi) {
-            float f[VEC];
-            Vec<T>::unpack(ldg16(X + (rowbase + wi) * a.ldx + c0), f);
-            apply_prologue<VEC>(f, a.pro_mode, a.pro_scale, a.pro_shift, c0);
+            for (int i = 0; i < VEC; ++i) v[q][i] = 0.f;
+          }
+        }
 #pragma unroll
-            for (int i = 0; i < VEC; ++i) acc[kh * 3 + kw][i] = fmaf(f[i], g[j][i], acc[kh * 3 + kw][i]);
+        for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+          for (int j = 0; j < DW_TW; ++j)
+#pragma unroll
+            for (int i = 0; i < VEC; ++i)
+              acc[kh * 3 + kw][i] = fmaf(v[j + kw][i], g[j][i], acc[kh * 3 + kw][i]);
+      }
+    } else {
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+        const int hi = ho * a.stride - a.pad + kh * a.dil;
+        if (hi < 0 || hi >= a.Hi) continue;
+        const long rowbase = ((long)n * a.Hi + hi) * a.Wi;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+#pragma unroll
+          for (int j = 0; j < DW_TW; ++j) {
+            const int wi = (w0 + j) * a.stride - a.pad + kw * a.dil;
+            if (w0 + j < a.Wo && wi >= 0 && wi < a.Wi) {
+              float f[VEC];
+              Vec<T>::unpack(ldg16(X + (rowbase + wi) * a.ldx + c0), f);
+              dw_act<VEC>(f, a.pro_mode, sc, sh);
+#pragma unroll
+              for (int i = 0; i < VEC; ++i)
+                acc[kh * 3 + kw][i] = fmaf(f[i], g[j][i], acc[kh * 3 + kw][i]);
+            }
           }
         }
       }
@@ -265,7 +354,7 @@ extern "C" int seg_dwconv_grid_y(int dtype, int C, int N, int Ho, int Wo) {
   const long strips = (long)N * Ho * ((Wo + DW_TW - 1) / DW_TW);
   const int gx = (CV + (1 << l) - 1) >> l;
   long gy = (strips + spb - 1) / spb;
-  long cap = 4096 / gx;  // ~16 blocks per CU in total
+  long cap = 1536 / gx;  // ~6 blocks per CU; bounds the number of partial rows
   if (cap < 1) cap = 1;
   if (gy > cap) gy = cap;
   return (int)gy;
@@ -296,17 +385,18 @@ extern "C" int seg_dwconv3x3(int dtype, int mode, const void* x, long ldx, int N
   const dim3 grid(gx, grid_y);
   const size_t lds = stat_partial ? (size_t)DW_THREADS * 2 * vec * sizeof(float) : 0;
   hipStream_t st = (hipStream_t)stream;
+  SEG_REQUIRE(a.strips < (1L << 31), "dwconv3x3: too many strips");
+  const bool fast = stride == 1 && dil == 1;  // for dgrad the host passes flipped taps, mode 0
+#define SEG_DW_LAUNCH(TT, MM, FF) \
+  hipLaunchKernelGGL((dwconv_kernel<TT, MM, FF>), grid, dim3(DW_THREADS), lds, st, a)
   if (dtype == DT_BF16) {
-    if (mode == MODE_FWD)
-      hipLaunchKernelGGL((dwconv_kernel<bf16_t, MODE_FWD>), grid, dim3(DW_THREADS), lds, st, a);
-    else
-      hipLaunchKernelGGL((dwconv_kernel<bf16_t, MODE_DGRAD>), grid, dim3(DW_THREADS), lds, st, a);
+    if (mode == MODE_FWD) { if (fast) SEG_DW_LAUNCH(bf16_t, MODE_FWD, true); else SEG_DW_LAUNCH(bf16_t, MODE_FWD, false); }
+    else SEG_DW_LAUNCH(bf16_t, MODE_DGRAD, false);
   } else {
-    if (mode == MODE_FWD)
-      hipLaunchKernelGGL((dwconv_kernel<float, MODE_FWD>), grid, dim3(DW_THREADS), lds, st, a);
-    else
-      hipLaunchKernelGGL((dwconv_kernel<float, MODE_DGRAD>), grid, dim3(DW_THREADS), lds, st, a);
+    if (mode == MODE_FWD) { if (fast) SEG_DW_LAUNCH(float, MODE_FWD, true); else SEG_DW_LAUNCH(float, MODE_FWD, false); }
+    else SEG_DW_LAUNCH(float, MODE_DGRAD, false);
   }
+#undef SEG_DW_LAUNCH
   return check_launch("dwconv3x3");
 }
 
@@ -331,9 +421,14 @@ extern "C" int seg_dwconv3x3_wgrad(int dtype, const void* x, long ldx, int N, in
   const dim3 grid(gx, grid_y);
   const size_t lds = (size_t)DW_THREADS * 3 * vec * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == DT_BF16)
-    hipLaunchKernelGGL((dwconv_wgrad_kernel<bf16_t>), grid, dim3(DW_THREADS), lds, st, a);
-  else
-    hipLaunchKernelGGL((dwconv_wgrad_kernel<float>), grid, dim3(DW_THREADS), lds, st, a);
+  SEG_REQUIRE(a.strips < (1L << 31), "dwconv3x3_wgrad: too many strips");
+  const bool fast = stride == 1 && dil == 1;
+  if (dtype == DT_BF16) {
+    if (fast) hipLaunchKernelGGL((dwconv_wgrad_kernel<bf16_t, true>), grid, dim3(DW_THREADS), lds, st, a);
+    else hipLaunchKernelGGL((dwconv_wgrad_kernel<bf16_t, false>), grid, dim3(DW_THREADS), lds, st, a);
+  } else {
+    if (fast) hipLaunchKernelGGL((dwconv_wgrad_kernel<float, true>), grid, dim3(DW_THREADS), lds, st, a);
+    else hipLaunchKernelGGL((dwconv_wgrad_kernel<float, false>), grid, dim3(DW_THREADS), lds, st, a);
+  }
   return check_launch("dwconv3x3_wgrad");
 }

@@ -80,22 +80,25 @@ def finish_bn(bn, partial, count):
     if count <= 1 and _sync_group(bn) is None:
         raise ValueError("Expected more than 1 value per channel when training, got count=%d"
                          % count)
-    C = partial.shape[-1]
-    sums = K.colsum(partial.view(partial.shape[0], 2 * C))
     group = _sync_group(bn)
     cnt = float(count)
-    if group is not None:
+    momentum = bn.momentum if bn.momentum is not None else 0.1
+    track = bn.training and bn.track_running_stats and bn.running_mean is not None
+    rm, rv = (bn.running_mean, bn.running_var) if track else (None, None)
+    if group is None:
+        mean, invstd, scale, shift = K.bn_finalize_p(partial, cnt, bn.weight, bn.bias, bn.eps,
+                                                     momentum, rm, rv)
+    else:
         # SyncBN statistics exchange: ONE all-reduce of 2C float64 sums over RCCL (torch's
         # nn.SyncBatchNorm all_gathers (mean, invstd, count) per layer instead —
         # torch/nn/modules/_functions.py:49,74).  Data-parallel shards are equal-sized
         # (tools/train.py uses drop_last batches), so the global count needs no exchange.
+        C = partial.shape[-1]
+        sums = K.colsum(partial.view(partial.shape[0], 2 * C))
         dist.all_reduce(sums, group=group)
         cnt = cnt * dist.get_world_size(group)
-    momentum = bn.momentum if bn.momentum is not None else 0.1
-    track = bn.training and bn.track_running_stats and bn.running_mean is not None
-    mean, invstd, scale, shift = K.bn_finalize(
-        sums, cnt, bn.weight, bn.bias, bn.eps, momentum,
-        bn.running_mean if track else None, bn.running_var if track else None)
+        mean, invstd, scale, shift = K.bn_finalize(sums, cnt, bn.weight, bn.bias, bn.eps,
+                                                   momentum, rm, rv)
     if track and bn.num_batches_tracked is not None:
         bn.num_batches_tracked += 1
     return BNState(bn.weight, bn.bias, mean, invstd, scale, shift, cnt, True, group)
@@ -110,10 +113,14 @@ def bn_input_backward(g, x, bn, relu, chan_mul=None, inplace=False):
         dx = K.bn_bwd_apply(g, x, (mode, None, None), chan_mul=chan_mul, out=g if inplace else None)
         return dx, None, None
     pro = (mode, bn.scale, bn.shift)
-    sums = K.bn_bwd_reduce(g, x, pro, chan_mul)
-    if bn.group is not None:
+    partial = K.bn_bwd_reduce_partial(g, x, pro, chan_mul)
+    if bn.group is None:
+        dgamma, dbeta, c0, c1 = K.bn_bwd_finalize_p(partial, bn.count, bn.mean, bn.invstd,
+                                                    bn.gamma)
+    else:
+        sums = K.colsum(partial)
         dist.all_reduce(sums, group=bn.group)
-    dgamma, dbeta, c0, c1 = K.bn_bwd_finalize(sums, bn.count, bn.mean, bn.invstd, bn.gamma)
+        dgamma, dbeta, c0, c1 = K.bn_bwd_finalize(sums, bn.count, bn.mean, bn.invstd, bn.gamma)
     if not bn.training:
         c0 = c1 = None
     dx = K.bn_bwd_apply(g, x, pro, c0, c1, chan_mul, out=g if inplace else None)

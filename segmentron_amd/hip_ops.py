@@ -145,8 +145,15 @@ def dwconv_dgrad(dy, w9c, stride, dil, in_hw):
     Hi, Wi = in_hw
     dx = torch.empty((N, Hi, Wi, C), dtype=dy.dtype, device=dy.device)
     gy = LIB.query("seg_dwconv_grid_y", _DT[dy.dtype], C, N, Hi, Wi)
-    LIB.call("seg_dwconv3x3", _DT[dy.dtype], 1, _p(dy), lddy, N, Ho, Wo, C, _p(w9c), stride, dil,
-             PRO_NONE, 0, 0, _p(dx), C, Hi, Wi, 0, gy, _stream())
+    if stride == 1:
+        # stride-1 data gradient = the forward correlation with the taps flipped (same dilation,
+        # pad = dil) -> reuses the forward kernel including its sliding-window fast path
+        LIB.call("seg_dwconv3x3", _DT[dy.dtype], 0, _p(dy), lddy, N, Ho, Wo, C,
+                 _p(w9c.flip(0).contiguous()), 1, dil, PRO_NONE, 0, 0, _p(dx), C, Hi, Wi, 0, gy,
+                 _stream())
+    else:
+        LIB.call("seg_dwconv3x3", _DT[dy.dtype], 1, _p(dy), lddy, N, Ho, Wo, C, _p(w9c), stride,
+                 dil, PRO_NONE, 0, 0, _p(dx), C, Hi, Wi, 0, gy, _stream())
     return dx
 
 
@@ -194,8 +201,8 @@ def bn_apply(x, pro_x=None, r=None, pro_r=None, chan_mul=None, post_relu=False, 
     return out
 
 
-def bn_bwd_reduce(g, x, pro, chan_mul=None):
-    """-> float64 [2C]: (sum g', sum g'*x)."""
+def bn_bwd_reduce_partial(g, x, pro, chan_mul=None):
+    """-> fp32 [grid_y, 2C] per-block (sum g', sum g'*x)."""
     N, H, W, C, ldg = nhwc(g)
     ldx = nhwc(x)[4]
     mode, s, t = _pro(pro)
@@ -204,7 +211,38 @@ def bn_bwd_reduce(g, x, pro, chan_mul=None):
     partial = torch.empty((gy, 2 * C), dtype=torch.float32, device=g.device)
     LIB.call("seg_bn_bwd_reduce", _DT[g.dtype], _p(g), ldg, _p(x), ldx, mode, _p(s), _p(t),
              _p(chan_mul), H * W, M, C, _p(partial), gy, _stream())
-    return colsum(partial, f64=True)
+    return partial
+
+
+def bn_bwd_reduce(g, x, pro, chan_mul=None):
+    """-> float64 [2C]: (sum g', sum g'*x)."""
+    return colsum(bn_bwd_reduce_partial(g, x, pro, chan_mul), f64=True)
+
+
+def _ws(R, C, dev):
+    return torch.empty(128 * C, dtype=torch.float64, device=dev) if R > 1024 else None
+
+
+def bn_finalize_p(partial, count, gamma, beta, eps, momentum, running_mean, running_var):
+    """partial fp32 [R, 2, C] (or [R, 2C]) -> mean, invstd, scale, shift (one fused launch)."""
+    R = partial.shape[0]
+    C = partial.numel() // (2 * R)
+    out = torch.empty((4, C), dtype=torch.float32, device=partial.device)
+    ws = _ws(R, C, partial.device)
+    LIB.call("seg_bn_finalize_p", _p(partial), R, float(count), _p(gamma), _p(beta), float(eps),
+             float(momentum), _p(running_mean), _p(running_var), _p(out[0]), _p(out[1]),
+             _p(out[2]), _p(out[3]), C, _p(ws), _stream())
+    return out[0], out[1], out[2], out[3]
+
+
+def bn_bwd_finalize_p(partial, count, mean, invstd, gamma):
+    R = partial.shape[0]
+    C = mean.numel()
+    out = torch.empty((4, C), dtype=torch.float32, device=mean.device)
+    ws = _ws(R, C, mean.device)
+    LIB.call("seg_bn_bwd_finalize_p", _p(partial), R, float(count), _p(mean), _p(invstd),
+             _p(gamma), _p(out[0]), _p(out[1]), _p(out[2]), _p(out[3]), C, _p(ws), _stream())
+    return out[0], out[1], out[2], out[3]
 
 
 def bn_bwd_finalize(sums, count, mean, invstd, gamma):

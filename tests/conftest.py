@@ -10,6 +10,9 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
 def pytest_configure(config):
+    import torch
+    # CPU reference computations: a 256-core GPU host oversubscribes oneDNN badly
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run through gpurun)")
 
 
