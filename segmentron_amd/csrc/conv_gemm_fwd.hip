@@ -39,9 +39,9 @@ template <typename T>
 __global__ __launch_bounds__(GEMM_THREADS) void conv_gemm_fwd_kernel(const ConvGemmArgs a) {
   constexpr int VEC = Vec<T>::N;
   constexpr int BK = ROW_BYTES / (int)sizeof(T);
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TILE_BYTES];
-  unsigned char* sA = smem;
-  unsigned char* sB = smem + TILE_BYTES;
+  // two stages of (A tile, B tile): global loads for slab k+1 are in flight and its LDS image
+  // is written while slab k is being multiplied -> one barrier per slab
+  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TILE_BYTES];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -116,9 +116,10 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv_gemm_fwd_kernel(const ConvG
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   const int nk = (a.K + BK - 1) / BK;
-  load_slab(0);
-  for (int kt = 0; kt < nk; ++kt) {
+  auto stage = [&](int buf) {
     // registers -> LDS (fused BN/ReLU prologue on the activation operand; padding stays zero)
+    unsigned char* sA = smem + buf * 2 * TILE_BYTES;
+    unsigned char* sB = sA + TILE_BYTES;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       uint4 v = ra[j];
@@ -131,42 +132,78 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv_gemm_fwd_kernel(const ConvG
       *reinterpret_cast<uint4*>(sA + (rb + 32 * j) * ROW_STRIDE + vc * 16) = v;
       *reinterpret_cast<uint4*>(sB + (rb + 32 * j) * ROW_STRIDE + vc * 16) = rbv[j];
     }
-    __syncthreads();
+  };
+  load_slab(0);
+  stage(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
     if (kt + 1 < nk) load_slab(kt + 1);  // global loads in flight under the MFMAs
-    mma_slab<T>(sA, sB, wm, wn, lane, acc);
+    mma_slab<T>(smem + cur * 2 * TILE_BYTES, smem + cur * 2 * TILE_BYTES + TILE_BYTES, wm, wn,
+                lane, acc);
+    if (kt + 1 < nk) stage(cur ^ 1);
     __syncthreads();
   }
 
-  // ---- epilogue
+  // ---- epilogue: accumulators -> (bias) -> LDS (per-wave 32x64 patch, row-major) -> 16-byte
+  // coalesced stores.  Column sums for the BatchNorm statistics are taken from the registers.
   const int col = lane & 31, hh = lane >> 5;
   T* __restrict__ Y = reinterpret_cast<T*>(a.y);
   float csum[2] = {0.f, 0.f}, csq[2] = {0.f, 0.f};
+  constexpr int EP_STRIDE = 64 * (int)sizeof(T) + 16;  // bytes per staged row (+pad)
+  unsigned char* ep = smem + wave * 32 * EP_STRIDE;     // 4 waves x 32 rows
+  float bias2[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int o = n0 + wn * 64 + j * 32 + col;
-    const float bias = (a.bias != nullptr && o < a.O) ? a.bias[o] : 0.f;
+    bias2[j] = (a.bias != nullptr && o < a.O) ? a.bias[o] : 0.f;
+  }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int r = (e & 3) + 8 * (e >> 2) + 4 * hh;
-        const int p = m0 + wm * 64 + i * 32 + r;
-        const float v = acc[i][j][e] + bias;
-        csum[j] += acc[i][j][e];
-        csq[j] += acc[i][j][e] * acc[i][j][e];
-        if (p < a.M && o < a.O) {
-          long row = p;
-          if (a.out_s != 1) {
-            const int wo = p % a.Wo;
-            const int t = p / a.Wo;
-            const int ho = t % a.Ho;
-            const int n = t / a.Ho;
-            row = ((long)n * a.out_H + (long)ho * a.out_s) * a.out_W + (long)wo * a.out_s;
-          }
-          Vec<T>::store1(Y + row * a.ldy + o, v);
+        const float v = acc[i][j][e];
+        csum[j] += v;
+        csq[j] += v * v;
+        Vec<T>::store1(reinterpret_cast<T*>(ep + r * EP_STRIDE) + j * 32 + col, v + bias2[j]);
+      }
+    }
+    // each wave only touches its own patch -> wave-level ordering is enough, but the compiler
+    // needs a barrier-class fence for LDS; all four waves run this in lockstep anyway
+    __syncthreads();
+    constexpr int VPR = 64 / VEC;  // vectors per staged row
+#pragma unroll
+    for (int q = 0; q < (32 * VPR) / 64; ++q) {
+      const int idx = q * 64 + lane;
+      const int r = idx / VPR, v = idx - r * VPR;
+      const int p = m0 + wm * 64 + i * 32 + r;
+      const int o = n0 + wn * 64 + v * VEC;
+      if (p < a.M && o < a.O) {
+        long row = p;
+        if (a.out_s != 1) {
+          const int wo = p % a.Wo;
+          const int t = p / a.Wo;
+          const int ho = t % a.Ho;
+          const int n = t / a.Ho;
+          row = ((long)n * a.out_H + (long)ho * a.out_s) * a.out_W + (long)wo * a.out_s;
+        }
+        const uint4 val = *reinterpret_cast<const uint4*>(ep + r * EP_STRIDE + v * 16);
+        T* dst = Y + row * a.ldy + o;
+        if (o + VEC <= a.O) {
+          stg16(dst, val);
+        } else {  // ragged channel tail (e.g. 19 classes): never write past O
+          float f[VEC];
+          Vec<T>::unpack(val, f);
+#pragma unroll
+          for (int k = 0; k < VEC; ++k)
+            if (o + k < a.O) Vec<T>::store1(dst + k, f[k]);
         }
       }
     }
+    __syncthreads();
   }
   if (a.stat_partial != nullptr) {
     // rows beyond M were staged as zeros (after the prologue), so they add nothing.

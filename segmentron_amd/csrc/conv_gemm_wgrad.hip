@@ -68,9 +68,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv_gemm_wgrad_kernel(const Wgr
   constexpr int PG = BKP / VEC;                    // pixel groups per slab (8)
   constexpr int BPO = (128 / VEC) * PG;            // VECxVEC blocks per operand slab
   constexpr int NBLK = 2 * BPO / GEMM_THREADS;     // blocks per thread (1 bf16 / 2 f32)
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TILE_BYTES];
-  unsigned char* sA = smem;               // dY^T : [o][p]
-  unsigned char* sB = smem + TILE_BYTES;  // X^T  : [k][p]
+  // two stages of (dY^T tile [o][p], X^T tile [k][p]); one barrier per slab
+  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TILE_BYTES];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -175,21 +174,31 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv_gemm_wgrad_kernel(const Wgr
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+  auto stage = [&](int buf) {
+    unsigned char* sA = smem + buf * 2 * TILE_BYTES;
+    unsigned char* sB = sA + TILE_BYTES;
+#pragma unroll
+    for (int q = 0; q < NBLK; ++q) {
+      uint4 w[VEC];
+      Transpose<T>::run(regs[q], w);
+      unsigned char* dst = (b_op[q] == 0 ? sA : sB) + (b_v[q] * VEC) * ROW_STRIDE + b_pg[q] * 16;
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) *reinterpret_cast<uint4*>(dst + i * ROW_STRIDE) = w[i];
+    }
+  };
   if (p_begin < p_end) {
     load_slab(p_begin);
+    stage(0);
+    __syncthreads();
+    int cur = 0;
     for (int p0 = p_begin; p0 < p_end; p0 += BKP) {
-#pragma unroll
-      for (int q = 0; q < NBLK; ++q) {
-        uint4 w[VEC];
-        Transpose<T>::run(regs[q], w);
-        unsigned char* dst = (b_op[q] == 0 ? sA : sB) + (b_v[q] * VEC) * ROW_STRIDE + b_pg[q] * 16;
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) *reinterpret_cast<uint4*>(dst + i * ROW_STRIDE) = w[i];
-      }
+      const bool more = p0 + BKP < p_end;
+      if (more) load_slab(p0 + BKP);
+      mma_slab<T>(smem + cur * 2 * TILE_BYTES, smem + cur * 2 * TILE_BYTES + TILE_BYTES, wm, wn,
+                  lane, acc);
+      if (more) stage(cur ^ 1);
       __syncthreads();
-      if (p0 + BKP < p_end) load_slab(p0 + BKP);
-      mma_slab<T>(sA, sB, wm, wn, lane, acc);
-      __syncthreads();
+      cur ^= 1;
     }
   }
 
