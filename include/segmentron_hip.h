@@ -82,16 +82,19 @@ int seg_colsum(const float* in, long R, int L, double* out_d, float* out_f, doub
                void* stream);
 /* sums = [sum x (C), sum x^2 (C)] over `count` samples.  Writes mean, invstd (biased var),
  * scale = gamma*invstd, shift = beta - mean*scale; updates running stats (nullable) with the
- * unbiased variance and `momentum`. */
+ * unbiased variance and `momentum`.  mean_offset (nullable, [C]) is added to the batch mean for the
+ * running_mean update only: the per-channel constant a folded convolution (seg_fold_weights) leaves
+ * out of its stored output because the following BatchNorm cancels it. */
 int seg_bn_finalize(const double* sums, double count, const float* gamma, const float* beta,
                     float eps, float momentum, float* running_mean, float* running_var,
-                    float* mean, float* invstd, float* scale, float* shift, int C, void* stream);
+                    float* mean, float* invstd, float* scale, float* shift, int C,
+                    const float* mean_offset, void* stream);
 /* Single-process BatchNorm: the same directly from the [R][2][C] fp32 partial rows the conv /
  * reduce kernels emit (column sum fused in, fp64).  ws: >= 128*C doubles, used when R > 1024. */
 int seg_bn_finalize_p(const float* partial, long R, double count, const float* gamma,
                       const float* beta, float eps, float momentum, float* running_mean,
                       float* running_var, float* mean, float* invstd, float* scale, float* shift,
-                      int C, double* ws, void* stream);
+                      int C, const float* mean_offset, double* ws, void* stream);
 /* eval mode: scale/shift from running statistics. */
 int seg_bn_eval_affine(const float* gamma, const float* beta, const float* rm, const float* rv,
                        float eps, float* scale, float* shift, int C, void* stream);
@@ -120,6 +123,23 @@ int seg_bn_bwd_apply(int dtype, const void* g, long ldg, const void* x, long ldx
                      const float* scale, const float* shift, const float* c0, const float* c1,
                      const float* chan_mul, long rows_per_n, void* dx, long lddx, long M, int C,
                      void* stream);
+
+/* ---- linear BatchNorm folded into a 1x1 convolution -------------------------------------------
+ * `relu_first` SeparableConv2d (segmentron/modules/basic.py:46-50) has no non-linearity between
+ * bn_depth and the pointwise conv: W (s.*x + t) = (W diag(s)) x + W t.
+ * fold_weights : Wp[o][c] = W[o][c]*scale[c] (dtype), WpT = its transpose [C][O] (nullable),
+ *                bprime[o] = sum_c W[o][c]*shift[c] (nullable).  W is fp32 [O][C].
+ * fold_bwd_*   : from dWp = dY^T x_raw (fp32 [O][C]) and db = colsum(dY) (nullable = 0):
+ *                dW, then dgamma/dbeta of the folded BatchNorm and the coefficients of
+ *                dx_raw = dY Wp - c0 - c1 x_raw.  dsdt = [ds (C), dt (C)] is all-reduced by the
+ *                caller between the two calls under SyncBN. */
+int seg_fold_weights(int dtype, const float* W, const float* scale, const float* shift, void* Wp,
+                     void* WpT, float* bprime, int O, int C, void* stream);
+int seg_fold_bwd_reduce(const float* W, const float* dWp, const float* scale, const float* shift,
+                        const float* db, float* dW, float* dsdt, int O, int C, void* stream);
+int seg_fold_bwd_finalize(const float* dsdt, double count, const float* mean, const float* invstd,
+                          const float* gamma, const float* scale, float* dgamma, float* dbeta,
+                          float* c0, float* c1, int C, void* stream);
 
 /* ---- F.interpolate(mode='bilinear') ---------------------------------------------------------
  * Replaces segmentron/models/deeplabv3_plus.py:39,44,71; segmentron/modules/module.py:64,96;

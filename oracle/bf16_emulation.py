@@ -13,6 +13,9 @@ Rounding points of the HIP bf16 path (segmentron_amd/csrc):
   * 1x1 / dense conv (seg_conv_gemm_fwd): activation operand = bf16(act(raw)) staged in LDS,
     weights bf16, fp32 MFMA accumulation, BN statistics from the fp32 accumulators, raw output
     stored as bf16(acc [+ bias])
+  * 1x1 conv whose input carries a LINEAR pending BN (no ReLU; csrc/fold.hip): operand = the raw
+    bf16 tensor as stored, weights = bf16(W * scale), the constant W @ shift is dropped when a
+    training-mode BN follows (it cancels) and added as an fp32 bias otherwise
   * depthwise (seg_dwconv3x3): operand act(raw) kept in fp32, weights fp32, fp32 accumulation,
     statistics from fp32, output stored bf16
   * BN finalize in fp64 -> fp32 scale/shift;  act(x) = relu(fma(x, scale, shift)) in fp32
@@ -81,7 +84,21 @@ class Bf16EmuNet:
         return g * invstd, b - sd[p + ".running_mean"] * g * invstd
 
     def conv(self, a, p, bnp=None, stride=1, pad=0, dil=1):
-        w = r16(self.sd[p + ".weight"])
+        wf = self.sd[p + ".weight"]
+        if a.s is not None and not a.relu and wf.shape[2:] == (1, 1) and (p + ".bias") not in self.sd:
+            # folded linear BatchNorm (see module docstring)
+            w = r16(wf * a.s.view(1, -1, 1, 1))
+            conv = (lambda u, v: F.conv2d(u.double(), v.double(), None, stride).float()) \
+                if self.accum64 else (lambda u, v: F.conv2d(u, v, None, stride))
+            y = conv(a.t, w)
+            keep_const = not (bnp is not None and self.training)
+            if keep_const:
+                y = y + (wf.view(wf.shape[0], -1) @ a.b).view(1, -1, 1, 1)
+            if bnp is None:
+                return _A(r16(y))
+            s, b = self._bn(y, bnp)
+            return _A(r16(y), s, b)
+        w = r16(wf)
         if self.accum64:
             y = F.conv2d(r16(a.val()).double(), w.double(), None, stride, pad, dil).float()
         else:

@@ -60,7 +60,8 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sums, double count
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float eps, float momentum, float* running_mean,
                                    float* running_var, float* mean_o, float* invstd_o,
-                                   float* scale_o, float* shift_o, int C) {
+                                   float* scale_o, float* shift_o, int C,
+                                   const float* __restrict__ mean_offset) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   const double mean = sums[c] / count;
@@ -75,7 +76,8 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sums, double count
   shift_o[c] = (float)((double)b - mean * (double)g * invstd);
   if (running_mean) {
     const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-    running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * mean);
+    const double off = mean_offset ? (double)mean_offset[c] : 0.0;
+    running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * (mean + off));
     running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unbiased);
   }
 }
@@ -302,13 +304,14 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_kernel(const BwdArgs 
 // ------------------------------------------------------------------ fused partials -> finalize
 // One launch instead of colsum + colsum_f64 + finalize (non-sync BatchNorm): a block owns 32
 // channels, its 8 row groups reduce the [R][2][C] partial rows in fp64 through LDS.
+// block = 8 channels x 32 row groups: short serial loops (R/32) and C/8 blocks in flight
 template <typename TIN>
 __device__ __forceinline__ void reduce_two_columns(const TIN* __restrict__ part, int R, int C,
-                                                   int c, int ry, int cx, double (&red)[2][8][33],
+                                                   int c, int ry, int cx, double (&red)[2][32][9],
                                                    double& s0, double& s1) {
   double a0 = 0.0, a1 = 0.0;
   if (c < C) {
-    for (int r = ry; r < R; r += 8) {
+    for (int r = ry; r < R; r += 32) {
       a0 += (double)part[(long)r * 2 * C + c];
       a1 += (double)part[(long)r * 2 * C + C + c];
     }
@@ -319,7 +322,7 @@ __device__ __forceinline__ void reduce_two_columns(const TIN* __restrict__ part,
   s0 = s1 = 0.0;
   if (ry == 0) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 0; k < 32; ++k) {
       s0 += red[0][k][cx];
       s1 += red[1][k][cx];
     }
@@ -330,10 +333,11 @@ template <typename TIN>
 __global__ __launch_bounds__(EW_THREADS) void bn_finalize_p_kernel(
     const TIN* __restrict__ part, int R, double count, const float* __restrict__ gamma,
     const float* __restrict__ beta, float eps, float momentum, float* running_mean,
-    float* running_var, float* mean_o, float* invstd_o, float* scale_o, float* shift_o, int C) {
-  __shared__ double red[2][8][33];
-  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cx;
+    float* running_var, float* mean_o, float* invstd_o, float* scale_o, float* shift_o, int C,
+    const float* __restrict__ mean_offset) {
+  __shared__ double red[2][32][9];
+  const int cx = threadIdx.x & 7, ry = threadIdx.x >> 3;
+  const int c = blockIdx.x * 8 + cx;
   double sx, sxx;
   reduce_two_columns<TIN>(part, R, C, c, ry, cx, red, sx, sxx);
   if (ry != 0 || c >= C) return;
@@ -348,7 +352,8 @@ __global__ __launch_bounds__(EW_THREADS) void bn_finalize_p_kernel(
   shift_o[c] = (float)((double)b - mean * (double)g * invstd);
   if (running_mean) {
     const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-    running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * mean);
+    const double off = mean_offset ? (double)mean_offset[c] : 0.0;
+    running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * (mean + off));
     running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unbiased);
   }
 }
@@ -358,9 +363,9 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_finalize_p_kernel(
     const TIN* __restrict__ part, int R, double count, const float* __restrict__ mean,
     const float* __restrict__ invstd, const float* __restrict__ gamma, float* dgamma, float* dbeta,
     float* c0_o, float* c1_o, int C) {
-  __shared__ double red[2][8][33];
-  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cx;
+  __shared__ double red[2][32][9];
+  const int cx = threadIdx.x & 7, ry = threadIdx.x >> 3;
+  const int c = blockIdx.x * 8 + cx;
   double sg, sgx;
   reduce_two_columns<TIN>(part, R, C, c, ry, cx, red, sg, sgx);
   if (ry != 0 || c >= C) return;
@@ -430,12 +435,12 @@ extern "C" int seg_colsum(const float* in, long R, int L, double* out_d, float* 
 extern "C" int seg_bn_finalize(const double* sums, double count, const float* gamma,
                                const float* beta, float eps, float momentum, float* running_mean,
                                float* running_var, float* mean, float* invstd, float* scale,
-                               float* shift, int C, void* stream) {
+                               float* shift, int C, const float* mean_offset, void* stream) {
   using namespace seg;
   SEG_REQUIRE(count >= 1.0 && C >= 1, "bn_finalize: bad count/C");
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream,
                      sums, count, gamma, beta, eps, momentum, running_mean, running_var, mean,
-                     invstd, scale, shift, C);
+                     invstd, scale, shift, C, mean_offset);
   return check_launch("bn_finalize");
 }
 
@@ -562,23 +567,23 @@ extern "C" int seg_bn_bwd_apply(int dtype, const void* g, long ldg, const void* 
 extern "C" int seg_bn_finalize_p(const float* partial, long R, double count, const float* gamma,
                                  const float* beta, float eps, float momentum,
                                  float* running_mean, float* running_var, float* mean,
-                                 float* invstd, float* scale, float* shift, int C, double* ws,
-                                 void* stream) {
+                                 float* invstd, float* scale, float* shift, int C,
+                                 const float* mean_offset, double* ws, void* stream) {
   using namespace seg;
   SEG_REQUIRE(count >= 1.0 && C >= 1 && R >= 1, "bn_finalize_p: bad count/C/R");
   hipStream_t st = (hipStream_t)stream;
-  const dim3 grid((C + 31) / 32);
+  const dim3 grid((C + 7) / 8);
   if (R <= 1024) {
     hipLaunchKernelGGL((bn_finalize_p_kernel<float>), grid, dim3(EW_THREADS), 0, st, partial,
                        (int)R, count, gamma, beta, eps, momentum, running_mean, running_var, mean,
-                       invstd, scale, shift, C);
+                       invstd, scale, shift, C, mean_offset);
   } else {
     SEG_REQUIRE(ws != nullptr, "bn_finalize_p: workspace required for R=%ld", R);
     hipLaunchKernelGGL((colsum_kernel<double>), dim3((2 * C + 31) / 32, 64), dim3(EW_THREADS), 0,
                        st, partial, R, 2 * C, ws);
     hipLaunchKernelGGL((bn_finalize_p_kernel<double>), grid, dim3(EW_THREADS), 0, st, ws, 64,
                        count, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd,
-                       scale, shift, C);
+                       scale, shift, C, mean_offset);
   }
   return check_launch("bn_finalize_p");
 }
@@ -590,7 +595,7 @@ extern "C" int seg_bn_bwd_finalize_p(const float* partial, long R, double count,
   using namespace seg;
   SEG_REQUIRE(count >= 1.0 && C >= 1 && R >= 1, "bn_bwd_finalize_p: bad count/C/R");
   hipStream_t st = (hipStream_t)stream;
-  const dim3 grid((C + 31) / 32);
+  const dim3 grid((C + 7) / 8);
   if (R <= 1024) {
     hipLaunchKernelGGL((bn_bwd_finalize_p_kernel<float>), grid, dim3(EW_THREADS), 0, st, partial,
                        (int)R, count, mean, invstd, gamma, dgamma, dbeta, c0, c1, C);

@@ -227,7 +227,7 @@ extern "C" int seg_conv_gemm_wgrad_splits(int dtype, int N, int Ho, int Wo, int 
   const int bkp = dtype == DT_BF16 ? 64 : 32;
   const long M = (long)N * Ho * Wo;
   const int tiles = ((O + BM - 1) / BM) * ((K + BN - 1) / BN);
-  long want = (768 + tiles - 1) / tiles;           // ~3 blocks per CU in flight
+  long want = 512 / tiles;                         // 2 blocks/CU are resident (72 KB LDS each)
   long maxs = (M + 8 * bkp - 1) / (8 * bkp);       // at least 8 slabs per split
   if (maxs < 1) maxs = 1;
   if (want > maxs) want = maxs;

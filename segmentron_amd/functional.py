@@ -65,7 +65,7 @@ def _sync_group(bn):
     return None
 
 
-def finish_bn(bn, partial, count):
+def finish_bn(bn, partial, count, mean_offset=None):
     """Turn conv-epilogue partials into a BNState (and update running stats like torch does).
     bn: nn.BatchNorm2d / nn.SyncBatchNorm module — eps / momentum / training read NOW."""
     use_batch = bn.training or bn.running_mean is None
@@ -87,7 +87,7 @@ def finish_bn(bn, partial, count):
     rm, rv = (bn.running_mean, bn.running_var) if track else (None, None)
     if group is None:
         mean, invstd, scale, shift = K.bn_finalize_p(partial, cnt, bn.weight, bn.bias, bn.eps,
-                                                     momentum, rm, rv)
+                                                     momentum, rm, rv, mean_offset)
     else:
         # SyncBN statistics exchange: ONE all-reduce of 2C float64 sums over RCCL (torch's
         # nn.SyncBatchNorm all_gathers (mean, invstd, count) per layer instead —
@@ -98,10 +98,21 @@ def finish_bn(bn, partial, count):
         dist.all_reduce(sums, group=group)
         cnt = cnt * dist.get_world_size(group)
         mean, invstd, scale, shift = K.bn_finalize(sums, cnt, bn.weight, bn.bias, bn.eps,
-                                                   momentum, rm, rv)
+                                                   momentum, rm, rv, mean_offset)
     if track and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked += 1
+        _PENDING_COUNTERS.append(bn.num_batches_tracked)
     return BNState(bn.weight, bn.bias, mean, invstd, scale, shift, cnt, True, group)
+
+
+_PENDING_COUNTERS = []
+
+
+def flush_bn_counters():
+    """`num_batches_tracked += 1` of every BatchNorm evaluated since the last flush, as ONE
+    multi-tensor launch (the reference does 146 scalar increments per forward)."""
+    if _PENDING_COUNTERS:
+        torch._foreach_add_(_PENDING_COUNTERS, 1)
+        del _PENDING_COUNTERS[:]
 
 
 def bn_input_backward(g, x, bn, relu, chan_mul=None, inplace=False):
@@ -212,6 +223,74 @@ class _ConvFn(torch.autograd.Function):
                 raise NotImplementedError("data gradient of a strided KxK convolution")
             dx, dgamma, dbeta = bn_input_backward(g, x, s.bn_in, s.relu, inplace=True)
         return dx, dgamma, dbeta, dW, dbias, None
+
+
+_ONES = {}
+
+
+def _ones(c, device):
+    key = (c, str(device))
+    if key not in _ONES:
+        _ONES[key] = torch.ones(c, dtype=torch.float32, device=device)
+    return _ONES[key]
+
+
+class _FoldConvFn(torch.autograd.Function):
+    """1x1 conv whose input carries a LINEAR pending BatchNorm (no ReLU): the BN is folded into
+    the weights (csrc/fold.hip), so forward / weight-gradient GEMMs read the raw tensor with no
+    prologue and BatchNorm backward needs no pass over the activation."""
+
+    @staticmethod
+    def forward(ctx, x, in_gamma, in_beta, weight, spec):
+        O, C = weight.shape[0], weight.shape[1]
+        bn = spec.bn_in
+        w2d = weight.detach().view(O, C)
+        wp, wpt, bp = K.fold_weights(w2d, bn.scale, bn.shift, x.dtype,
+                                     want_transpose=ctx.needs_input_grad[0])
+        spec.mean_offset = bp
+        # a training-mode BatchNorm right after the conv cancels the constant W@shift exactly, so
+        # it is left out of the stored tensor (and only re-enters the running_mean update)
+        bias = None if spec.drop_const else bp
+        y, spec.partial = K.conv_gemm(x, wp, O, 1, 1, spec.stride, 0, 1, None, bias, spec.out,
+                                      spec.want_stats)
+        ctx.spec = spec
+        ctx.wpt = wpt
+        ctx.save_for_backward(x, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        s = ctx.spec
+        bn = s.bn_in
+        O, C = weight.shape[0], weight.shape[1]
+        if K.nhwc(dy)[4] % K.vec_of(dy.dtype) != 0:
+            dy = dy.contiguous()
+        dwp = K.conv_wgrad(x, dy, O, 1, 1, s.stride, 0, 1, None)
+        db = None
+        if not s.drop_const:  # eval-mode consumer: the constant term carries gradient
+            db = K.bn_bwd_reduce(dy, dy, (PRO_NONE, None, None))[:O].float()
+        dW, dsdt = K.fold_bwd_reduce(weight.detach().view(O, C), dwp, bn.scale, bn.shift, db)
+        if bn.group is not None:
+            dist.all_reduce(dsdt, group=bn.group)
+        dgamma, dbeta, c0, c1 = K.fold_bwd_finalize(dsdt, bn.count, bn.mean, bn.invstd, bn.gamma,
+                                                    bn.scale)
+        if bn.group is not None:
+            ws = dist.get_world_size(bn.group)
+            dgamma, dbeta = dgamma / ws, dbeta / ws
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if s.stride == 1:
+                g, _ = K.conv_gemm(dy, ctx.wpt, C, 1, 1, 1, 0, 1)
+            else:
+                g, _ = K.conv_gemm(dy, ctx.wpt, C, 1, 1, 1, 0, 1,
+                                   scatter=(x.shape[1], x.shape[2], s.stride))
+            if bn.training:
+                ones = _ones(C, x.device)
+                dx = K.bn_bwd_apply(g, x, (PRO_AFFINE, ones, ones), c0, c1, out=g)
+            else:
+                dx = g
+        return dx, dgamma, dbeta, dW.view_as(weight), None
 
 
 class _DwFn(torch.autograd.Function):
@@ -372,15 +451,23 @@ def conv_bn(act, conv, bn=None, out=None):
     """conv (nn.Conv2d, groups=1) [+ BatchNorm statistics].  Returns an Act whose BN (if any) and
     ReLU are pending; caller sets ``.relu``."""
     x = act.t
-    k = conv.kernel_size[0]
+    batch_stats = bn is not None and (bn.training or bn.running_mean is None)
     spec = ConvSpec(act, conv.stride[0], conv.padding[0], conv.dilation[0], out,
-                    want_stats=bn is not None and (bn.training or bn.running_mean is None))
+                    want_stats=batch_stats)
     g, b = act.params
-    y = _ConvFn.apply(x, g, b, conv.weight, conv.bias, spec)
+    foldable = (act.bn is not None and not act.relu and conv.kernel_size == (1, 1)
+                and conv.padding[0] == 0 and conv.bias is None)
+    if foldable:
+        spec.drop_const = batch_stats
+        y = _FoldConvFn.apply(x, g, b, conv.weight, spec)
+        offset = spec.mean_offset if batch_stats else None
+    else:
+        y = _ConvFn.apply(x, g, b, conv.weight, conv.bias, spec)
+        offset = None
     if bn is None:
         return Act(y)
     N, Ho, Wo, _ = y.shape
-    return Act(y, finish_bn(bn, spec.partial, N * Ho * Wo))
+    return Act(y, finish_bn(bn, spec.partial, N * Ho * Wo, offset))
 
 
 def dwconv_bn(act, conv, bn, out=None):

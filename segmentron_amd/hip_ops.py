@@ -170,13 +170,14 @@ def dwconv_wgrad(x, dy, stride, dil, pro=None):
 
 
 # ----------------------------------------------------------------------------- batch norm
-def bn_finalize(sums, count, gamma, beta, eps, momentum, running_mean, running_var):
+def bn_finalize(sums, count, gamma, beta, eps, momentum, running_mean, running_var,
+                mean_offset=None):
     C = sums.numel() // 2
     dev = sums.device
     out = torch.empty((4, C), dtype=torch.float32, device=dev)
     LIB.call("seg_bn_finalize", _p(sums), float(count), _p(gamma), _p(beta), float(eps),
              float(momentum), _p(running_mean), _p(running_var), _p(out[0]), _p(out[1]),
-             _p(out[2]), _p(out[3]), C, _stream())
+             _p(out[2]), _p(out[3]), C, _p(mean_offset), _stream())
     return out[0], out[1], out[2], out[3]  # mean, invstd, scale, shift
 
 
@@ -223,7 +224,8 @@ def _ws(R, C, dev):
     return torch.empty(128 * C, dtype=torch.float64, device=dev) if R > 1024 else None
 
 
-def bn_finalize_p(partial, count, gamma, beta, eps, momentum, running_mean, running_var):
+def bn_finalize_p(partial, count, gamma, beta, eps, momentum, running_mean, running_var,
+                  mean_offset=None):
     """partial fp32 [R, 2, C] (or [R, 2C]) -> mean, invstd, scale, shift (one fused launch)."""
     R = partial.shape[0]
     C = partial.numel() // (2 * R)
@@ -231,7 +233,7 @@ def bn_finalize_p(partial, count, gamma, beta, eps, momentum, running_mean, runn
     ws = _ws(R, C, partial.device)
     LIB.call("seg_bn_finalize_p", _p(partial), R, float(count), _p(gamma), _p(beta), float(eps),
              float(momentum), _p(running_mean), _p(running_var), _p(out[0]), _p(out[1]),
-             _p(out[2]), _p(out[3]), C, _p(ws), _stream())
+             _p(out[2]), _p(out[3]), C, _p(mean_offset), _p(ws), _stream())
     return out[0], out[1], out[2], out[3]
 
 
@@ -263,6 +265,37 @@ def bn_bwd_apply(g, x, pro, c0=None, c1=None, chan_mul=None, out=None):
     LIB.call("seg_bn_bwd_apply", _DT[g.dtype], _p(g), ldg, _p(x), ldx, mode, _p(s), _p(t), _p(c0),
              _p(c1), _p(chan_mul), H * W, _p(out), lddx, N * H * W, C, _stream())
     return out
+
+
+# ----------------------------------------------------------------------------- BN fold
+def fold_weights(w2d, scale, shift, dtype, want_transpose=False, want_bias=True):
+    """fp32 W [O,C] -> (W*scale in dtype, its transpose [C,O] or None, W@shift fp32 or None)."""
+    O, C = w2d.shape
+    dev = w2d.device
+    wp = torch.empty((O, C), dtype=dtype, device=dev)
+    wpt = torch.empty((C, O), dtype=dtype, device=dev) if want_transpose else None
+    bp = torch.empty(O, dtype=torch.float32, device=dev) if want_bias else None
+    LIB.call("seg_fold_weights", _DT[dtype], _p(w2d), _p(scale), _p(shift), _p(wp), _p(wpt),
+             _p(bp), O, C, _stream())
+    return wp, wpt, bp
+
+
+def fold_bwd_reduce(w2d, dwp, scale, shift, db=None):
+    """-> (dW fp32 [O,C], dsdt fp32 [2C])."""
+    O, C = w2d.shape
+    dW = torch.empty((O, C), dtype=torch.float32, device=w2d.device)
+    dsdt = torch.empty(2 * C, dtype=torch.float32, device=w2d.device)
+    LIB.call("seg_fold_bwd_reduce", _p(w2d), _p(dwp), _p(scale), _p(shift), _p(db), _p(dW),
+             _p(dsdt), O, C, _stream())
+    return dW, dsdt
+
+
+def fold_bwd_finalize(dsdt, count, mean, invstd, gamma, scale):
+    C = mean.numel()
+    out = torch.empty((4, C), dtype=torch.float32, device=mean.device)
+    LIB.call("seg_fold_bwd_finalize", _p(dsdt), float(count), _p(mean), _p(invstd), _p(gamma),
+             _p(scale), _p(out[0]), _p(out[1]), _p(out[2]), _p(out[3]), C, _stream())
+    return out[0], out[1], out[2], out[3]  # dgamma, dbeta, c0, c1
 
 
 # ----------------------------------------------------------------------------- resize

@@ -32,6 +32,7 @@ class DeepLabV3Plus(SegBaseModel):
         size = x.shape[2:]
         c1, _, c3, c4 = self.encoder(x)
         y = self.head(c4, c1)  # NHWC logits at c1 resolution
+        F.flush_bn_counters()
         return (F.logits_to_nchw(y, size, align_corners=True),)
 
 
