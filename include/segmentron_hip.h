@@ -39,12 +39,15 @@ int seg_version(void);
  * fp32 per-tile (sum, sum of squares) of the pre-bias fp32 results, for the following BatchNorm.
  * out_s != 1 scatters output pixel (n,ho,wo) to row ((n*out_H + ho*out_s)*out_W + wo*out_s)
  * (data-gradient of a strided 1x1 conv; the caller zero-fills y first).
- * The same entry point computes data gradients: pass dy as x and the transposed/flipped weights. */
+ * The same entry point computes data gradients: pass dy as x and the transposed/flipped weights.
+ * ep_x (nullable, addressed like y with pitch ldep) fuses the BatchNorm-backward correction of a
+ * folded layer into the store: y = acc - ep_c0[o] - ep_c1[o]*ep_x[row][o] (see seg_fold_*). */
 int seg_conv_gemm_fwd(int dtype, const void* x, long ldx, int N, int Hi, int Wi, int C,
                       const void* w, int O, int KH, int KW, int stride, int pad, int dil,
                       int pro_mode, const float* pro_scale, const float* pro_shift,
                       const float* bias, void* y, long ldy, int Ho, int Wo, int out_H, int out_W,
-                      int out_s, float* stat_partial, void* stream);
+                      int out_s, float* stat_partial, const void* ep_x, long ldep,
+                      const float* ep_c0, const float* ep_c1, void* stream);
 int seg_conv_gemm_tiles_m(int N, int Ho, int Wo);
 
 /* Weight gradient of the same convolution (autograd's conv2d backward wrt weight):

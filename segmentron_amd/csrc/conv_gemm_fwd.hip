@@ -26,7 +26,12 @@ struct ConvGemmArgs {
   const float* pro_shift;
   const float* bias;
   float* stat_partial;  // [tiles_m][2][O] or null
-  long ldx, ldy;
+  // optional epilogue correction (data gradient through a folded BatchNorm, fold.hip):
+  //   y[p][o] = acc - ep_c0[o] - ep_c1[o] * ep_x[p][o]      (ep_x addressed like y)
+  const void* ep_x;
+  const float* ep_c0;
+  const float* ep_c1;
+  long ldx, ldy, ldep;
   int N, Hi, Wi, C, Ho, Wo, O;
   int KH, KW, stride, pad, dil;
   int pro_mode;
@@ -190,8 +195,16 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv_gemm_fwd_kernel(const ConvG
           const int n = t / a.Ho;
           row = ((long)n * a.out_H + (long)ho * a.out_s) * a.out_W + (long)wo * a.out_s;
         }
-        const uint4 val = *reinterpret_cast<const uint4*>(ep + r * EP_STRIDE + v * 16);
+        uint4 val = *reinterpret_cast<const uint4*>(ep + r * EP_STRIDE + v * 16);
         T* dst = Y + row * a.ldy + o;
+        if (a.ep_x != nullptr && o + VEC <= a.O) {
+          float f[VEC], xv[VEC];
+          Vec<T>::unpack(val, f);
+          Vec<T>::unpack(ldg16(reinterpret_cast<const T*>(a.ep_x) + row * a.ldep + o), xv);
+#pragma unroll
+          for (int k = 0; k < VEC; ++k) f[k] = f[k] - a.ep_c0[o + k] - a.ep_c1[o + k] * xv[k];
+          val = Vec<T>::pack(f);
+        }
         if (o + VEC <= a.O) {
           stg16(dst, val);
         } else {  // ragged channel tail (e.g. 19 classes): never write past O
@@ -244,7 +257,8 @@ extern "C" int seg_conv_gemm_fwd(int dtype, const void* x, long ldx, int N, int 
                                  int dil, int pro_mode, const float* pro_scale,
                                  const float* pro_shift, const float* bias, void* y, long ldy,
                                  int Ho, int Wo, int out_H, int out_W, int out_s,
-                                 float* stat_partial, void* stream) {
+                                 float* stat_partial, const void* ep_x, long ldep,
+                                 const float* ep_c0, const float* ep_c1, void* stream) {
   using namespace seg;
   const int vec = dtype == DT_BF16 ? 8 : 4;
   SEG_REQUIRE(dtype == DT_F32 || dtype == DT_BF16, "conv_gemm_fwd: bad dtype %d", dtype);
@@ -257,6 +271,9 @@ extern "C" int seg_conv_gemm_fwd(int dtype, const void* x, long ldx, int N, int 
   ConvGemmArgs a;
   a.x = x; a.w = w; a.y = y;
   a.pro_scale = pro_scale; a.pro_shift = pro_shift; a.bias = bias; a.stat_partial = stat_partial;
+  a.ep_x = ep_x; a.ep_c0 = ep_c0; a.ep_c1 = ep_c1; a.ldep = ldep;
+  SEG_REQUIRE(ep_x == nullptr || (ep_c0 && ep_c1 && O % vec == 0 && ldep % vec == 0),
+              "conv_gemm_fwd: epilogue correction needs c0/c1 and vector-aligned O/ldep");
   a.ldx = ldx; a.ldy = ldy;
   a.N = N; a.Hi = Hi; a.Wi = Wi; a.C = C; a.Ho = Ho; a.Wo = Wo; a.O = O;
   a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad; a.dil = dil;

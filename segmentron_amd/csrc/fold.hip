@@ -36,18 +36,18 @@ __global__ __launch_bounds__(256) void fold_weights_kernel(const float* __restri
   if (lane == 0 && bprime) bprime[o] = acc;
 }
 
-// block: 32 columns (c) x 8 row groups (o)
+// block: 8 columns (c) x 32 row groups (o) -> C/8 blocks, O/32 serial iterations
 __global__ __launch_bounds__(256) void fold_bwd_reduce_kernel(
     const float* __restrict__ W, const float* __restrict__ dWp, const float* __restrict__ s,
     const float* __restrict__ t, const float* __restrict__ db, float* __restrict__ dW,
     float* __restrict__ dsdt, int O, int C) {
-  __shared__ float red[2][8][33];
-  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cx;
+  __shared__ float red[2][32][9];
+  const int cx = threadIdx.x & 7, ry = threadIdx.x >> 3;
+  const int c = blockIdx.x * 8 + cx;
   float a0 = 0.f, a1 = 0.f;
   if (c < C) {
     const float sc = s[c], tc = t[c];
-    for (int o = ry; o < O; o += 8) {
+    for (int o = ry; o < O; o += 32) {
       const float w = W[(long)o * C + c], g = dWp[(long)o * C + c];
       const float dbo = db ? db[o] : 0.f;
       dW[(long)o * C + c] = fmaf(g, sc, dbo * tc);
@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void fold_bwd_reduce_kernel(
   if (ry == 0 && c < C) {
     float s0 = 0.f, s1 = 0.f;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 0; k < 32; ++k) {
       s0 += red[0][k][cx];
       s1 += red[1][k][cx];
     }
@@ -111,7 +111,7 @@ extern "C" int seg_fold_bwd_reduce(const float* W, const float* dWp, const float
                                    int O, int C, void* stream) {
   using namespace seg;
   SEG_REQUIRE(O >= 1 && C >= 1, "fold_bwd_reduce: empty");
-  hipLaunchKernelGGL(fold_bwd_reduce_kernel, dim3((C + 31) / 32), dim3(256), 0,
+  hipLaunchKernelGGL(fold_bwd_reduce_kernel, dim3((C + 7) / 8), dim3(256), 0,
                      (hipStream_t)stream, W, dWp, scale, shift, db, dW, dsdt, O, C);
   return check_launch("fold_bwd_reduce");
 }

@@ -281,15 +281,18 @@ class _FoldConvFn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             if s.stride == 1:
-                g, _ = K.conv_gemm(dy, ctx.wpt, C, 1, 1, 1, 0, 1)
+                # dx = dY W' - c0 - c1 x : the BatchNorm-backward correction rides in the
+                # data-gradient GEMM's epilogue (no separate pass over the activation)
+                dx, _ = K.conv_gemm(dy, ctx.wpt, C, 1, 1, 1, 0, 1,
+                                    ep=(x, c0, c1) if bn.training else None)
             else:
                 g, _ = K.conv_gemm(dy, ctx.wpt, C, 1, 1, 1, 0, 1,
                                    scatter=(x.shape[1], x.shape[2], s.stride))
-            if bn.training:
-                ones = _ones(C, x.device)
-                dx = K.bn_bwd_apply(g, x, (PRO_AFFINE, ones, ones), c0, c1, out=g)
-            else:
-                dx = g
+                if bn.training:
+                    ones = _ones(C, x.device)
+                    dx = K.bn_bwd_apply(g, x, (PRO_AFFINE, ones, ones), c0, c1, out=g)
+                else:
+                    dx = g
         return dx, dgamma, dbeta, dW.view_as(weight), None
 
 

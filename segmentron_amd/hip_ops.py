@@ -71,7 +71,7 @@ def conv_out_size(Hi, k, stride, pad, dil):
 
 
 def conv_gemm(x, w_packed, O, KH, KW, stride, pad, dil, pro=None, bias=None, out=None,
-              want_stats=False, scatter=None):
+              want_stats=False, scatter=None, ep=None):
     """x NHWC; w_packed [O, KH*KW*C] in x.dtype.  Returns (y, stat_partial|None).
     scatter=(out_H, out_W, s): write output pixel (ho,wo) at (ho*s, wo*s) of a zero-filled
     [N,out_H,out_W,O] tensor (data gradient of a strided 1x1 conv)."""
@@ -92,9 +92,14 @@ def conv_gemm(x, w_packed, O, KH, KW, stride, pad, dil, pro=None, bias=None, out
         tm = LIB.query("seg_conv_gemm_tiles_m", N, Ho, Wo)
         partial = torch.empty((tm, 2, O), dtype=torch.float32, device=x.device)
     assert w_packed.dtype == x.dtype and w_packed.is_contiguous()
+    ep_x, ldep, ep_c0, ep_c1 = None, 0, None, None
+    if ep is not None:  # (x_like_output, c0, c1): y = acc - c0 - c1 * x  (folded-BN backward)
+        ep_x, ep_c0, ep_c1 = ep
+        assert tuple(ep_x.shape) == tuple(out.shape)
+        ldep = nhwc(ep_x)[4]
     LIB.call("seg_conv_gemm_fwd", _DT[x.dtype], _p(x), ldx, N, Hi, Wi, C, _p(w_packed), O, KH, KW,
              stride, pad, dil, mode, _p(ps), _p(pt), _p(bias), _p(out), ldy, Ho, Wo, oH, oW, os_,
-             _p(partial), _stream())
+             _p(partial), _p(ep_x), ldep, _p(ep_c0), _p(ep_c1), _stream())
     return out, partial
 
 

@@ -309,3 +309,42 @@ def test_errors_are_reported_not_fatal():
         K().conv_gemm(x, w, 8, 1, 1, 1, 0, 1)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         K().bn_apply(torch.zeros(1, 2, 2, 8))
+
+
+# ------------------------------------------------------------------------------ BN fold
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+def test_fold_linear_bn_into_pointwise_matches_autograd(dtype):
+    """relu_first SeparableConv2d tail: dw_raw -> BN_train(bn_depth) -> 1x1 conv -> (BN_train
+    follows, so the constant W@shift is dropped).  Forward, dW, dgamma, dbeta and dx_raw through
+    the folded path vs torch autograd of conv(batch_norm(x))."""
+    N, C, O, H, W = 2, 72, 40, 9, 11
+    x = quant(rnd((N, C, H, W), 1) * 1.3 + 0.2, dtype)
+    wt = rnd((O, C, 1, 1), 2, 0.2)
+    gamma, beta = (torch.rand(C) + 0.5), rnd((C,), 3, 0.2)
+    xr = x.double().requires_grad_()
+    wr = wt.double().requires_grad_()
+    gr, br = gamma.double().requires_grad_(), beta.double().requires_grad_()
+    xn = TF.batch_norm(xr, None, None, gr, br, True, 0.1, 1e-3)
+    y = TF.conv2d(xn, wr)
+    # a following training-mode BatchNorm makes dL/dy sum to zero per channel
+    dy = rnd(tuple(y.shape), 5)
+    dy = quant(dy - dy.mean((0, 2, 3), keepdim=True), dtype)
+    y.backward(dy.double())
+    Fm, Km = F(), K()
+    sums = torch.cat([x.double().sum((0, 2, 3)), (x.double() ** 2).sum((0, 2, 3))]).to(DEV)
+    gd, bd = gamma.to(DEV), beta.to(DEV)
+    mean, invstd, scale, shift = Km.bn_finalize(sums, N * H * W, gd, bd, 1e-3, 0.1, None, None)
+    w2d = wt.view(O, C).to(DEV)
+    wp, wpt, bp = Km.fold_weights(w2d, scale, shift, dtype, want_transpose=True)
+    xd = to_dev_nhwc(x, dtype)
+    yd, _ = Km.conv_gemm(xd, wp, O, 1, 1, 1, 0, 1, None, bp)
+    assert_close(to_cpu_nchw(yd), y.detach(), dtype, "folded fwd", fac=2)
+    dyd = to_dev_nhwc(dy, dtype)
+    dwp = Km.conv_wgrad(xd, dyd, O, 1, 1, 1, 0, 1, None)
+    dW, dsdt = Km.fold_bwd_reduce(w2d, dwp, scale, shift, None)
+    dgamma, dbeta, c0, c1 = Km.fold_bwd_finalize(dsdt, N * H * W, mean, invstd, gd, scale)
+    dx, _ = Km.conv_gemm(dyd, wpt, C, 1, 1, 1, 0, 1, ep=(xd, c0, c1))
+    assert_close(dW.view(O, C, 1, 1).cpu(), wr.grad, torch.float32, "folded dW", fac=50)
+    assert_close(dgamma.cpu(), gr.grad, torch.float32, "folded dgamma", fac=50)
+    assert dbeta.abs().max().item() == 0.0 and br.grad.abs().max().item() < 1e-9
+    assert_close(to_cpu_nchw(dx), xr.grad, dtype, "folded dx", fac=3)
