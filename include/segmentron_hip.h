@@ -49,6 +49,9 @@ int seg_conv_gemm_fwd(int dtype, const void* x, long ldx, int N, int Hi, int Wi,
                       int out_s, float* stat_partial, const void* ep_x, long ldep,
                       const float* ep_c0, const float* ep_c1, void* stream);
 int seg_conv_gemm_tiles_m(int N, int Ho, int Wo);
+/* tuning knob (not a correctness switch): LDS pipeline variant of the GEMM kernels; returns the
+ * previous value, negative = query only. */
+int seg_conv_gemm_config(int double_buffer);
 
 /* Weight gradient of the same convolution (autograd's conv2d backward wrt weight):
  * partial[s][o][k] for s < splits (fp32); sum over s with seg_colsum gives dW[O][KH*KW*C].
@@ -58,6 +61,7 @@ int seg_conv_gemm_wgrad(int dtype, const void* x, long ldx, int N, int Hi, int W
                         int stride, int pad, int dil, int pro_mode, const float* pro_scale,
                         const float* pro_shift, float* partial, int splits, void* stream);
 int seg_conv_gemm_wgrad_splits(int dtype, int N, int Ho, int Wo, int O, int K);
+int seg_conv_gemm_wgrad_config(int double_buffer);
 
 /* ---- nn.Conv2d, groups=C, 3x3, padding=dilation (depthwise) --------------------------------
  * Replaces segmentron/modules/basic.py:38-40 (SeparableConv2d.depthwise), :152-153.

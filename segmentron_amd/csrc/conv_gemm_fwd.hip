@@ -40,13 +40,17 @@ struct ConvGemmArgs {
   int tiles_m, tiles_n;
 };
 
-template <typename T>
-__global__ __launch_bounds__(GEMM_THREADS) void conv_gemm_fwd_kernel(const ConvGemmArgs a) {
+// FAST : 1x1, stride 1, no padding — the 96 %-of-FLOPs case: operand rows are addressed by
+//        pointers set up once and advanced by a constant per K-slab (no per-slab index math).
+// DBUF : two LDS stages, one barrier per slab (2 blocks/CU) vs one stage, two barriers per slab
+//        (3 blocks/CU).  The variant is chosen by the host (seg_conv_gemm_config).
+template <typename T, bool FAST, bool DBUF>
+__global__ __launch_bounds__(GEMM_THREADS, (DBUF || !FAST) ? 2 : 3) void conv_gemm_fwd_kernel(
+    const ConvGemmArgs a) {
   constexpr int VEC = Vec<T>::N;
   constexpr int BK = ROW_BYTES / (int)sizeof(T);
-  // two stages of (A tile, B tile): global loads for slab k+1 are in flight and its LDS image
-  // is written while slab k is being multiplied -> one barrier per slab
-  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TILE_BYTES];
+  constexpr int NSTAGE = DBUF ? 2 : 1;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NSTAGE * 2 * TILE_BYTES];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -60,23 +64,38 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv_gemm_fwd_kernel(const ConvG
   const T* __restrict__ X = reinterpret_cast<const T*>(a.x);
   const T* __restrict__ W = reinterpret_cast<const T*>(a.w);
 
+  // general path state
   long a_base[4];
   int a_hi0[4], a_wi0[4];
+  // fast path state: row pointers (advanced by the slab offset) and validity
+  const T* pa[4];
+  const T* pb[4];
+  unsigned row_ok = 0, col_ok = 0;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int p = m0 + rb + 32 * j;
-    if (p < a.M) {
-      const int wo = p % a.Wo;
-      const int t = p / a.Wo;
-      const int ho = t % a.Ho;
-      const int n = t / a.Ho;
-      a_base[j] = (long)n * a.Hi * a.Wi;
-      a_hi0[j] = ho * a.stride - a.pad;
-      a_wi0[j] = wo * a.stride - a.pad;
+    const int o = n0 + rb + 32 * j;
+    pb[j] = W + (long)(o < a.O ? o : 0) * a.K + vc * VEC;
+    if (o < a.O) col_ok |= 1u << j;
+    if (FAST) {
+      pa[j] = X + (long)(p < a.M ? p : 0) * a.ldx + vc * VEC;
+      if (p < a.M) row_ok |= 1u << j;
+      a_base[j] = 0; a_hi0[j] = 0; a_wi0[j] = 0;
     } else {
-      a_base[j] = 0;
-      a_hi0[j] = -(1 << 28);  // never in range
-      a_wi0[j] = -(1 << 28);
+      pa[j] = X;
+      if (p < a.M) {
+        const int wo = p % a.Wo;
+        const int t = p / a.Wo;
+        const int ho = t % a.Ho;
+        const int n = t / a.Ho;
+        a_base[j] = (long)n * a.Hi * a.Wi;
+        a_hi0[j] = ho * a.stride - a.pad;
+        a_wi0[j] = wo * a.stride - a.pad;
+      } else {
+        a_base[j] = 0;
+        a_hi0[j] = -(1 << 28);  // never in range
+        a_wi0[j] = -(1 << 28);
+      }
     }
   }
   const bool single_tap = (a.KH * a.KW == 1);
@@ -86,29 +105,38 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv_gemm_fwd_kernel(const ConvG
   int cur_c = 0;  // channel of this thread's A vector in the slab being staged
   auto load_slab = [&](int kt) {
     const int kv = kt * BK + vc * VEC;
-    int c = kv, dh = 0, dw = 0;
-    if (!single_tap) {
-      const int kidx = kv / a.C;
-      c = kv - kidx * a.C;
-      const int kh = kidx / a.KW;
-      dh = kh * a.dil;
-      dw = (kidx - kh * a.KW) * a.dil;
-    }
-    cur_c = c;
     const bool kok = kv < a.K;
+    if (FAST) {
+      cur_c = kv;
+      a_ok_mask = kok ? row_ok : 0u;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int hi = a_hi0[j] + dh, wi = a_wi0[j] + dw;
-      const bool ok = kok && hi >= 0 && hi < a.Hi && wi >= 0 && wi < a.Wi;
-      ra[j] = make_uint4(0, 0, 0, 0);
-      if (ok) ra[j] = ldg16(X + (a_base[j] + (long)hi * a.Wi + wi) * a.ldx + c);
-      a_ok_mask = ok ? (a_ok_mask | (1u << j)) : (a_ok_mask & ~(1u << j));
+      for (int j = 0; j < 4; ++j) {
+        ra[j] = make_uint4(0, 0, 0, 0);
+        if ((a_ok_mask >> j) & 1u) ra[j] = ldg16(pa[j] + kt * BK);
+      }
+    } else {
+      int c = kv, dh = 0, dw = 0;
+      if (!single_tap) {
+        const int kidx = kv / a.C;
+        c = kv - kidx * a.C;
+        const int kh = kidx / a.KW;
+        dh = kh * a.dil;
+        dw = (kidx - kh * a.KW) * a.dil;
+      }
+      cur_c = c;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int hi = a_hi0[j] + dh, wi = a_wi0[j] + dw;
+        const bool ok = kok && hi >= 0 && hi < a.Hi && wi >= 0 && wi < a.Wi;
+        ra[j] = make_uint4(0, 0, 0, 0);
+        if (ok) ra[j] = ldg16(X + (a_base[j] + (long)hi * a.Wi + wi) * a.ldx + c);
+        a_ok_mask = ok ? (a_ok_mask | (1u << j)) : (a_ok_mask & ~(1u << j));
+      }
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int o = n0 + rb + 32 * j;
       rbv[j] = make_uint4(0, 0, 0, 0);
-      if (kok && o < a.O) rbv[j] = ldg16(W + (long)o * a.K + kv);
+      if (kok && ((col_ok >> j) & 1u)) rbv[j] = ldg16(pb[j] + kt * BK);
     }
   };
 
@@ -123,7 +151,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv_gemm_fwd_kernel(const ConvG
   const int nk = (a.K + BK - 1) / BK;
   auto stage = [&](int buf) {
     // registers -> LDS (fused BN/ReLU prologue on the activation operand; padding stays zero)
-    unsigned char* sA = smem + buf * 2 * TILE_BYTES;
+    unsigned char* sA = smem + (DBUF ? buf : 0) * 2 * TILE_BYTES;
     unsigned char* sB = sA + TILE_BYTES;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -139,15 +167,25 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv_gemm_fwd_kernel(const ConvG
     }
   };
   load_slab(0);
-  stage(0);
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) load_slab(kt + 1);  // global loads in flight under the MFMAs
-    mma_slab<T>(smem + cur * 2 * TILE_BYTES, smem + cur * 2 * TILE_BYTES + TILE_BYTES, wm, wn,
-                lane, acc);
-    if (kt + 1 < nk) stage(cur ^ 1);
+  if (DBUF) {
+    stage(0);
     __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = kt & 1;
+      if (kt + 1 < nk) load_slab(kt + 1);  // global loads in flight under the MFMAs
+      mma_slab<T>(smem + cur * 2 * TILE_BYTES, smem + cur * 2 * TILE_BYTES + TILE_BYTES, wm, wn,
+                  lane, acc);
+      if (kt + 1 < nk) stage(cur ^ 1);
+      __syncthreads();
+    }
+  } else {
+    for (int kt = 0; kt < nk; ++kt) {
+      stage(0);
+      __syncthreads();
+      if (kt + 1 < nk) load_slab(kt + 1);
+      mma_slab<T>(smem, smem + TILE_BYTES, wm, wn, lane, acc);
+      __syncthreads();
+    }
   }
 
   // ---- epilogue: accumulators -> (bias) -> LDS (per-wave 32x64 patch, row-major) -> 16-byte
@@ -243,14 +281,31 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv_gemm_fwd_kernel(const ConvG
   }
 }
 
+static int g_gemm_dbuf = 1;  // host-selectable pipeline variant (seg_conv_gemm_config)
+
 template <typename T>
 static int launch_conv_gemm_fwd(const ConvGemmArgs& a, hipStream_t stream) {
-  const int grid = a.tiles_m * a.tiles_n;
-  hipLaunchKernelGGL((conv_gemm_fwd_kernel<T>), dim3(grid), dim3(GEMM_THREADS), 0, stream, a);
+  const dim3 grid(a.tiles_m * a.tiles_n), block(GEMM_THREADS);
+  const bool fast = a.KH * a.KW == 1 && a.stride == 1 && a.pad == 0;
+  if (fast) {
+    if (g_gemm_dbuf) hipLaunchKernelGGL((conv_gemm_fwd_kernel<T, true, true>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((conv_gemm_fwd_kernel<T, true, false>), grid, block, 0, stream, a);
+  } else {
+    if (g_gemm_dbuf) hipLaunchKernelGGL((conv_gemm_fwd_kernel<T, false, true>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((conv_gemm_fwd_kernel<T, false, false>), grid, block, 0, stream, a);
+  }
   return check_launch("conv_gemm_fwd");
 }
 
 }  // namespace seg
+
+// Process-wide tuning knob: 1 = two LDS stages / one barrier per slab, 0 = one stage (more
+// resident blocks).  Returns the previous value; a negative argument only queries.
+extern "C" int seg_conv_gemm_config(int double_buffer) {
+  const int prev = seg::g_gemm_dbuf;
+  if (double_buffer >= 0) seg::g_gemm_dbuf = double_buffer ? 1 : 0;
+  return prev;
+}
 
 extern "C" int seg_conv_gemm_fwd(int dtype, const void* x, long ldx, int N, int Hi, int Wi, int C,
                                  const void* w, int O, int KH, int KW, int stride, int pad,

@@ -61,15 +61,16 @@ template <> struct Transpose<bf16_t> {  // 8x8 of 16-bit
   }
 };
 
-template <typename T>
-__global__ __launch_bounds__(GEMM_THREADS) void conv_gemm_wgrad_kernel(const WgradArgs a) {
+template <typename T, bool DBUF>
+__global__ __launch_bounds__(GEMM_THREADS, (DBUF || sizeof(T) == 4) ? 2 : 3) void conv_gemm_wgrad_kernel(
+    const WgradArgs a) {
   constexpr int VEC = Vec<T>::N;
   constexpr int BKP = ROW_BYTES / (int)sizeof(T);  // pixels per slab (64 bf16 / 32 f32)
   constexpr int PG = BKP / VEC;                    // pixel groups per slab (8)
   constexpr int BPO = (128 / VEC) * PG;            // VECxVEC blocks per operand slab
   constexpr int NBLK = 2 * BPO / GEMM_THREADS;     // blocks per thread (1 bf16 / 2 f32)
-  // two stages of (dY^T tile [o][p], X^T tile [k][p]); one barrier per slab
-  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TILE_BYTES];
+  // (dY^T tile [o][p], X^T tile [k][p]) x {1,2} stages
+  __shared__ __attribute__((aligned(16))) unsigned char smem[(DBUF ? 4 : 2) * TILE_BYTES];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -115,32 +116,47 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv_gemm_wgrad_kernel(const Wgr
     }
   }
 
+  // row pointers of the first slab (pixel p_begin + pg*VEC), advanced by a constant per slab
+  const T* b_ptr[NBLK];
+  bool b_vec[NBLK];
+#pragma unroll
+  for (int q = 0; q < NBLK; ++q) {
+    const long p = p_begin + b_pg[q] * VEC;
+    if (b_op[q] == 0) {
+      const int o = o0 + b_v[q] * VEC;
+      b_ptr[q] = DY + p * a.lddy + (b_colok[q] ? o : 0);
+      b_vec[q] = o + VEC <= a.O;
+    } else {
+      b_ptr[q] = X + p * a.ldx + b_c[q];
+      b_vec[q] = true;
+    }
+  }
   uint4 regs[NBLK][VEC];
   auto load_slab = [&](int p0) {
 #pragma unroll
     for (int q = 0; q < NBLK; ++q) {
+      const long ld = b_op[q] == 0 ? a.lddy : a.ldx;
+      const T* base = b_ptr[q] + (long)(p0 - p_begin) * ld;
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
         const int p = p0 + b_pg[q] * VEC + j;
         uint4 v = make_uint4(0, 0, 0, 0);
         if (p < p_end && b_colok[q]) {
           if (b_op[q] == 0) {
-            const int o = o0 + b_v[q] * VEC;
-            if (o + VEC <= a.O) {
-              v = ldg16(DY + (long)p * a.lddy + o);
+            if (b_vec[q]) {
+              v = ldg16(base + j * ld);
             } else {  // ragged channel tail (e.g. O = 19): element-wise
+              const int o = o0 + b_v[q] * VEC;
               float f[VEC];
 #pragma unroll
               for (int i = 0; i < VEC; ++i)
-                f[i] = (o + i < a.O) ? Vec<T>::load1(DY + (long)p * a.lddy + o + i) : 0.f;
+                f[i] = (o + i < a.O) ? Vec<T>::load1(base + j * ld + i) : 0.f;
               v = Vec<T>::pack(f);
             }
           } else {
-            long off;
+            const T* src = base + j * ld;
             bool ok = true;
-            if (simple) {
-              off = (long)p * a.ldx + b_c[q];
-            } else {
+            if (!simple) {
               const int wo = p % a.Wo;
               const int t = p / a.Wo;
               const int ho = t % a.Ho;
@@ -148,10 +164,10 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv_gemm_wgrad_kernel(const Wgr
               const int hi = ho * a.stride - a.pad + b_dh[q];
               const int wi = wo * a.stride - a.pad + b_dw[q];
               ok = hi >= 0 && hi < a.Hi && wi >= 0 && wi < a.Wi;
-              off = (((long)n * a.Hi + hi) * a.Wi + wi) * a.ldx + b_c[q];
+              src = X + (((long)n * a.Hi + hi) * a.Wi + wi) * a.ldx + b_c[q];
             }
             if (ok) {
-              v = ldg16(X + off);
+              v = ldg16(src);
               if (a.pro_mode != PRO_NONE) {
                 float f[VEC];
                 Vec<T>::unpack(v, f);
@@ -175,7 +191,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv_gemm_wgrad_kernel(const Wgr
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   auto stage = [&](int buf) {
-    unsigned char* sA = smem + buf * 2 * TILE_BYTES;
+    unsigned char* sA = smem + (DBUF ? buf : 0) * 2 * TILE_BYTES;
     unsigned char* sB = sA + TILE_BYTES;
 #pragma unroll
     for (int q = 0; q < NBLK; ++q) {
@@ -188,17 +204,27 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv_gemm_wgrad_kernel(const Wgr
   };
   if (p_begin < p_end) {
     load_slab(p_begin);
-    stage(0);
-    __syncthreads();
-    int cur = 0;
-    for (int p0 = p_begin; p0 < p_end; p0 += BKP) {
-      const bool more = p0 + BKP < p_end;
-      if (more) load_slab(p0 + BKP);
-      mma_slab<T>(smem + cur * 2 * TILE_BYTES, smem + cur * 2 * TILE_BYTES + TILE_BYTES, wm, wn,
-                  lane, acc);
-      if (more) stage(cur ^ 1);
+    if (DBUF) {
+      stage(0);
       __syncthreads();
-      cur ^= 1;
+      int cur = 0;
+      for (int p0 = p_begin; p0 < p_end; p0 += BKP) {
+        const bool more = p0 + BKP < p_end;
+        if (more) load_slab(p0 + BKP);
+        mma_slab<T>(smem + cur * 2 * TILE_BYTES, smem + cur * 2 * TILE_BYTES + TILE_BYTES, wm, wn,
+                    lane, acc);
+        if (more) stage(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+      }
+    } else {
+      for (int p0 = p_begin; p0 < p_end; p0 += BKP) {
+        stage(0);
+        __syncthreads();
+        if (p0 + BKP < p_end) load_slab(p0 + BKP);
+        mma_slab<T>(smem, smem + TILE_BYTES, wm, wn, lane, acc);
+        __syncthreads();
+      }
     }
   }
 
@@ -222,12 +248,20 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv_gemm_wgrad_kernel(const Wgr
 
 }  // namespace seg
 
+namespace seg { static int g_wgrad_dbuf = 1; }
+// tuning knob for the weight-gradient kernel, same semantics as seg_conv_gemm_config
+extern "C" int seg_conv_gemm_wgrad_config(int double_buffer) {
+  const int prev = seg::g_wgrad_dbuf;
+  if (double_buffer >= 0) seg::g_wgrad_dbuf = double_buffer ? 1 : 0;
+  return prev;
+}
+
 extern "C" int seg_conv_gemm_wgrad_splits(int dtype, int N, int Ho, int Wo, int O, int K) {
   using namespace seg;
   const int bkp = dtype == DT_BF16 ? 64 : 32;
   const long M = (long)N * Ho * Wo;
   const int tiles = ((O + BM - 1) / BM) * ((K + BN - 1) / BN);
-  long want = 512 / tiles;                         // 2 blocks/CU are resident (72 KB LDS each)
+  long want = (g_wgrad_dbuf ? 512 : 768) / tiles;  // resident blocks: 2 (two stages) or 3 per CU
   long maxs = (M + 8 * bkp - 1) / (8 * bkp);       // at least 8 slabs per split
   if (maxs < 1) maxs = 1;
   if (want > maxs) want = maxs;
@@ -260,9 +294,13 @@ extern "C" int seg_conv_gemm_wgrad(int dtype, const void* x, long ldx, int N, in
   a.chunk = ((slabs + splits - 1) / splits) * bkp;
   const int grid = a.tiles_o * a.tiles_k * splits;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == DT_BF16)
-    hipLaunchKernelGGL((conv_gemm_wgrad_kernel<bf16_t>), dim3(grid), dim3(GEMM_THREADS), 0, st, a);
-  else
-    hipLaunchKernelGGL((conv_gemm_wgrad_kernel<float>), dim3(grid), dim3(GEMM_THREADS), 0, st, a);
+  const dim3 g(grid), b(GEMM_THREADS);
+  if (dtype == DT_BF16) {
+    if (g_wgrad_dbuf) hipLaunchKernelGGL((conv_gemm_wgrad_kernel<bf16_t, true>), g, b, 0, st, a);
+    else hipLaunchKernelGGL((conv_gemm_wgrad_kernel<bf16_t, false>), g, b, 0, st, a);
+  } else {
+    if (g_wgrad_dbuf) hipLaunchKernelGGL((conv_gemm_wgrad_kernel<float, true>), g, b, 0, st, a);
+    else hipLaunchKernelGGL((conv_gemm_wgrad_kernel<float, false>), g, b, 0, st, a);
+  }
   return check_launch("conv_gemm_wgrad");
 }
