@@ -281,7 +281,8 @@ __global__ __launch_bounds__(GEMM_THREADS, (DBUF || !FAST) ? 2 : 3) void conv_ge
   }
 }
 
-static int g_gemm_dbuf = 1;  // host-selectable pipeline variant (seg_conv_gemm_config)
+static int g_gemm_dbuf = 0;  // single LDS stage, 3 blocks/CU: measured faster on every C3 shape
+                             // (gpurun_out/gemm_bench2: 709 vs 622 TF on 1536->2048 @65x129)
 
 template <typename T>
 static int launch_conv_gemm_fwd(const ConvGemmArgs& a, hipStream_t stream) {

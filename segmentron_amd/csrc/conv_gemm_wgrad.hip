@@ -248,7 +248,7 @@ __global__ __launch_bounds__(GEMM_THREADS, (DBUF || sizeof(T) == 4) ? 2 : 3) voi
 
 }  // namespace seg
 
-namespace seg { static int g_wgrad_dbuf = 1; }
+namespace seg { static int g_wgrad_dbuf = 0; }  // see conv_gemm_fwd.hip: single stage measured faster
 // tuning knob for the weight-gradient kernel, same semantics as seg_conv_gemm_config
 extern "C" int seg_conv_gemm_wgrad_config(int double_buffer) {
   const int prev = seg::g_wgrad_dbuf;

@@ -460,6 +460,15 @@ def conv_bn(act, conv, bn=None, out=None):
     g, b = act.params
     foldable = (act.bn is not None and not act.relu and conv.kernel_size == (1, 1)
                 and conv.padding[0] == 0 and conv.bias is None)
+    if not foldable and (act.bn is not None or act.relu) and conv.out_channels >= 256:
+        # a wide GEMM re-applies the prologue once per 128-column tile of its output
+        # (tools/gemm_bench.py: 709 -> 408 TF forward, 419 -> 222 TF weight gradient on
+        # 1536->2048): cheaper to materialise the activated tensor once and run plain GEMMs
+        act = Act(materialize(act))
+        x = act.t
+        spec = ConvSpec(act, conv.stride[0], conv.padding[0], conv.dilation[0], out,
+                        want_stats=batch_stats)
+        g, b = act.params
     if foldable:
         spec.drop_const = batch_stats
         y = _FoldConvFn.apply(x, g, b, conv.weight, spec)
