@@ -16,6 +16,7 @@ import torch.distributed as dist
 import torch.nn as nn
 
 from . import hip_ops as K
+from . import parallel
 from .hip_ops import PRO_AFFINE, PRO_NONE, PRO_RELU
 
 
@@ -58,11 +59,7 @@ class Act:
         return self.t.shape
 
 
-def _sync_group(bn):
-    if isinstance(bn, nn.SyncBatchNorm) and bn.training and dist.is_available() \
-            and dist.is_initialized() and dist.get_world_size() > 1:
-        return bn.process_group if bn.process_group is not None else dist.group.WORLD
-    return None
+_sync_group = parallel.sync_group
 
 
 def finish_bn(bn, partial, count, mean_offset=None):
@@ -89,14 +86,9 @@ def finish_bn(bn, partial, count, mean_offset=None):
         mean, invstd, scale, shift = K.bn_finalize_p(partial, cnt, bn.weight, bn.bias, bn.eps,
                                                      momentum, rm, rv, mean_offset)
     else:
-        # SyncBN statistics exchange: ONE all-reduce of 2C float64 sums over RCCL (torch's
-        # nn.SyncBatchNorm all_gathers (mean, invstd, count) per layer instead —
-        # torch/nn/modules/_functions.py:49,74).  Data-parallel shards are equal-sized
-        # (tools/train.py uses drop_last batches), so the global count needs no exchange.
         C = partial.shape[-1]
         sums = K.colsum(partial.view(partial.shape[0], 2 * C))
-        dist.all_reduce(sums, group=group)
-        cnt = cnt * dist.get_world_size(group)
+        sums, cnt = parallel.allreduce_forward_sums(sums, cnt, group)
         mean, invstd, scale, shift = K.bn_finalize(sums, cnt, bn.weight, bn.bias, bn.eps,
                                                    momentum, rm, rv, mean_offset)
     if track and bn.num_batches_tracked is not None:
@@ -129,17 +121,13 @@ def bn_input_backward(g, x, bn, relu, chan_mul=None, inplace=False):
         dgamma, dbeta, c0, c1 = K.bn_bwd_finalize_p(partial, bn.count, bn.mean, bn.invstd,
                                                     bn.gamma)
     else:
-        sums = K.colsum(partial)
-        dist.all_reduce(sums, group=bn.group)
+        sums = parallel.allreduce_backward_sums(K.colsum(partial), bn.group)
         dgamma, dbeta, c0, c1 = K.bn_bwd_finalize(sums, bn.count, bn.mean, bn.invstd, bn.gamma)
     if not bn.training:
         c0 = c1 = None
     dx = K.bn_bwd_apply(g, x, pro, c0, c1, chan_mul, out=g if inplace else None)
     if bn.group is not None:
-        # every rank holds the GLOBAL sums; DDP averages parameter grads over ranks, torch's
-        # SyncBatchNorm backward returns the LOCAL dgamma/dbeta — emulate by dividing.
-        ws = dist.get_world_size(bn.group)
-        dgamma, dbeta = dgamma / ws, dbeta / ws
+        dgamma, dbeta = parallel.local_param_grads(dgamma, dbeta, bn.group)
     return dx, dgamma, dbeta
 
 
@@ -272,12 +260,11 @@ class _FoldConvFn(torch.autograd.Function):
             db = K.bn_bwd_reduce(dy, dy, (PRO_NONE, None, None))[:O].float()
         dW, dsdt = K.fold_bwd_reduce(weight.detach().view(O, C), dwp, bn.scale, bn.shift, db)
         if bn.group is not None:
-            dist.all_reduce(dsdt, group=bn.group)
+            parallel.allreduce_backward_sums(dsdt, bn.group)
         dgamma, dbeta, c0, c1 = K.fold_bwd_finalize(dsdt, bn.count, bn.mean, bn.invstd, bn.gamma,
                                                     bn.scale)
         if bn.group is not None:
-            ws = dist.get_world_size(bn.group)
-            dgamma, dbeta = dgamma / ws, dbeta / ws
+            dgamma, dbeta = parallel.local_param_grads(dgamma, dbeta, bn.group)
         dx = None
         if ctx.needs_input_grad[0]:
             if s.stride == 1:

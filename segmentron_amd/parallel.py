@@ -1,0 +1,41 @@
+"""Data-parallel exchange steps of the hot path (one process per GPU, RCCL over xGMI through
+torch.distributed backend "nccl"; the same code runs on gloo for the CPU tests).
+
+The path shards by image.  Two exchange steps exist per training step:
+  * gradients: DistributedDataParallel bucketed all-reduce (torch, unchanged — tools/train.py:108-111)
+  * SyncBatchNorm statistics (tools/train.py:76): per BN ONE all-reduce of the 2C float64 sums
+    [sum x, sum x^2] in forward and ONE of 2C [sum g', sum g'*x] (or [ds, dt] for folded layers)
+    in backward — torch's nn.SyncBatchNorm instead all_gathers (mean, invstd, count) in forward
+    (torch/nn/modules/_functions.py:49,74).  Same statistics, fewer and smaller messages.
+"""
+import torch.distributed as dist
+import torch.nn as nn
+
+
+def sync_group(bn):
+    """Process group to synchronise over, or None (plain BN / eval / single process)."""
+    if isinstance(bn, nn.SyncBatchNorm) and bn.training and dist.is_available() \
+            and dist.is_initialized() and dist.get_world_size() > 1:
+        return bn.process_group if bn.process_group is not None else dist.group.WORLD
+    return None
+
+
+def allreduce_forward_sums(sums, local_count, group):
+    """sums: float64 [2C] local (sum x, sum x^2) -> (global sums, global count).
+    Shards are equal-sized (drop_last batches), so the count is local_count * world."""
+    dist.all_reduce(sums, group=group)
+    return sums, float(local_count) * dist.get_world_size(group)
+
+
+def allreduce_backward_sums(sums, group):
+    """sums: [2C] local (sum g', sum g'*x) or (ds, dt) -> global, in place."""
+    dist.all_reduce(sums, group=group)
+    return sums
+
+
+def local_param_grads(dgamma, dbeta, group):
+    """Every rank computed dgamma/dbeta from GLOBAL sums; DistributedDataParallel will average
+    parameter gradients over ranks, and torch's SyncBatchNorm returns LOCAL sums there — divide
+    so that DDP's mean reproduces the reference value (global / world)."""
+    ws = dist.get_world_size(group)
+    return dgamma / ws, dbeta / ws

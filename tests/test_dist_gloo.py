@@ -1,0 +1,89 @@
+"""CPU, world_size 2, gloo: the data-parallel exchange protocol of the hot path
+(segmentron_amd/parallel.py — the code the HIP path calls under SyncBatchNorm + DDP).
+Each rank holds half of a batch; after the exchanges the BatchNorm forward statistics, the
+input gradient of its shard and the DDP-averaged parameter gradients must equal single-process
+full-batch BatchNorm (torch autograd, float64)."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn.functional as TF
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from segmentron_amd import parallel
+        torch.manual_seed(0)  # same full batch on every rank; each takes its shard
+        N, C, H, W = 4, 24, 5, 7
+        x = (torch.randn(N, C, H, W, dtype=torch.float64) * 1.7 + 0.4).requires_grad_()
+        gamma = (torch.rand(C, dtype=torch.float64) + 0.5).requires_grad_()
+        beta = torch.randn(C, dtype=torch.float64).requires_grad_()
+        g = torch.randn(N, C, H, W, dtype=torch.float64)
+        eps = 1e-3
+        y = torch.relu(TF.batch_norm(x, None, None, gamma, beta, True, 0.1, eps))
+        y.backward(g)
+
+        sync = torch.nn.SyncBatchNorm(C).train()
+        group = parallel.sync_group(sync)
+        assert group is not None
+        assert parallel.sync_group(torch.nn.BatchNorm2d(C).train()) is None
+        assert parallel.sync_group(torch.nn.SyncBatchNorm(C).eval()) is None
+
+        per = N // world
+        xs = x.detach()[rank * per:(rank + 1) * per]
+        gs = g[rank * per:(rank + 1) * per]
+        # ---- forward exchange
+        sums = torch.cat([xs.sum((0, 2, 3)), (xs * xs).sum((0, 2, 3))])
+        sums, cnt = parallel.allreduce_forward_sums(sums, xs.numel() // C, group)
+        assert cnt == N * H * W
+        mean = sums[:C] / cnt
+        var = sums[C:] / cnt - mean * mean
+        invstd = 1.0 / torch.sqrt(var + eps)
+        xd = x.detach()
+        assert torch.allclose(mean, xd.mean((0, 2, 3)), rtol=1e-12, atol=1e-12)
+        assert torch.allclose(var, xd.var((0, 2, 3), unbiased=False), rtol=1e-10, atol=1e-12)
+        scale = gamma.detach() * invstd
+        shift = beta.detach() - mean * scale
+        # ---- backward exchange (formulas of seg_bn_bwd_finalize / seg_bn_bwd_apply)
+        ylin = xs * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+        gp = gs * (ylin > 0)
+        bs = torch.cat([gp.sum((0, 2, 3)), (gp * xs).sum((0, 2, 3))])
+        bs = parallel.allreduce_backward_sums(bs, group)
+        sg, sgx = bs[:C], bs[C:]
+        dgamma = (sgx - mean * sg) * invstd
+        dbeta = sg
+        c1 = scale * (dgamma / cnt) * invstd
+        c0 = scale * (sg / cnt) - c1 * mean
+        dx = scale.view(1, -1, 1, 1) * gp - c0.view(1, -1, 1, 1) - c1.view(1, -1, 1, 1) * xs
+        assert torch.allclose(dx, x.grad[rank * per:(rank + 1) * per], rtol=1e-9, atol=1e-11)
+        # ---- parameter gradients as DistributedDataParallel will see them
+        dgl, dbl = parallel.local_param_grads(dgamma, dbeta, group)
+        avg = torch.stack([dgl, dbl])
+        dist.all_reduce(avg)
+        avg /= world  # DDP averages
+        assert torch.allclose(avg[0], gamma.grad / world, rtol=1e-9, atol=1e-11)
+        assert torch.allclose(avg[1], beta.grad / world, rtol=1e-9, atol=1e-11)
+        ret[rank] = 1
+    finally:
+        dist.destroy_process_group()
+
+
+def test_syncbn_exchange_protocol_world_size_2():
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert dict(ret) == {0: 1, 1: 1}
