@@ -79,6 +79,17 @@ int seg_dwconv3x3_wgrad(int dtype, const void* x, long ldx, int N, int Hi, int W
                         int pro_mode, const float* pro_scale, const float* pro_shift,
                         float* partial, int grid_y, void* stream);
 
+/* Fused stride-1 backward of the depthwise conv in ONE pass over (dy, x):
+ *   g[p]  = relu_mask(x[p]) * sum_k dy[p - d_k] * w9c[k]        (gradient wrt act(x), masked)
+ *   partial_w  [grid_y][9][C] : weight-gradient partials (sum rows -> dW[9][C])
+ *   partial_bn [grid_y][2][C] : (sum g, sum g*x_raw) for seg_bn_bwd_finalize_p (nullable)
+ * x is the forward input (raw tensor + prologue), w9c the forward taps.  grid_y from
+ * seg_dwconv_grid_y(dtype, C, N, H, W). */
+int seg_dwconv3x3_bwd_fused(int dtype, const void* dy, long lddy, const void* x, long ldx, int N,
+                            int H, int W, int C, const float* w9c, int dil, int pro_mode,
+                            const float* pro_scale, const float* pro_shift, void* g, long ldg,
+                            float* partial_w, float* partial_bn, int grid_y, void* stream);
+
 /* ---- nn.BatchNorm2d / nn.SyncBatchNorm (train + eval, forward + backward) -------------------
  * Replaces F.batch_norm behind every `bn*` module (segmentron/modules/basic.py:41,43,70;
  * segmentron/modules/module.py:46,54,58; xception.py:22,78,82) and torch's SyncBatchNorm

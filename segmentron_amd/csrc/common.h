@@ -20,14 +20,21 @@ enum { PRO_NONE = 0, PRO_RELU = 1, PRO_AFFINE = 2, PRO_AFFINE_RELU = 3 };
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) {
   return __uint_as_float(((uint32_t)v) << 16);
 }
-// round-to-nearest-even, finite inputs (NaN payloads are not preserved; not needed here)
-__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
-  uint32_t u = __float_as_uint(f);
-  u += 0x7FFFu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
-}
+// float -> bf16, round-to-nearest-even.  Native __bf16 conversions lower to the gfx950
+// v_cvt_pk_bf16_f32 instruction (two elements per VALU op) — the hand-rolled integer rounding
+// sequence cost ~5 VALU ops per element in every store path.
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-  return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+  f32x2_t f = {lo, hi};
+  union { bf16x2_t v; uint32_t u; } c;
+  c.v = __builtin_convertvector(f, bf16x2_t);
+  return c.u;
+}
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+  union { __bf16 b; bf16_t u; } c;
+  c.b = static_cast<__bf16>(f);
+  return c.u;
 }
 
 // 16-byte vector view of T: VEC elements
@@ -59,6 +66,30 @@ template <> struct Vec<bf16_t> {
   }
   __device__ static __forceinline__ float load1(const bf16_t* p) { return bf16_to_f32(*p); }
   __device__ static __forceinline__ void store1(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+};
+
+// 4-element vector view (16 B of fp32, 8 B of bf16) for register-heavy kernels
+template <typename T> struct HVec;
+template <> struct HVec<float> {
+  static constexpr int N = 4;
+  __device__ static __forceinline__ void load(const float* p, float* f) {
+    const uint4 v = *reinterpret_cast<const uint4*>(p);
+    Vec<float>::unpack(v, f);
+  }
+  __device__ static __forceinline__ void store(float* p, const float* f) {
+    *reinterpret_cast<uint4*>(p) = Vec<float>::pack(f);
+  }
+};
+template <> struct HVec<bf16_t> {
+  static constexpr int N = 4;
+  __device__ static __forceinline__ void load(const bf16_t* p, float* f) {
+    const uint2 v = *reinterpret_cast<const uint2*>(p);
+    f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xFFFF0000u);
+    f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xFFFF0000u);
+  }
+  __device__ static __forceinline__ void store(bf16_t* p, const float* f) {
+    *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]));
+  }
 };
 
 __device__ __forceinline__ uint4 ldg16(const void* p) { return *reinterpret_cast<const uint4*>(p); }

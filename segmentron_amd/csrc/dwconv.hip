@@ -331,6 +331,182 @@ __global__ __launch_bounds__(DW_THREADS) void dwconv_wgrad_kernel(const DwWgradA
   }
 }
 
+// ---- fused backward (stride 1):  one pass over (dy, x) produces
+//   g'[p]      = relu_mask(x[p]) * sum_k dy[p - dk] * w[k]          (data gradient wrt act(x))
+//   dW[k]     += dy[p - dk] * act(x[p])                              (the SAME shifted dy values)
+//   (sum g', sum g'*x)                                               (BatchNorm-backward sums)
+// replacing three kernels (dgrad, wgrad, bn_bwd_reduce) that each re-read dy / x.
+struct DwBwdArgs {
+  const void* dy; const void* x; void* g;
+  const float* w;  // [9][C]
+  const float* pro_scale; const float* pro_shift;
+  float* partial_w;   // [gridDim.y][9][C]
+  float* partial_bn;  // [gridDim.y][2][C] or null
+  long lddy, ldx, ldg;
+  int N, H, W, C, dil, pro_mode, cvb_log2, CV;
+  long strips;
+};
+
+template <typename T, bool FAST>
+__global__ __launch_bounds__(DW_THREADS) void dwconv_bwd_fused_kernel(const DwBwdArgs a) {
+  constexpr int VEC = HVec<T>::N;  // 4 channels per thread (8-byte bf16 vectors): this kernel
+                                   // carries 9 tap accumulators per channel
+  extern __shared__ __attribute__((aligned(16))) float dw_smem[];
+  const int tid = threadIdx.x;
+  const int cvb = 1 << a.cvb_log2;
+  const int cx = tid & (cvb - 1), sy = tid >> a.cvb_log2;
+  const int spb = DW_THREADS >> a.cvb_log2;
+  const int cv = blockIdx.x * cvb + cx;
+  const bool cok = cv < a.CV;
+  const int c0 = cok ? cv * VEC : 0;
+  const T* __restrict__ DY = reinterpret_cast<const T*>(a.dy);
+  const T* __restrict__ X = reinterpret_cast<const T*>(a.x);
+  T* __restrict__ G = reinterpret_cast<T*>(a.g);
+  const int WQ = (a.W + DW_TW - 1) / DW_TW;
+  const int d = a.dil;
+
+  float sc[VEC], sh[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    sc[i] = (a.pro_mode & PRO_AFFINE) ? a.pro_scale[c0 + i] : 1.f;
+    sh[i] = (a.pro_mode & PRO_AFFINE) ? a.pro_shift[c0 + i] : 0.f;
+  }
+  float accw[9][VEC], s1[VEC], s2[VEC];
+#pragma unroll
+  for (int k = 0; k < 9; ++k)
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) accw[k][i] = 0.f;
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) s1[i] = s2[i] = 0.f;
+
+  const int nstrips = (int)a.strips;
+  for (int s = blockIdx.y * spb + sy; s < nstrips; s += gridDim.y * spb) {
+    if (!cok) continue;
+    const int wq = s % WQ;
+    const int t = s / WQ;
+    const int h = t % a.H;
+    const int n = t / a.H;
+    const int w0 = wq * DW_TW;
+    const long prow = ((long)n * a.H + h) * a.W;
+    // centre pixels: raw x (for mask / BN sums) and activated x (for the weight gradient)
+    float xr[DW_TW][VEC], xa[DW_TW][VEC], g[DW_TW][VEC];
+#pragma unroll
+    for (int j = 0; j < DW_TW; ++j) {
+      if (w0 + j < a.W) {
+        HVec<T>::load(X + (prow + w0 + j) * a.ldx + c0, xr[j]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) xr[j][i] = 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        xa[j][i] = xr[j][i];
+        g[j][i] = 0.f;
+      }
+      dw_act<VEC>(xa[j], a.pro_mode, sc, sh);
+      if (!(w0 + j < a.W)) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) xa[j][i] = 0.f;
+      }
+    }
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int r = h + (1 - kh) * d;  // dy row feeding tap row kh
+      if (r < 0 || r >= a.H) continue;
+      const long rowbase = ((long)n * a.H + r) * a.W;
+      if (FAST) {
+        float v[DW_TW + 2][VEC];
+#pragma unroll
+        for (int q = 0; q < DW_TW + 2; ++q) {
+          const int c = w0 - 1 + q;
+          if (c >= 0 && c < a.W) {
+            HVec<T>::load(DY + (rowbase + c) * a.lddy + c0, v[q]);
+          } else {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) v[q][i] = 0.f;
+          }
+        }
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          float wv[VEC];
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) wv[i] = a.w[(kh * 3 + kw) * a.C + c0 + i];
+#pragma unroll
+          for (int j = 0; j < DW_TW; ++j)
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+              const float dyv = v[j + 2 - kw][i];
+              g[j][i] = fmaf(dyv, wv[i], g[j][i]);
+              accw[kh * 3 + kw][i] = fmaf(dyv, xa[j][i], accw[kh * 3 + kw][i]);
+            }
+        }
+      } else {
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          float wv[VEC];
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) wv[i] = a.w[(kh * 3 + kw) * a.C + c0 + i];
+#pragma unroll
+          for (int j = 0; j < DW_TW; ++j) {
+            const int c = w0 + j + (1 - kw) * d;
+            if (w0 + j < a.W && c >= 0 && c < a.W) {
+              float dyv[VEC];
+              HVec<T>::load(DY + (rowbase + c) * a.lddy + c0, dyv);
+#pragma unroll
+              for (int i = 0; i < VEC; ++i) {
+                g[j][i] = fmaf(dyv[i], wv[i], g[j][i]);
+                accw[kh * 3 + kw][i] = fmaf(dyv[i], xa[j][i], accw[kh * 3 + kw][i]);
+              }
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < DW_TW; ++j) {
+      if (w0 + j < a.W) {
+        if (a.pro_mode & PRO_RELU) {
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) g[j][i] = xa[j][i] > 0.f ? g[j][i] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+          s1[i] += g[j][i];
+          s2[i] = fmaf(g[j][i], xr[j][i], s2[i]);
+        }
+        HVec<T>::store(G + (prow + w0 + j) * a.ldg + c0, g[j]);
+      }
+    }
+  }
+  // block reductions (LDS: [spb][cvb][3*VEC] reused): 9 taps in three rounds, then BN sums
+#pragma unroll
+  for (int k3 = 0; k3 < 4; ++k3) {
+    if (k3 == 3 && a.partial_bn == nullptr) break;
+    float* mine = dw_smem + ((long)sy * cvb + cx) * 3 * VEC;
+#pragma unroll
+    for (int kk = 0; kk < 3; ++kk)
+#pragma unroll
+      for (int i = 0; i < VEC; ++i)
+        mine[kk * VEC + i] = k3 < 3 ? accw[(k3 < 3 ? k3 : 0) * 3 + kk][i]
+                                    : (kk == 0 ? s1[i] : (kk == 1 ? s2[i] : 0.f));
+    __syncthreads();
+    const int ncol = (k3 < 3 ? 3 : 2) * VEC;
+    for (int e = tid; e < cvb * 3 * VEC; e += DW_THREADS) {
+      const int lcx = e / (3 * VEC), k = e % (3 * VEC);
+      if (k >= ncol) continue;
+      float tot = 0.f;
+      for (int r = 0; r < spb; ++r) tot += dw_smem[(long)r * cvb * 3 * VEC + e];
+      const int kk = k / VEC, ci = k % VEC;
+      const int c = (blockIdx.x * cvb + lcx) * VEC + ci;
+      if (c < a.C) {
+        if (k3 < 3) a.partial_w[((long)blockIdx.y * 9 + k3 * 3 + kk) * a.C + c] = tot;
+        else a.partial_bn[((long)blockIdx.y * 2 + kk) * a.C + c] = tot;
+      }
+    }
+    __syncthreads();
+  }
+}
+
 static int pick_cvb_log2(int CV) {
   // largest utilisation among 32/16/8 channel vectors per block; ties -> wider
   int best = 5;
@@ -431,4 +607,42 @@ extern "C" int seg_dwconv3x3_wgrad(int dtype, const void* x, long ldx, int N, in
     else hipLaunchKernelGGL((dwconv_wgrad_kernel<float, false>), grid, dim3(DW_THREADS), lds, st, a);
   }
   return check_launch("dwconv3x3_wgrad");
+}
+
+// Fused stride-1 backward: g = relu_mask(x) * dgrad(dy), partial_w [grid_y][9][C],
+// partial_bn [grid_y][2][C] = (sum g, sum g*x_raw) (nullable).  x is the forward input (raw tensor
+// + prologue), w9c the forward taps (not reversed).
+extern "C" int seg_dwconv3x3_bwd_fused(int dtype, const void* dy, long lddy, const void* x,
+                                       long ldx, int N, int H, int W, int C, const float* w9c,
+                                       int dil, int pro_mode, const float* pro_scale,
+                                       const float* pro_shift, void* g, long ldg,
+                                       float* partial_w, float* partial_bn, int grid_y,
+                                       void* stream) {
+  using namespace seg;
+  const int vec = 4;  // HVec: 4 channels per thread in both element types
+  SEG_REQUIRE(dtype == DT_F32 || dtype == DT_BF16, "dwconv3x3_bwd_fused: bad dtype %d", dtype);
+  SEG_REQUIRE(C % vec == 0 && ldx % vec == 0 && lddy % vec == 0 && ldg % vec == 0,
+              "dwconv3x3_bwd_fused: C/ld must be multiples of %d", vec);
+  SEG_REQUIRE(((pro_mode & PRO_AFFINE) == 0) || (pro_scale && pro_shift),
+              "dwconv3x3_bwd_fused: affine prologue without scale/shift");
+  SEG_REQUIRE(grid_y >= 1 && partial_w != nullptr, "dwconv3x3_bwd_fused: bad grid/partials");
+  DwBwdArgs a;
+  a.dy = dy; a.x = x; a.g = g; a.w = w9c; a.pro_scale = pro_scale; a.pro_shift = pro_shift;
+  a.partial_w = partial_w; a.partial_bn = partial_bn;
+  a.lddy = lddy; a.ldx = ldx; a.ldg = ldg; a.N = N; a.H = H; a.W = W; a.C = C; a.dil = dil;
+  a.pro_mode = pro_mode; a.CV = C / vec; a.cvb_log2 = pick_cvb_log2(a.CV);
+  a.strips = (long)N * H * ((W + DW_TW - 1) / DW_TW);
+  SEG_REQUIRE(a.strips < (1L << 31), "dwconv3x3_bwd_fused: too many strips");
+  const int gx = (a.CV + (1 << a.cvb_log2) - 1) >> a.cvb_log2;
+  const dim3 grid(gx, grid_y);
+  const size_t lds = (size_t)DW_THREADS * 3 * vec * sizeof(float);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == DT_BF16) {
+    if (dil == 1) hipLaunchKernelGGL((dwconv_bwd_fused_kernel<bf16_t, true>), grid, dim3(DW_THREADS), lds, st, a);
+    else hipLaunchKernelGGL((dwconv_bwd_fused_kernel<bf16_t, false>), grid, dim3(DW_THREADS), lds, st, a);
+  } else {
+    if (dil == 1) hipLaunchKernelGGL((dwconv_bwd_fused_kernel<float, true>), grid, dim3(DW_THREADS), lds, st, a);
+    else hipLaunchKernelGGL((dwconv_bwd_fused_kernel<float, false>), grid, dim3(DW_THREADS), lds, st, a);
+  }
+  return check_launch("dwconv3x3_bwd_fused");
 }

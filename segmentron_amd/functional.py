@@ -11,6 +11,8 @@ deferred tensor sum correctly under plain torch autograd.
 Host code here is plumbing (allocation, weight packing, torch.autograd, torch.distributed);
 all arithmetic on activations is done by libsegmentron_hip.so.
 """
+import weakref
+
 import torch
 import torch.distributed as dist
 import torch.nn as nn
@@ -132,9 +134,28 @@ def bn_input_backward(g, x, bn, relu, chan_mul=None, inplace=False):
 
 
 # ----------------------------------------------------------------------------- weight packing
+_WCACHE = {}
+
+
+def cached_pack(param, kind, builder):
+    """Packed / transposed / cast views of a parameter are rebuilt only when the parameter
+    changes (optimizer.step / load_state_dict bump `_version`): forward and backward of one
+    step share them, and inference packs once."""
+    key = (id(param), kind)
+    ent = _WCACHE.get(key)
+    ver, ptr = param._version, param.data_ptr()
+    if ent is not None and ent[0] == ver and ent[1] == ptr and ent[2]() is param:
+        return ent[3]
+    val = builder()
+    _WCACHE[key] = (ver, ptr, weakref.ref(param), val)
+    return val
+
+
 def pack_conv_weight(w, cx, dtype):
     """[O, Cw, KH, KW] fp32 -> [O, KH*KW*cx] (`dtype`), input channels zero-padded to cx."""
     O, Cw, KH, KW = w.shape
+    if KH == 1 and KW == 1 and cx == Cw:
+        return w.detach().reshape(O, Cw).to(dtype)
     p = w.detach().permute(0, 2, 3, 1)
     if cx != Cw:
         p = torch.nn.functional.pad(p, (0, cx - Cw))
@@ -144,10 +165,26 @@ def pack_conv_weight(w, cx, dtype):
 def pack_conv_weight_dgrad(w, opad, dtype):
     """-> [Cw, KH*KW*opad]: spatially flipped, in/out swapped, out channels padded to opad."""
     O, Cw, KH, KW = w.shape
+    if KH == 1 and KW == 1 and opad == O:
+        out = torch.empty((Cw, O), dtype=dtype, device=w.device)
+        out.copy_(w.detach().reshape(O, Cw).t())  # one transposing, casting copy
+        return out
     p = w.detach().flip(2, 3).permute(1, 2, 3, 0)
     if opad != O:
         p = torch.nn.functional.pad(p, (0, opad - O))
     return p.reshape(Cw, KH * KW * opad).to(dtype).contiguous()
+
+
+def pack_dw_weight(w, flipped=False):
+    """[C,1,3,3] -> fp32 [9, C] tap-major (optionally with the taps reversed, for the stride-1
+    data gradient)."""
+    C = w.shape[0]
+    t = w.detach().reshape(C, 9)
+    if flipped:
+        t = t.flip(1)
+    out = torch.empty((9, C), dtype=torch.float32, device=w.device)
+    out.copy_(t.t())
+    return out
 
 
 def _round_up(v, m):
@@ -171,7 +208,8 @@ class _ConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, in_gamma, in_beta, weight, bias, spec):
         O, Cw, KH, KW = weight.shape
-        wp = pack_conv_weight(weight, x.shape[-1], x.dtype)
+        cx, dt = x.shape[-1], x.dtype
+        wp = cached_pack(weight, ("fwd", cx, dt), lambda: pack_conv_weight(weight, cx, dt))
         y, spec.partial = K.conv_gemm(x, wp, O, KH, KW, spec.stride, spec.pad, spec.dil, spec.pro,
                                       bias, spec.out, spec.want_stats)
         ctx.spec = spec
@@ -194,14 +232,18 @@ class _ConvFn(torch.autograd.Function):
             dy_full = dy
         Cx = x.shape[-1]
         dWp = K.conv_wgrad(x, dy, O, KH, KW, s.stride, s.pad, s.dil, s.pro)
-        dW = dWp.view(O, KH, KW, Cx)[..., :Cw].permute(0, 3, 1, 2).contiguous()
+        if KH == 1 and KW == 1 and Cx == Cw:
+            dW = dWp.view(O, Cw, 1, 1)
+        else:
+            dW = dWp.view(O, KH, KW, Cx)[..., :Cw].permute(0, 3, 1, 2).contiguous()
         dbias = None
         if ctx.has_bias:
             dbias = K.bn_bwd_reduce(dy_full, dy_full, (PRO_NONE, None, None))[:O].float()
         dx = dgamma = dbeta = None
         if ctx.needs_input_grad[0]:
-            Op = dy_full.shape[-1]
-            wt = pack_conv_weight_dgrad(weight, Op, x.dtype)
+            Op, dt = dy_full.shape[-1], x.dtype
+            wt = cached_pack(weight, ("dgrad", Op, dt),
+                             lambda: pack_conv_weight_dgrad(weight, Op, dt))
             if s.stride == 1:
                 g, _ = K.conv_gemm(dy_full, wt, Cw, KH, KW, 1, s.dil * (KH - 1) - s.pad, s.dil)
             elif KH == 1 and KW == 1 and s.pad == 0:
@@ -288,8 +330,7 @@ class _DwFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, in_gamma, in_beta, weight, spec):
-        C = weight.shape[0]
-        w9c = weight.detach().reshape(C, 9).t().contiguous().float()
+        w9c = cached_pack(weight, "dw", lambda: pack_dw_weight(weight))
         y, spec.partial = K.dwconv(x, w9c, spec.stride, spec.dil, spec.pro, spec.out,
                                    spec.want_stats)
         ctx.spec = spec
@@ -303,13 +344,34 @@ class _DwFn(torch.autograd.Function):
         C = weight.shape[0]
         if K.nhwc(dy)[4] % K.vec_of(dy.dtype) != 0:
             dy = dy.contiguous()
-        dW9c = K.dwconv_wgrad(x, dy, s.stride, s.dil, s.pro)
-        dW = dW9c.t().reshape(C, 1, 3, 3).contiguous()
         dx = dgamma = dbeta = None
-        if ctx.needs_input_grad[0]:
-            w9c = weight.detach().reshape(C, 9).t().contiguous().float()
-            g = K.dwconv_dgrad(dy, w9c, s.stride, s.dil, (x.shape[1], x.shape[2]))
-            dx, dgamma, dbeta = bn_input_backward(g, x, s.bn_in, s.relu, inplace=True)
+        if s.stride == 1 and ctx.needs_input_grad[0]:
+            # one pass over (dy, x): masked data gradient + weight-gradient partials + BN sums
+            bn = s.bn_in
+            w9c = cached_pack(weight, "dw", lambda: pack_dw_weight(weight))
+            g, dW9c, pb = K.dwconv_bwd_fused(x, dy, w9c, s.dil, s.pro, want_bn=bn is not None)
+            if bn is None:
+                dx = g  # plain / ReLU input: the masked gradient is final
+            else:
+                if bn.group is None:
+                    dgamma, dbeta, c0, c1 = K.bn_bwd_finalize_p(pb, bn.count, bn.mean, bn.invstd,
+                                                                bn.gamma)
+                else:
+                    sums = parallel.allreduce_backward_sums(K.colsum(pb), bn.group)
+                    dgamma, dbeta, c0, c1 = K.bn_bwd_finalize(sums, bn.count, bn.mean, bn.invstd,
+                                                              bn.gamma)
+                    dgamma, dbeta = parallel.local_param_grads(dgamma, dbeta, bn.group)
+                if not bn.training:
+                    c0 = c1 = None
+                # the ReLU mask is already in g: apply only the affine part of the BN backward
+                dx = K.bn_bwd_apply(g, x, (PRO_AFFINE, bn.scale, bn.shift), c0, c1, out=g)
+        else:
+            dW9c = K.dwconv_wgrad(x, dy, s.stride, s.dil, s.pro)
+            if ctx.needs_input_grad[0]:
+                w9c = cached_pack(weight, "dw", lambda: pack_dw_weight(weight))
+                g = K.dwconv_dgrad(dy, w9c, s.stride, s.dil, (x.shape[1], x.shape[2]))
+                dx, dgamma, dbeta = bn_input_backward(g, x, s.bn_in, s.relu, inplace=True)
+        dW = dW9c.t().reshape(C, 1, 3, 3).contiguous()
         return dx, dgamma, dbeta, dW, None
 
 

@@ -155,6 +155,7 @@ def dwconv(x, w9c, stride, dil, pro=None, out=None, want_stats=False):
 
 
 def dwconv_dgrad(dy, w9c, stride, dil, in_hw):
+    """stride 1: `w9c` must hold the taps REVERSED (pack_dw_weight(..., flipped=True))."""
     N, Ho, Wo, C, lddy = nhwc(dy)
     Hi, Wi = in_hw
     dx = torch.empty((N, Hi, Wi, C), dtype=dy.dtype, device=dy.device)
@@ -162,13 +163,27 @@ def dwconv_dgrad(dy, w9c, stride, dil, in_hw):
     if stride == 1:
         # stride-1 data gradient = the forward correlation with the taps flipped (same dilation,
         # pad = dil) -> reuses the forward kernel including its sliding-window fast path
-        LIB.call("seg_dwconv3x3", _DT[dy.dtype], 0, _p(dy), lddy, N, Ho, Wo, C,
-                 _p(w9c.flip(0).contiguous()), 1, dil, PRO_NONE, 0, 0, _p(dx), C, Hi, Wi, 0, gy,
-                 _stream())
+        LIB.call("seg_dwconv3x3", _DT[dy.dtype], 0, _p(dy), lddy, N, Ho, Wo, C, _p(w9c), 1, dil,
+                 PRO_NONE, 0, 0, _p(dx), C, Hi, Wi, 0, gy, _stream())
     else:
         LIB.call("seg_dwconv3x3", _DT[dy.dtype], 1, _p(dy), lddy, N, Ho, Wo, C, _p(w9c), stride,
                  dil, PRO_NONE, 0, 0, _p(dx), C, Hi, Wi, 0, gy, _stream())
     return dx
+
+
+def dwconv_bwd_fused(x, dy, w9c, dil, pro=None, want_bn=False):
+    """stride-1 depthwise backward in one pass: returns (g masked by the prologue's ReLU,
+    dW fp32 [9, C], bn_partial fp32 [gy, 2C] | None)."""
+    N, H, W, C, ldx = nhwc(x)
+    lddy = nhwc(dy)[4]
+    mode, ps, pt = _pro(pro)
+    g = torch.empty((N, H, W, C), dtype=x.dtype, device=x.device)
+    gy = LIB.query("seg_dwconv_grid_y", _DT[x.dtype], C, N, H, W)
+    pw = torch.empty((gy, 9 * C), dtype=torch.float32, device=x.device)
+    pb = torch.empty((gy, 2 * C), dtype=torch.float32, device=x.device) if want_bn else None
+    LIB.call("seg_dwconv3x3_bwd_fused", _DT[x.dtype], _p(dy), lddy, _p(x), ldx, N, H, W, C,
+             _p(w9c), dil, mode, _p(ps), _p(pt), _p(g), C, _p(pw), _p(pb), gy, _stream())
+    return g, colsum(pw, f64=False).view(9, C), pb
 
 
 def dwconv_wgrad(x, dy, stride, dil, pro=None):

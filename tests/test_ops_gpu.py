@@ -171,10 +171,22 @@ def test_dwconv_fwd_dgrad_wgrad(case, dtype):
     dy = quant(rnd(tuple(ref.shape), 3), dtype)
     ref.backward(dy.double())
     dyd = to_dev_nhwc(dy, dtype)
-    g = K().dwconv_dgrad(dyd, w9c, stride, dil, (H, W))
+    g = K().dwconv_dgrad(dyd, w9c.flip(0).contiguous() if stride == 1 else w9c, stride, dil, (H, W))
     assert_close(to_cpu_nchw(g), xa.grad, dtype, "dw dgrad")
     dW = K().dwconv_wgrad(to_dev_nhwc(x, dtype), dyd, stride, dil, pro)
     assert_close(dW.t().reshape(C, 1, 3, 3).cpu(), wd.grad, torch.float32, "dw wgrad", fac=20)
+    if stride == 1:  # fused one-pass backward: masked dgrad + wgrad + BN-backward sums
+        gf, dWf, pb = K().dwconv_bwd_fused(to_dev_nhwc(x, dtype), dyd, w9c, dil, pro, want_bn=True)
+        mask = (xa.detach() > 0).double() if (mode & 1) else torch.ones_like(xa.detach())
+        gref = xa.grad * mask
+        assert_close(to_cpu_nchw(gf), gref, dtype, "fused dw dgrad")
+        assert_close(dWf.t().reshape(C, 1, 3, 3).cpu(), wd.grad, torch.float32, "fused dw wgrad", fac=20)
+        sums = K().colsum(pb).cpu()
+        assert_close(sums[:C], gref.sum((0, 2, 3)), torch.float32, "fused sum g",
+                     scale=gref.abs().sum((0, 2, 3)).max().item(), fac=300 if dtype == torch.bfloat16 else 5)
+        assert_close(sums[C:], (gref * x.double()).sum((0, 2, 3)), torch.float32, "fused sum gx",
+                     scale=(gref * x.double()).abs().sum((0, 2, 3)).max().item(),
+                     fac=300 if dtype == torch.bfloat16 else 5)
 
 
 # ------------------------------------------------------------------------------ batch norm
