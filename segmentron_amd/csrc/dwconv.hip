@@ -40,6 +40,15 @@ struct DwArgs {
   long strips;        // N * Ho * ceil(Wo / TW)
 };
 
+// q = s / d for 0 <= s < 2^24 via a float reciprocal and one fix-up (replaces a ~40-instruction
+// integer division in the per-strip index decode)
+__device__ __forceinline__ int fast_div(int s, int d, float inv) {
+  int q = (int)((float)s * inv);
+  if (q * d > s) --q;
+  if ((q + 1) * d <= s) ++q;
+  return q;
+}
+
 template <int VEC>
 __device__ __forceinline__ void dw_act(float* f, int mode, const float* sc, const float* sh) {
   if (mode & PRO_AFFINE) {
@@ -69,6 +78,7 @@ __global__ __launch_bounds__(DW_THREADS) void dwconv_kernel(const DwArgs a) {
   const T* __restrict__ X = reinterpret_cast<const T*>(a.x);
   T* __restrict__ Y = reinterpret_cast<T*>(a.y);
   const int WQ = (a.Wo + DW_TW - 1) / DW_TW;
+  const float inv_wq = 1.0f / (float)WQ, inv_ho = 1.0f / (float)a.Ho;
 
   float sc[VEC], sh[VEC];
 #pragma unroll
@@ -83,10 +93,10 @@ __global__ __launch_bounds__(DW_THREADS) void dwconv_kernel(const DwArgs a) {
   const int nstrips = (int)a.strips;
   for (int s = blockIdx.y * spb + sy; s < nstrips; s += gridDim.y * spb) {
     if (!cok) continue;
-    const int wq = s % WQ;
-    const int t = s / WQ;
-    const int ho = t % a.Ho;
-    const int n = t / a.Ho;
+    const int t = fast_div(s, WQ, inv_wq);
+    const int wq = s - t * WQ;
+    const int n = fast_div(t, a.Ho, inv_ho);
+    const int ho = t - n * a.Ho;
     const int w0 = wq * DW_TW;
     float acc[DW_TW][VEC];
 #pragma unroll
@@ -103,14 +113,15 @@ __global__ __launch_bounds__(DW_THREADS) void dwconv_kernel(const DwArgs a) {
         float v[DW_TW + 2][VEC];
 #pragma unroll
         for (int q = 0; q < DW_TW + 2; ++q) {
+          // unconditional load from a clamped column + select-to-zero: no divergent branch
+          // around the load, so the six loads of a row issue back to back
           const int wi = w0 - 1 + q;
-          if (wi >= 0 && wi < a.Wi) {
-            Vec<T>::unpack(ldg16(X + (rowbase + wi) * a.ldx + c0), v[q]);
-            dw_act<VEC>(v[q], a.pro_mode, sc, sh);
-          } else {
+          const int wic = min(max(wi, 0), a.Wi - 1);
+          Vec<T>::unpack(ldg16(X + (rowbase + wic) * a.ldx + c0), v[q]);
+          dw_act<VEC>(v[q], a.pro_mode, sc, sh);
+          const float keep = (wi == wic) ? 1.f : 0.f;
 #pragma unroll
-            for (int i = 0; i < VEC; ++i) v[q][i] = 0.f;
-          }
+          for (int i = 0; i < VEC; ++i) v[q][i] *= keep;
         }
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw) {
@@ -228,6 +239,7 @@ __global__ __launch_bounds__(DW_THREADS) void dwconv_wgrad_kernel(const DwWgradA
   const T* __restrict__ X = reinterpret_cast<const T*>(a.x);
   const T* __restrict__ DY = reinterpret_cast<const T*>(a.dy);
   const int WQ = (a.Wo + DW_TW - 1) / DW_TW;
+  const float inv_wq = 1.0f / (float)WQ, inv_ho = 1.0f / (float)a.Ho;
 
   float sc[VEC], sh[VEC];
 #pragma unroll
@@ -244,21 +256,20 @@ __global__ __launch_bounds__(DW_THREADS) void dwconv_wgrad_kernel(const DwWgradA
   const int nstrips = (int)a.strips;
   for (int s = blockIdx.y * spb + sy; s < nstrips; s += gridDim.y * spb) {
     if (!cok) continue;
-    const int wq = s % WQ;
-    const int t = s / WQ;
-    const int ho = t % a.Ho;
-    const int n = t / a.Ho;
+    const int t = fast_div(s, WQ, inv_wq);
+    const int wq = s - t * WQ;
+    const int n = fast_div(t, a.Ho, inv_ho);
+    const int ho = t - n * a.Ho;
     const int w0 = wq * DW_TW;
     const long orow = ((long)n * a.Ho + ho) * a.Wo;
     float g[DW_TW][VEC];
 #pragma unroll
     for (int j = 0; j < DW_TW; ++j) {
-      if (w0 + j < a.Wo) {
-        Vec<T>::unpack(ldg16(DY + (orow + w0 + j) * a.lddy + c0), g[j]);
-      } else {
+      const int wc = min(w0 + j, a.Wo - 1);
+      Vec<T>::unpack(ldg16(DY + (orow + wc) * a.lddy + c0), g[j]);
+      const float keep = (w0 + j < a.Wo) ? 1.f : 0.f;
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) g[j][i] = 0.f;
-      }
+      for (int i = 0; i < VEC; ++i) g[j][i] *= keep;
     }
     if (FAST) {
 #pragma unroll
@@ -269,14 +280,15 @@ __global__ __launch_bounds__(DW_THREADS) void dwconv_wgrad_kernel(const DwWgradA
         float v[DW_TW + 2][VEC];
 #pragma unroll
         for (int q = 0; q < DW_TW + 2; ++q) {
+          // unconditional load from a clamped column + select-to-zero: no divergent branch
+          // around the load, so the six loads of a row issue back to back
           const int wi = w0 - 1 + q;
-          if (wi >= 0 && wi < a.Wi) {
-            Vec<T>::unpack(ldg16(X + (rowbase + wi) * a.ldx + c0), v[q]);
-            dw_act<VEC>(v[q], a.pro_mode, sc, sh);
-          } else {
+          const int wic = min(max(wi, 0), a.Wi - 1);
+          Vec<T>::unpack(ldg16(X + (rowbase + wic) * a.ldx + c0), v[q]);
+          dw_act<VEC>(v[q], a.pro_mode, sc, sh);
+          const float keep = (wi == wic) ? 1.f : 0.f;
 #pragma unroll
-            for (int i = 0; i < VEC; ++i) v[q][i] = 0.f;
-          }
+          for (int i = 0; i < VEC; ++i) v[q][i] *= keep;
         }
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw)
@@ -363,6 +375,7 @@ __global__ __launch_bounds__(DW_THREADS) void dwconv_bwd_fused_kernel(const DwBw
   const T* __restrict__ X = reinterpret_cast<const T*>(a.x);
   T* __restrict__ G = reinterpret_cast<T*>(a.g);
   const int WQ = (a.W + DW_TW - 1) / DW_TW;
+  const float inv_wq = 1.0f / (float)WQ, inv_h = 1.0f / (float)a.H;
   const int d = a.dil;
 
   float sc[VEC], sh[VEC];
@@ -382,31 +395,29 @@ __global__ __launch_bounds__(DW_THREADS) void dwconv_bwd_fused_kernel(const DwBw
   const int nstrips = (int)a.strips;
   for (int s = blockIdx.y * spb + sy; s < nstrips; s += gridDim.y * spb) {
     if (!cok) continue;
-    const int wq = s % WQ;
-    const int t = s / WQ;
-    const int h = t % a.H;
-    const int n = t / a.H;
+    const int t = fast_div(s, WQ, inv_wq);
+    const int wq = s - t * WQ;
+    const int n = fast_div(t, a.H, inv_h);
+    const int h = t - n * a.H;
     const int w0 = wq * DW_TW;
     const long prow = ((long)n * a.H + h) * a.W;
     // centre pixels: raw x (for mask / BN sums) and activated x (for the weight gradient)
     float xr[DW_TW][VEC], xa[DW_TW][VEC], g[DW_TW][VEC];
 #pragma unroll
     for (int j = 0; j < DW_TW; ++j) {
-      if (w0 + j < a.W) {
-        HVec<T>::load(X + (prow + w0 + j) * a.ldx + c0, xr[j]);
-      } else {
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) xr[j][i] = 0.f;
-      }
+      const int wc = min(w0 + j, a.W - 1);
+      HVec<T>::load(X + (prow + wc) * a.ldx + c0, xr[j]);
+      const float keep = (w0 + j < a.W) ? 1.f : 0.f;
 #pragma unroll
       for (int i = 0; i < VEC; ++i) {
         xa[j][i] = xr[j][i];
         g[j][i] = 0.f;
       }
       dw_act<VEC>(xa[j], a.pro_mode, sc, sh);
-      if (!(w0 + j < a.W)) {
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) xa[j][i] = 0.f;
+      for (int i = 0; i < VEC; ++i) {
+        xa[j][i] *= keep;
+        xr[j][i] *= keep;
       }
     }
 #pragma unroll
@@ -419,12 +430,11 @@ __global__ __launch_bounds__(DW_THREADS) void dwconv_bwd_fused_kernel(const DwBw
 #pragma unroll
         for (int q = 0; q < DW_TW + 2; ++q) {
           const int c = w0 - 1 + q;
-          if (c >= 0 && c < a.W) {
-            HVec<T>::load(DY + (rowbase + c) * a.lddy + c0, v[q]);
-          } else {
+          const int cc = min(max(c, 0), a.W - 1);
+          HVec<T>::load(DY + (rowbase + cc) * a.lddy + c0, v[q]);
+          const float keep = (c == cc) ? 1.f : 0.f;
 #pragma unroll
-            for (int i = 0; i < VEC; ++i) v[q][i] = 0.f;
-          }
+          for (int i = 0; i < VEC; ++i) v[q][i] *= keep;
         }
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw) {
