@@ -27,8 +27,16 @@ def timeit(fn, iters=20):
 
 
 def main():
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", type=int, default=-1)
+    ap.add_argument("--what", default="all")
+    ap.add_argument("--iters", type=int, default=20)
+    args = ap.parse_args()
     dt = torch.bfloat16
-    for name, N, H, W, C in SHAPES:
+    for idx, (name, N, H, W, C) in enumerate(SHAPES):
+        if args.only >= 0 and idx != args.only:
+            continue
         dil = 2 if "d2" in name else 1
         x = torch.randn((N, H, W, C), device="cuda").to(dt)
         dy = torch.randn((N, H, W, C), device="cuda").to(dt)
@@ -41,7 +49,10 @@ def main():
 
         def rec(key, us, passes):
             r[key] = {"us": round(us, 1), "GBps": round(passes * mb / us * 1e3, 0)}
-        rec("fwd+stats", timeit(lambda: K.dwconv(x, w9c, 1, dil, pro, want_stats=True)), 2)
+        rec("fwd+stats", timeit(lambda: K.dwconv(x, w9c, 1, dil, pro, want_stats=True), args.iters), 2)
+        if args.what == "fwd":
+            print(json.dumps(r), flush=True)
+            continue
         rec("dgrad", timeit(lambda: K.dwconv_dgrad(dy, w9c, 1, dil, (H, W))), 2)
         rec("wgrad", timeit(lambda: K.dwconv_wgrad(x, dy, 1, dil, pro)), 2)
         rec("bn_reduce", timeit(lambda: K.bn_bwd_reduce_partial(dy, x, pro)), 2)
