@@ -41,6 +41,14 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
 template <typename T> struct Vec;
 template <> struct Vec<float> {
   static constexpr int N = 4;
+  typedef uint4 raw_t;
+  __device__ static __forceinline__ raw_t load_raw(const float* p) {
+    return *reinterpret_cast<const uint4*>(p);
+  }
+  __device__ static __forceinline__ void unpack_raw(const raw_t& v, float* f) { unpack(v, f); }
+  __device__ static __forceinline__ void store(float* p, const float* f) {
+    *reinterpret_cast<uint4*>(p) = pack(f);
+  }
   __device__ static __forceinline__ void unpack(const uint4& v, float* f) {
     f[0] = __uint_as_float(v.x); f[1] = __uint_as_float(v.y);
     f[2] = __uint_as_float(v.z); f[3] = __uint_as_float(v.w);
@@ -54,6 +62,14 @@ template <> struct Vec<float> {
 };
 template <> struct Vec<bf16_t> {
   static constexpr int N = 8;
+  typedef uint4 raw_t;
+  __device__ static __forceinline__ raw_t load_raw(const bf16_t* p) {
+    return *reinterpret_cast<const uint4*>(p);
+  }
+  __device__ static __forceinline__ void unpack_raw(const raw_t& v, float* f) { unpack(v, f); }
+  __device__ static __forceinline__ void store(bf16_t* p, const float* f) {
+    *reinterpret_cast<uint4*>(p) = pack(f);
+  }
   __device__ static __forceinline__ void unpack(const uint4& v, float* f) {
     f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xFFFF0000u);
     f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xFFFF0000u);
@@ -72,6 +88,13 @@ template <> struct Vec<bf16_t> {
 template <typename T> struct HVec;
 template <> struct HVec<float> {
   static constexpr int N = 4;
+  typedef uint4 raw_t;
+  __device__ static __forceinline__ raw_t load_raw(const float* p) {
+    return *reinterpret_cast<const uint4*>(p);
+  }
+  __device__ static __forceinline__ void unpack_raw(const raw_t& v, float* f) {
+    Vec<float>::unpack(v, f);
+  }
   __device__ static __forceinline__ void load(const float* p, float* f) {
     const uint4 v = *reinterpret_cast<const uint4*>(p);
     Vec<float>::unpack(v, f);
@@ -82,6 +105,14 @@ template <> struct HVec<float> {
 };
 template <> struct HVec<bf16_t> {
   static constexpr int N = 4;
+  typedef uint2 raw_t;
+  __device__ static __forceinline__ raw_t load_raw(const bf16_t* p) {
+    return *reinterpret_cast<const uint2*>(p);
+  }
+  __device__ static __forceinline__ void unpack_raw(const raw_t& v, float* f) {
+    f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xFFFF0000u);
+    f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xFFFF0000u);
+  }
   __device__ static __forceinline__ void load(const bf16_t* p, float* f) {
     const uint2 v = *reinterpret_cast<const uint2*>(p);
     f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xFFFF0000u);

@@ -16,6 +16,7 @@
 // channel vectors, blockIdx.y the strips (grid-stride), one row of statistics partials per
 // blockIdx.y (deterministic: LDS tree over the strips of a block, fp64 finish in bn_finalize).
 #include "common.h"
+#include <type_traits>
 
 namespace seg {
 
@@ -65,8 +66,11 @@ __device__ __forceinline__ void dw_act(float* f, int mode, const float* sc, cons
 // gradient through flipped taps): per input row the TW+2 needed vectors are loaded and
 // activated ONCE and reused by the three horizontal taps (18 loads / strip instead of 36).
 template <typename T, int MODE, bool FAST>
-__global__ __launch_bounds__(DW_THREADS) void dwconv_kernel(const DwArgs a) {
-  constexpr int VEC = Vec<T>::N;
+__global__ __launch_bounds__(DW_THREADS, FAST ? 3 : 2) void dwconv_kernel(const DwArgs a) {
+  // FAST: 4 channels per thread (8-byte bf16 vectors) so that 18 packed loads + accumulators fit
+  // ~120 VGPRs (3-4 waves/SIMD, all loads of a strip in flight); generic: 16-byte vectors
+  using V = typename std::conditional<FAST, HVec<T>, Vec<T>>::type;
+  constexpr int VEC = V::N;
   extern __shared__ __attribute__((aligned(16))) float dw_smem[];
   const int tid = threadIdx.x;
   const int cvb = 1 << a.cvb_log2;
@@ -105,21 +109,38 @@ __global__ __launch_bounds__(DW_THREADS) void dwconv_kernel(const DwArgs a) {
       for (int i = 0; i < VEC; ++i) acc[j][i] = 0.f;
 
     if (FAST) {
-#pragma unroll 1
+      // all 18 loads of the strip are issued before the first use (kept packed: 72 VGPRs) from
+      // clamped row / column indices — no branch sits between loads, one wait covers them all;
+      // out-of-image taps are zeroed by a select after the activation (= zero padding).
+      typename V::raw_t raw[3][DW_TW + 2];
+      float ckeep[DW_TW + 2], rkeep[3];
+#pragma unroll
+      for (int q = 0; q < DW_TW + 2; ++q) {
+        const int wi = w0 - 1 + q;
+        ckeep[q] = (wi >= 0 && wi < a.Wi) ? 1.f : 0.f;
+      }
+#pragma unroll
       for (int kh = 0; kh < 3; ++kh) {
         const int hi = ho - 1 + kh;
-        if (hi < 0 || hi >= a.Hi) continue;
-        const long rowbase = ((long)n * a.Hi + hi) * a.Wi;
+        const int hic = min(max(hi, 0), a.Hi - 1);
+        rkeep[kh] = (hi == hic) ? 1.f : 0.f;
+        // 32-bit element offsets from the (uniform) tensor base: one VGPR per address and the
+        // compiler can use the scalar-base + vector-offset form of global_load
+        const unsigned rowbase = (unsigned)((n * a.Hi + hic) * a.Wi);
+#pragma unroll
+        for (int q = 0; q < DW_TW + 2; ++q) {
+          const unsigned wic = (unsigned)min(max(w0 - 1 + q, 0), a.Wi - 1);
+          raw[kh][q] = V::load_raw(X + ((rowbase + wic) * (unsigned)a.ldx + (unsigned)c0));
+        }
+      }
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
         float v[DW_TW + 2][VEC];
 #pragma unroll
         for (int q = 0; q < DW_TW + 2; ++q) {
-          // unconditional load from a clamped column + select-to-zero: no divergent branch
-          // around the load, so the six loads of a row issue back to back
-          const int wi = w0 - 1 + q;
-          const int wic = min(max(wi, 0), a.Wi - 1);
-          Vec<T>::unpack(ldg16(X + (rowbase + wic) * a.ldx + c0), v[q]);
+          V::unpack_raw(raw[kh][q], v[q]);
           dw_act<VEC>(v[q], a.pro_mode, sc, sh);
-          const float keep = (wi == wic) ? 1.f : 0.f;
+          const float keep = ckeep[q] * rkeep[kh];
 #pragma unroll
           for (int i = 0; i < VEC; ++i) v[q][i] *= keep;
         }
@@ -167,7 +188,7 @@ __global__ __launch_bounds__(DW_THREADS) void dwconv_kernel(const DwArgs a) {
             ok = ok && wi >= 0 && wi < a.Wi;
             if (ok) {
               float f[VEC];
-              Vec<T>::unpack(ldg16(X + (rowbase + wi) * a.ldx + c0), f);
+              V::unpack_raw(V::load_raw(X + (rowbase + wi) * a.ldx + c0), f);
               dw_act<VEC>(f, a.pro_mode, sc, sh);
 #pragma unroll
               for (int i = 0; i < VEC; ++i) acc[j][i] = fmaf(f[i], wv[i], acc[j][i]);
@@ -180,7 +201,7 @@ __global__ __launch_bounds__(DW_THREADS) void dwconv_kernel(const DwArgs a) {
 #pragma unroll
     for (int j = 0; j < DW_TW; ++j) {
       if (w0 + j < a.Wo) {
-        stg16(Y + (orow + w0 + j) * a.ldy + c0, Vec<T>::pack(acc[j]));
+        V::store(Y + (orow + w0 + j) * a.ldy + c0, acc[j]);
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
           ssum[i] += acc[j][i];
@@ -420,19 +441,33 @@ __global__ __launch_bounds__(DW_THREADS) void dwconv_bwd_fused_kernel(const DwBw
         xr[j][i] *= keep;
       }
     }
+    if (FAST) {
+      typename HVec<T>::raw_t raw[3][DW_TW + 2];
+      float ckeep[DW_TW + 2], rkeep[3];
 #pragma unroll
-    for (int kh = 0; kh < 3; ++kh) {
-      const int r = h + (1 - kh) * d;  // dy row feeding tap row kh
-      if (r < 0 || r >= a.H) continue;
-      const long rowbase = ((long)n * a.H + r) * a.W;
-      if (FAST) {
+      for (int q = 0; q < DW_TW + 2; ++q) {
+        const int c = w0 - 1 + q;
+        ckeep[q] = (c >= 0 && c < a.W) ? 1.f : 0.f;
+      }
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+        const int r = h + 1 - kh;  // dy row feeding tap row kh
+        const int rc = min(max(r, 0), a.H - 1);
+        rkeep[kh] = (r == rc) ? 1.f : 0.f;
+        const unsigned rowbase = (unsigned)((n * a.H + rc) * a.W);
+#pragma unroll
+        for (int q = 0; q < DW_TW + 2; ++q) {
+          const unsigned cc = (unsigned)min(max(w0 - 1 + q, 0), a.W - 1);
+          raw[kh][q] = HVec<T>::load_raw(DY + ((rowbase + cc) * (unsigned)a.lddy + (unsigned)c0));
+        }
+      }
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
         float v[DW_TW + 2][VEC];
 #pragma unroll
         for (int q = 0; q < DW_TW + 2; ++q) {
-          const int c = w0 - 1 + q;
-          const int cc = min(max(c, 0), a.W - 1);
-          HVec<T>::load(DY + (rowbase + cc) * a.lddy + c0, v[q]);
-          const float keep = (c == cc) ? 1.f : 0.f;
+          HVec<T>::unpack_raw(raw[kh][q], v[q]);
+          const float keep = ckeep[q] * rkeep[kh];
 #pragma unroll
           for (int i = 0; i < VEC; ++i) v[q][i] *= keep;
         }
@@ -450,7 +485,13 @@ __global__ __launch_bounds__(DW_THREADS) void dwconv_bwd_fused_kernel(const DwBw
               accw[kh * 3 + kw][i] = fmaf(dyv, xa[j][i], accw[kh * 3 + kw][i]);
             }
         }
-      } else {
+      }
+    } else {
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+        const int r = h + (1 - kh) * d;
+        if (r < 0 || r >= a.H) continue;
+        const long rowbase = ((long)n * a.H + r) * a.W;
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw) {
           float wv[VEC];
@@ -564,15 +605,17 @@ extern "C" int seg_dwconv3x3(int dtype, int mode, const void* x, long ldx, int N
   a.stat_partial = stat_partial; a.ldx = ldx; a.ldy = ldy;
   a.N = N; a.Hi = Hi; a.Wi = Wi; a.C = C; a.Ho = Ho; a.Wo = Wo;
   a.stride = stride; a.pad = dil; a.dil = dil; a.pro_mode = pro_mode;
-  a.CV = C / vec; a.cvb_log2 = pick_cvb_log2(a.CV);
+  const bool fast = mode == MODE_FWD && stride == 1 && dil == 1;  // dgrad: flipped taps, mode 0
+  const int kvec = fast ? 4 : vec;  // channels per thread
+  a.CV = C / kvec; a.cvb_log2 = pick_cvb_log2(a.CV);
   a.strips = (long)N * Ho * ((Wo + DW_TW - 1) / DW_TW);
   const int gx = (a.CV + (1 << a.cvb_log2) - 1) >> a.cvb_log2;
   SEG_REQUIRE(grid_y >= 1, "dwconv3x3: grid_y must be >= 1");
   const dim3 grid(gx, grid_y);
-  const size_t lds = stat_partial ? (size_t)DW_THREADS * 2 * vec * sizeof(float) : 0;
+  const size_t lds = stat_partial ? (size_t)DW_THREADS * 2 * kvec * sizeof(float) : 0;
   hipStream_t st = (hipStream_t)stream;
   SEG_REQUIRE(a.strips < (1L << 31), "dwconv3x3: too many strips");
-  const bool fast = stride == 1 && dil == 1;  // for dgrad the host passes flipped taps, mode 0
+  SEG_REQUIRE((long)N * Hi * Wi * ldx < (1L << 31), "dwconv3x3: tensor exceeds 32-bit offsets");
 #define SEG_DW_LAUNCH(TT, MM, FF) \
   hipLaunchKernelGGL((dwconv_kernel<TT, MM, FF>), grid, dim3(DW_THREADS), lds, st, a)
   if (dtype == DT_BF16) {
@@ -643,6 +686,7 @@ extern "C" int seg_dwconv3x3_bwd_fused(int dtype, const void* dy, long lddy, con
   a.pro_mode = pro_mode; a.CV = C / vec; a.cvb_log2 = pick_cvb_log2(a.CV);
   a.strips = (long)N * H * ((W + DW_TW - 1) / DW_TW);
   SEG_REQUIRE(a.strips < (1L << 31), "dwconv3x3_bwd_fused: too many strips");
+  SEG_REQUIRE((long)N * H * W * lddy < (1L << 31), "dwconv3x3_bwd_fused: 32-bit offsets");
   const int gx = (a.CV + (1 << a.cvb_log2) - 1) >> a.cvb_log2;
   const dim3 grid(gx, grid_y);
   const size_t lds = (size_t)DW_THREADS * 3 * vec * sizeof(float);
