@@ -345,8 +345,11 @@ class _DwFn(torch.autograd.Function):
         if K.nhwc(dy)[4] % K.vec_of(dy.dtype) != 0:
             dy = dy.contiguous()
         dx = dgamma = dbeta = None
-        if s.stride == 1 and ctx.needs_input_grad[0]:
+        big = x.numel() * x.element_size() >= (40 << 20)
+        if s.stride == 1 and ctx.needs_input_grad[0] and big:
             # one pass over (dy, x): masked data gradient + weight-gradient partials + BN sums
+            # (tools/dw_bench.py: 397 vs 707 us on the 269 MB entry-flow tensors; on the 24 MB
+            # middle-flow tensors the three separate kernels are faster, 115 vs 131 us)
             bn = s.bn_in
             w9c = cached_pack(weight, "dw", lambda: pack_dw_weight(weight))
             g, dW9c, pb = K.dwconv_bwd_fused(x, dy, w9c, s.dil, s.pro, want_bn=bn is not None)
@@ -368,7 +371,10 @@ class _DwFn(torch.autograd.Function):
         else:
             dW9c = K.dwconv_wgrad(x, dy, s.stride, s.dil, s.pro)
             if ctx.needs_input_grad[0]:
-                w9c = cached_pack(weight, "dw", lambda: pack_dw_weight(weight))
+                if s.stride == 1:  # forward kernel with reversed taps
+                    w9c = cached_pack(weight, "dw_flip", lambda: pack_dw_weight(weight, True))
+                else:
+                    w9c = cached_pack(weight, "dw", lambda: pack_dw_weight(weight))
                 g = K.dwconv_dgrad(dy, w9c, s.stride, s.dil, (x.shape[1], x.shape[2]))
                 dx, dgamma, dbeta = bn_input_backward(g, x, s.bn_in, s.relu, inplace=True)
         dW = dW9c.t().reshape(C, 1, 3, 3).contiguous()
