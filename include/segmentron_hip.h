@@ -40,6 +40,9 @@ int seg_version(void);
  * out_s != 1 scatters output pixel (n,ho,wo) to row ((n*out_H + ho*out_s)*out_W + wo*out_s)
  * (data-gradient of a strided 1x1 conv; the caller zero-fills y first).
  * The same entry point computes data gradients: pass dy as x and the transposed/flipped weights.
+ * tconv = 1: transposed-stride gather — x is dy [N,Hi,Wi,C=O_fwd], (Ho,Wo) the size of dx, w packed
+ * [C_fwd][KH*KW*O_fwd] (not flipped): dx[h,w] = sum dy[(h+pad-kh*dil)/stride, ...] W (exact
+ * divisions only) = data gradient of a strided KxK convolution (resnet.py:52-53, hrnet.py:195-204).
  * ep_x (nullable, addressed like y with pitch ldep) fuses the BatchNorm-backward correction of a
  * folded layer into the store: y = acc - ep_c0[o] - ep_c1[o]*ep_x[row][o] (see seg_fold_*). */
 int seg_conv_gemm_fwd(int dtype, const void* x, long ldx, int N, int Hi, int Wi, int C,
@@ -47,7 +50,7 @@ int seg_conv_gemm_fwd(int dtype, const void* x, long ldx, int N, int Hi, int Wi,
                       int pro_mode, const float* pro_scale, const float* pro_shift,
                       const float* bias, void* y, long ldy, int Ho, int Wo, int out_H, int out_W,
                       int out_s, float* stat_partial, const void* ep_x, long ldep,
-                      const float* ep_c0, const float* ep_c1, void* stream);
+                      const float* ep_c0, const float* ep_c1, int tconv, void* stream);
 int seg_conv_gemm_tiles_m(int N, int Ho, int Wo);
 /* tuning knob (not a correctness switch): LDS pipeline variant of the GEMM kernels; returns the
  * previous value, negative = query only. */
@@ -118,11 +121,12 @@ int seg_bn_eval_affine(const float* gamma, const float* beta, const float* rm, c
                        float eps, float* scale, float* shift, int C, void* stream);
 /* Materialise: y = post_relu?( act_x(x) * chan_mul[n][c] + act_r(r) )  (r, chan_mul nullable).
  * Covers BN+ReLU materialisation, the residual adds of xception.py:40,42 / resnet.py:38,78 and
- * nn.Dropout2d (segmentron/modules/module.py:60; chan_mul = mask/(1-p), rows_per_n = H*W). */
+ * nn.Dropout2d (segmentron/modules/module.py:60; chan_mul = mask/(1-p), rows_per_n = H*W) and
+ * nn.Dropout (module.py:21, pspnet.py:52; elem_mul = per-element mask/(1-p) of the element type). */
 int seg_bn_apply(int dtype, const void* x, long ldx, int mode_x, const float* sx, const float* tx,
                  const void* r, long ldr, int mode_r, const float* sr, const float* tr,
-                 const float* chan_mul, long rows_per_n, int post_relu, void* y, long ldy, long M,
-                 int C, void* stream);
+                 const float* chan_mul, long rows_per_n, const void* elem_mul, long ldm,
+                 int post_relu, void* y, long ldy, long M, int C, void* stream);
 /* Backward of "act(x) consumed with gradient g": g' = g * chan_mul * relu_mask.
  * reduce  : partial[grid_y][2][C] = (sum g', sum g'*x) per block
  * finalize: dgamma, dbeta and the coefficients c0,c1 of  dx = scale*g' - c0 - c1*x
@@ -130,7 +134,8 @@ int seg_bn_apply(int dtype, const void* x, long ldx, int mode_x, const float* sx
 int seg_bn_bwd_grid_y(int dtype, int C, long M);
 int seg_bn_bwd_reduce(int dtype, const void* g, long ldg, const void* x, long ldx, int mode,
                       const float* scale, const float* shift, const float* chan_mul,
-                      long rows_per_n, long M, int C, float* partial, int grid_y, void* stream);
+                      long rows_per_n, const void* elem_mul, long ldm, long M, int C,
+                      float* partial, int grid_y, void* stream);
 int seg_bn_bwd_finalize(const double* sums, double count, const float* mean, const float* invstd,
                         const float* gamma, float* dgamma, float* dbeta, float* c0, float* c1,
                         int C, void* stream);
@@ -139,8 +144,8 @@ int seg_bn_bwd_finalize_p(const float* partial, long R, double count, const floa
                           float* c0, float* c1, int C, double* ws, void* stream);
 int seg_bn_bwd_apply(int dtype, const void* g, long ldg, const void* x, long ldx, int mode,
                      const float* scale, const float* shift, const float* c0, const float* c1,
-                     const float* chan_mul, long rows_per_n, void* dx, long lddx, long M, int C,
-                     void* stream);
+                     const float* chan_mul, long rows_per_n, const void* elem_mul, long ldm,
+                     void* dx, long lddx, long M, int C, void* stream);
 
 /* ---- linear BatchNorm folded into a 1x1 convolution -------------------------------------------
  * `relu_first` SeparableConv2d (segmentron/modules/basic.py:46-50) has no non-linearity between
@@ -158,6 +163,25 @@ int seg_fold_bwd_reduce(const float* W, const float* dWp, const float* scale, co
 int seg_fold_bwd_finalize(const float* dsdt, double count, const float* mean, const float* invstd,
                           const float* gamma, const float* scale, float* dgamma, float* dbeta,
                           float* c0, float* c1, int C, void* stream);
+
+/* ---- pooling --------------------------------------------------------------------------------
+ * nn.MaxPool2d(k, stride, pad) (segmentron/models/backbones/resnet.py:119) on a deferred
+ * activation; idx = one byte per output element (winning tap), consumed by the backward gather. */
+int seg_maxpool_fwd(int dtype, const void* x, long ldx, int N, int Hi, int Wi, int C, int k,
+                    int stride, int pad, int pro_mode, const float* pro_scale,
+                    const float* pro_shift, void* y, long ldy, int Ho, int Wo, void* idx,
+                    void* stream);
+int seg_maxpool_bwd(int dtype, void* gx, long ldgx, int N, int Hi, int Wi, int C, int k, int stride,
+                    int pad, const void* gy, long ldgy, int Ho, int Wo, const void* idx,
+                    void* stream);
+/* nn.AdaptiveAvgPool2d(o) (segmentron/modules/module.py:52,89), ATen bins
+ * [floor(i*H/o), ceil((i+1)*H/o)).  partial: fp32 [chunks][N*o*o][C] bin SUMS (reduce over chunks
+ * with seg_colsum, divide by the bin area). */
+int seg_adaptive_avgpool_chunks(int H, int W, int o);
+int seg_adaptive_avgpool_partial(int dtype, const void* x, long ldx, int N, int H, int W, int C,
+                                 int o, float* partial, int chunks, void* stream);
+int seg_adaptive_avgpool_bwd(int dtype, void* gx, long ldgx, int N, int H, int W, int C, int o,
+                             const void* gy, long ldgy, void* stream);
 
 /* ---- F.interpolate(mode='bilinear') ---------------------------------------------------------
  * Replaces segmentron/models/deeplabv3_plus.py:39,44,71; segmentron/modules/module.py:64,96;

@@ -1,0 +1,118 @@
+#!/usr/bin/env python3
+"""Fixtures for the other BASELINE configs, generated from the REFERENCE (dev container only).
+
+    python oracle/gen_golden_more.py c1     # FCN resnet50 (OS16)            -> tests/golden/c1_*
+    python oracle/gen_golden_more.py c4     # PSPNet resnet50 (OS8, aux)     -> tests/golden/c4_*
+
+One process per model (the reference cfg singleton freezes).  resnet50 is used instead of
+resnet101 to keep the fixtures small — same blocks, same code path (BASELINE C1 as written,
+"FCN-resnet18", cannot run in the reference: fcn.py:16 hard-codes 2048 input channels, F4).
+Each run asserts that oracle/torch_ref.py reproduces the reference bit-for-bit (forward and
+every parameter gradient) before writing:
+  <tag>_state_keys.json, <tag>_bn_calib.npz, <tag>_eval.npz (logits), <tag>_train.npz
+  (loss, per-output logits checksum, grad norms, a few full gradients).
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+from oracle import ref_import, synth, torch_ref  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+CASES = {
+    "c1": dict(yaml="configs/cityscapes_fcn.yaml", over=["MODEL.BACKBONE", "resnet50"],
+               fn="fcn_resnet", os=16, aux=False, hw=(65, 97), eps_enc=None),
+    "c4": dict(yaml="configs/cityscapes_pspnet_resnet.yaml", over=["MODEL.BACKBONE", "resnet50"],
+               fn="pspnet_resnet", os=8, aux=True, hw=(49, 65), eps_enc=None),
+}
+
+
+def main(tag):
+    c = CASES[tag]
+    torch.set_num_threads(min(16, os.cpu_count()))
+    model, cfg = ref_import.build_reference_model(c["yaml"], c["over"])
+    ref_import.apply_bn_attrs(model, cfg)
+    sd0 = model.state_dict()
+    json.dump({"model": cfg.MODEL.MODEL_NAME, "backbone": cfg.MODEL.BACKBONE, "config": c["yaml"],
+               "overrides": c["over"], "n_params": int(sum(p.numel() for p in model.parameters())),
+               "keys": [(k, list(v.shape)) for k, v in sd0.items()]},
+              open(os.path.join(GOLD, tag + "_state_keys.json"), "w"))
+    sd = synth.synth_like(sd0, seed=0)
+    model.load_state_dict(sd, strict=True)
+    H, W = c["hw"]
+    x = synth.synth_images(2, H, W, seed=0)
+    y = synth.synth_targets(2, H, W, seed=0)
+    drops = [m for m in model.modules() if isinstance(m, (torch.nn.Dropout, torch.nn.Dropout2d))]
+    for d in drops:
+        d.p = 0.0
+    # calibrate BN running stats (see gen_golden.py)
+    bns = [m for m in model.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+    saved = [m.momentum for m in bns]
+    for m in bns:
+        m.momentum = 1.0
+    model.train()
+    with torch.no_grad():
+        model(x)
+    for m, mom in zip(bns, saved):
+        m.momentum = mom
+    calib = {}
+    msd = model.state_dict()
+    for k, v in msd.items():
+        if k.endswith("running_var"):
+            calib[k] = (v * (0.8 + 0.45 * torch.rand(v.shape, generator=synth._gen(7, k)))).clone()
+        elif k.endswith("running_mean"):
+            rv = msd[k[:-4] + "var"]
+            calib[k] = (v + 0.05 * rv.sqrt() * torch.randn(v.shape, generator=synth._gen(7, k))).clone()
+    np.savez_compressed(os.path.join(GOLD, tag + "_bn_calib.npz"),
+                        **{k: v.numpy() for k, v in calib.items()})
+    sd.update(calib)
+    for k in sd:
+        if k.endswith("num_batches_tracked"):
+            sd[k] = torch.zeros((), dtype=torch.long)
+    model.load_state_dict(sd, strict=True)
+
+    kw = dict(output_stride=c["os"], aux=c["aux"], eps_encoder=c["eps_enc"], drop_p=0.0)
+    model.eval()
+    with torch.no_grad():
+        outs = model(x)
+        net = torch_ref.OracleNet(torch_ref.clone_state(sd), training=False, **kw)
+        o_outs = getattr(net, c["fn"])(x)
+    for a, b in zip(outs, o_outs):
+        assert (a - b).abs().max().item() == 0.0, "oracle differs from the reference (eval)"
+    print(tag, "eval logits", tuple(outs[0].shape), "absmax %.3f" % outs[0].abs().max().item())
+    np.savez_compressed(os.path.join(GOLD, tag + "_eval.npz"), logits=outs[0].numpy(),
+                        argmax=outs[0].argmax(1).to(torch.uint8).numpy())
+
+    model.train()
+    model.zero_grad()
+    outs = model(x)
+    loss = torch_ref.mix_softmax_ce(outs, y, aux_weight=cfg.SOLVER.AUX_WEIGHT)
+    loss.backward()
+    grads = {k: p.grad for k, p in model.named_parameters() if p.grad is not None}
+    osd = torch_ref.clone_state(sd, requires_grad=True)
+    net = torch_ref.OracleNet(osd, training=True, **kw)
+    o_outs = getattr(net, c["fn"])(x)
+    o_loss = torch_ref.mix_softmax_ce(o_outs, y, aux_weight=cfg.SOLVER.AUX_WEIGHT)
+    o_loss.backward()
+    assert abs(loss.item() - o_loss.item()) == 0.0
+    worst = max((osd[k].grad - g).abs().max().item() for k, g in grads.items())
+    assert worst == 0.0, "oracle backward differs from the reference: %g" % worst
+    print(tag, "train loss %.6f; oracle == reference bit-for-bit (fwd + %d grads)" % (loss.item(), len(grads)))
+    names = list(grads)
+    payload = {"loss": np.float64(loss.item()), "logits": outs[0].detach().numpy(),
+               "grad_norm_keys": np.array(names),
+               "grad_norms": np.array([float(grads[k].double().norm()) for k in names])}
+    for k in names[:2] + names[len(names) // 2:len(names) // 2 + 2] + names[-2:]:
+        if grads[k].numel() <= 300000:
+            payload["grad::" + k] = grads[k].numpy()
+    np.savez_compressed(os.path.join(GOLD, tag + "_train.npz"), **payload)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])

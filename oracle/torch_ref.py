@@ -173,6 +173,102 @@ class OracleNet:
         return tuple(outs)
 
 
+# ---------------------------------------------------------------------- ResNet / FCN / PSPNet
+def _resnet_plan(self):
+    os_ = self.output_stride
+    if os_ == 32:
+        return [1, 1], [2, 2]
+    if os_ == 16:
+        return [1, 2], [2, 1]
+    if os_ == 8:
+        return [2, 4], [1, 1]
+    raise NotImplementedError
+
+
+def _res_block(self, x, p, stride, dilation, previous_dilation):
+    """BasicBlockV1b / BottleneckV1b — segmentron/models/backbones/resnet.py:9-81."""
+    sd = self.sd
+    identity = x
+    if (p + ".conv3.weight") in sd:  # bottleneck: 1x1 -> 3x3(stride, dil) -> 1x1
+        out = F.relu(self.bn(self.conv(x, p + ".conv1"), p + ".bn1"))
+        out = F.relu(self.bn(self.conv(out, p + ".conv2", stride, dilation, dilation), p + ".bn2"))
+        out = self.bn(self.conv(out, p + ".conv3"), p + ".bn3")
+    else:  # basic: 3x3(stride, dil) -> 3x3(previous_dilation)
+        out = F.relu(self.bn(self.conv(x, p + ".conv1", stride, dilation, dilation), p + ".bn1"))
+        out = self.bn(self.conv(out, p + ".conv2", 1, previous_dilation, previous_dilation),
+                      p + ".bn2")
+    if (p + ".downsample.0.weight") in sd:
+        identity = self.bn(self.conv(x, p + ".downsample.0", stride), p + ".downsample.1")
+    return F.relu(out + identity)
+
+
+def _res_layer(self, x, p, stride, dilation):
+    """ResNetV1._make_layer — resnet.py:147-181 (first block of a dilated stage: dilation/2)."""
+    first = 1 if dilation in (1, 2) else 2
+    x = _res_block(self, x, p + ".0", stride, first, dilation)
+    j = 1
+    while (p + ".%d.conv1.weight" % j) in self.sd:
+        x = _res_block(self, x, p + ".%d" % j, 1, dilation, dilation)
+        j += 1
+    return x
+
+
+def _resnet(self, x, prefix="encoder"):
+    """ResNetV1.forward — resnet.py:183-199 (plain and deep-stem variants)."""
+    dil, strides = _resnet_plan(self)
+    p = prefix + "."
+    if (p + "conv1.0.weight") in self.sd:  # deep stem
+        x = F.relu(self.bn(self.conv(x, p + "conv1.0", 2, 1), p + "conv1.1"))
+        x = F.relu(self.bn(self.conv(x, p + "conv1.3", 1, 1), p + "conv1.4"))
+        x = self.conv(x, p + "conv1.6", 1, 1)
+    else:
+        x = self.conv(x, p + "conv1", 2, 3)
+    x = F.relu(self.bn(x, p + "bn1"))
+    x = F.max_pool2d(x, 3, 2, 1)
+    c1 = _res_layer(self, x, p + "layer1", 1, 1)
+    c2 = _res_layer(self, c1, p + "layer2", 2, 1)
+    c3 = _res_layer(self, c2, p + "layer3", strides[0], dil[0])
+    c4 = _res_layer(self, c3, p + "layer4", strides[1], dil[1])
+    return c1, c2, c3, c4
+
+
+def _fcn_resnet(self, x):
+    """FCN.forward — segmentron/models/fcn.py:22-34."""
+    size = x.shape[2:]
+    _, _, c3, c4 = _resnet(self, x)
+    outs = [F.interpolate(self.fcn_head(c4, "head"), size, mode="bilinear", align_corners=True)]
+    if self.aux:
+        outs.append(F.interpolate(self.fcn_head(c3, "auxlayer"), size, mode="bilinear",
+                                  align_corners=True))
+    return tuple(outs)
+
+
+def _pspnet_resnet(self, x):
+    """PSPNet.forward + _PSPHead + PyramidPooling — pspnet.py:28-58, module.py:82-97."""
+    size = x.shape[2:]
+    _, _, c3, c4 = _resnet(self, x)
+    hw = c4.shape[2:]
+    feats = [c4]
+    for i, o in enumerate((1, 2, 3, 6)):
+        f = F.adaptive_avg_pool2d(c4, o)
+        f = self.conv_bn_relu(f, "head.psp.convs.%d" % i)
+        feats.append(F.interpolate(f, hw, mode="bilinear", align_corners=True))
+    y = torch.cat(feats, dim=1)
+    y = F.relu(self.bn(self.conv(y, "head.block.0", 1, 1), "head.block.1"))
+    y = F.dropout(y, self.drop_p, self.training)
+    y = self.conv(y, "head.block.4")
+    outs = [F.interpolate(y, size, mode="bilinear", align_corners=True)]
+    if self.aux:
+        outs.append(F.interpolate(self.fcn_head(c3, "auxlayer"), size, mode="bilinear",
+                                  align_corners=True))
+    return tuple(outs)
+
+
+OracleNet.resnet = _resnet
+OracleNet.fcn_resnet = _fcn_resnet
+OracleNet.pspnet_resnet = _pspnet_resnet
+
+
 def mix_softmax_ce(outputs, target, aux_weight=0.4, ignore_index=-1):
     """MixSoftmaxCrossEntropyLoss — segmentron/solver/loss.py:16-46 (sum of per-output CE,
     aux outputs weighted by cfg.SOLVER.AUX_WEIGHT)."""

@@ -99,6 +99,8 @@ struct ApplyArgs {
   const void* x; const void* r; void* y;
   const float* sx; const float* tx; const float* sr; const float* tr;
   const float* chan_mul;  // optional [N][C] multiplier (Dropout2d mask * 1/(1-p)); rows_per_n rows each
+  const void* elem_mul;   // optional per-element multiplier of type T, pitch ldm (nn.Dropout mask/(1-p))
+  long ldm;
   long ldx, ldr, ldy;
   long M; int C, CV;
   int mode_x, mode_r, post_relu;
@@ -156,6 +158,12 @@ __global__ __launch_bounds__(EW_THREADS) void bn_apply_kernel(const ApplyArgs a)
 #pragma unroll
       for (int k = 0; k < VEC; ++k) f[k] *= m[k];
     }
+    if (a.elem_mul) {
+      float m[VEC];
+      Vec<T>::unpack(ldg16(reinterpret_cast<const T*>(a.elem_mul) + (long)row * a.ldm + c0), m);
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) f[k] *= m[k];
+    }
     if (R) {
       float g[VEC];
       Vec<T>::unpack(ldg16(R + (long)row * a.ldr + c0), g);
@@ -176,6 +184,7 @@ struct BwdArgs {
   const void* g; const void* x; void* dx;
   const float* scale; const float* shift; const float* c0; const float* c1;
   const float* chan_mul; long rows_per_n;
+  const void* elem_mul; long ldm;
   float* partial;  // [gridDim.y][2][C]
   long ldg, ldx, lddx;
   long M; int C, CV;
@@ -192,6 +201,12 @@ __device__ __forceinline__ void masked_grad(const BwdArgs& a, const T* G, const 
   Vec<T>::unpack(ldg16(X + (long)row * a.ldx + c0), x);
   if (a.chan_mul) {
     const float* m = a.chan_mul + (long)(row / (int)a.rows_per_n) * a.C + c0;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) g[k] *= m[k];
+  }
+  if (a.elem_mul) {
+    float m[VEC];
+    Vec<T>::unpack(ldg16(reinterpret_cast<const T*>(a.elem_mul) + (long)row * a.ldm + c0), m);
 #pragma unroll
     for (int k = 0; k < VEC; ++k) g[k] *= m[k];
   }
@@ -456,8 +471,9 @@ extern "C" int seg_bn_eval_affine(const float* gamma, const float* beta, const f
 // y = post_relu?( act_x(x) * chan_mul + act_r(r) )
 extern "C" int seg_bn_apply(int dtype, const void* x, long ldx, int mode_x, const float* sx,
                             const float* tx, const void* r, long ldr, int mode_r, const float* sr,
-                            const float* tr, const float* chan_mul, long rows_per_n, int post_relu,
-                            void* y, long ldy, long M, int C, void* stream) {
+                            const float* tr, const float* chan_mul, long rows_per_n,
+                            const void* elem_mul, long ldm, int post_relu, void* y, long ldy,
+                            long M, int C, void* stream) {
   using namespace seg;
   const int vec = dtype == DT_BF16 ? 8 : 4;
   SEG_REQUIRE(dtype == DT_F32 || dtype == DT_BF16, "bn_apply: bad dtype %d", dtype);
@@ -468,6 +484,7 @@ extern "C" int seg_bn_apply(int dtype, const void* x, long ldx, int mode_x, cons
               "bn_apply: missing scale/shift (r)");
   ApplyArgs a;
   a.x = x; a.r = r; a.y = y; a.sx = sx; a.tx = tx; a.sr = sr; a.tr = tr; a.chan_mul = chan_mul;
+  a.elem_mul = elem_mul; a.ldm = ldm;
   a.ldx = ldx; a.ldr = ldr; a.ldy = ldy; a.M = M; a.C = C; a.CV = C / vec;
   a.mode_x = mode_x; a.mode_r = mode_r; a.post_relu = post_relu;
   a.rows_per_n = rows_per_n > 0 ? rows_per_n : 1;
@@ -500,8 +517,9 @@ extern "C" int seg_bn_bwd_grid_y(int dtype, int C, long M) {
 // partial[grid_y][2][C] = per-block (sum g', sum g'*x),  g' = g * chan_mul * relu_mask(mode)
 extern "C" int seg_bn_bwd_reduce(int dtype, const void* g, long ldg, const void* x, long ldx,
                                  int mode, const float* scale, const float* shift,
-                                 const float* chan_mul, long rows_per_n, long M, int C,
-                                 float* partial, int grid_y, void* stream) {
+                                 const float* chan_mul, long rows_per_n, const void* elem_mul,
+                                 long ldm, long M, int C, float* partial, int grid_y,
+                                 void* stream) {
   using namespace seg;
   const int vec = dtype == DT_BF16 ? 8 : 4;
   SEG_REQUIRE(dtype == DT_F32 || dtype == DT_BF16, "bn_bwd_reduce: bad dtype %d", dtype);
@@ -511,6 +529,7 @@ extern "C" int seg_bn_bwd_reduce(int dtype, const void* g, long ldg, const void*
   BwdArgs a;
   a.g = g; a.x = x; a.dx = nullptr; a.scale = scale; a.shift = shift; a.c0 = nullptr; a.c1 = nullptr;
   a.chan_mul = chan_mul; a.rows_per_n = rows_per_n > 0 ? rows_per_n : 1;
+  a.elem_mul = elem_mul; a.ldm = ldm;
   a.partial = partial; a.ldg = ldg; a.ldx = ldx; a.lddx = 0; a.M = M; a.C = C; a.CV = C / vec;
   a.mode = mode; a.cvb_log2 = pick_cvb_log2_ew(a.CV);
   const int gx = (a.CV + (1 << a.cvb_log2) - 1) >> a.cvb_log2;
@@ -538,8 +557,9 @@ extern "C" int seg_bn_bwd_finalize(const double* sums, double count, const float
 // backward / dropout-mask backward).  c0/c1 null with AFFINE -> eval-mode BN backward (scale only).
 extern "C" int seg_bn_bwd_apply(int dtype, const void* g, long ldg, const void* x, long ldx,
                                 int mode, const float* scale, const float* shift, const float* c0,
-                                const float* c1, const float* chan_mul, long rows_per_n, void* dx,
-                                long lddx, long M, int C, void* stream) {
+                                const float* c1, const float* chan_mul, long rows_per_n,
+                                const void* elem_mul, long ldm, void* dx, long lddx, long M, int C,
+                                void* stream) {
   using namespace seg;
   const int vec = dtype == DT_BF16 ? 8 : 4;
   SEG_REQUIRE(dtype == DT_F32 || dtype == DT_BF16, "bn_bwd_apply: bad dtype %d", dtype);
@@ -549,6 +569,7 @@ extern "C" int seg_bn_bwd_apply(int dtype, const void* g, long ldg, const void* 
   BwdArgs a;
   a.g = g; a.x = x; a.dx = dx; a.scale = scale; a.shift = shift; a.c0 = c0; a.c1 = c1;
   a.chan_mul = chan_mul; a.rows_per_n = rows_per_n > 0 ? rows_per_n : 1;
+  a.elem_mul = elem_mul; a.ldm = ldm;
   a.partial = nullptr; a.ldg = ldg; a.ldx = ldx; a.lddx = lddx; a.M = M; a.C = C; a.CV = C / vec;
   a.mode = mode;
   SEG_REQUIRE(M < (1L << 31), "bn_bwd_apply: M overflows int");

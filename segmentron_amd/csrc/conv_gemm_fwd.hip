@@ -35,6 +35,7 @@ struct ConvGemmArgs {
   int N, Hi, Wi, C, Ho, Wo, O;
   int KH, KW, stride, pad, dil;
   int pro_mode;
+  int tconv;  // 1: transposed-stride gather (data gradient of a strided KxK convolution)
   int M, K;
   int out_H, out_W, out_s;  // output row scatter geometry (out_s == 1 -> dense rows)
   int tiles_m, tiles_n;
@@ -89,8 +90,8 @@ __global__ __launch_bounds__(GEMM_THREADS, (DBUF || !FAST) ? 2 : 3) void conv_ge
         const int ho = t % a.Ho;
         const int n = t / a.Ho;
         a_base[j] = (long)n * a.Hi * a.Wi;
-        a_hi0[j] = ho * a.stride - a.pad;
-        a_wi0[j] = wo * a.stride - a.pad;
+        a_hi0[j] = a.tconv ? ho + a.pad : ho * a.stride - a.pad;
+        a_wi0[j] = a.tconv ? wo + a.pad : wo * a.stride - a.pad;
       } else {
         a_base[j] = 0;
         a_hi0[j] = -(1 << 28);  // never in range
@@ -126,8 +127,18 @@ __global__ __launch_bounds__(GEMM_THREADS, (DBUF || !FAST) ? 2 : 3) void conv_ge
       cur_c = c;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int hi = a_hi0[j] + dh, wi = a_wi0[j] + dw;
-        const bool ok = kok && hi >= 0 && hi < a.Hi && wi >= 0 && wi < a.Wi;
+        int hi = a_hi0[j] + dh, wi = a_wi0[j] + dw;
+        bool ok = kok;
+        if (a.tconv) {
+          // dx[h,w] += dy[(h + pad - kh*dil)/s, (w + pad - kw*dil)/s] * W[.,kh,kw,.] when the
+          // divisions are exact
+          hi = a_hi0[j] - dh;
+          wi = a_wi0[j] - dw;
+          ok = ok && hi >= 0 && wi >= 0 && (hi % a.stride) == 0 && (wi % a.stride) == 0;
+          hi /= a.stride;
+          wi /= a.stride;
+        }
+        ok = ok && hi >= 0 && hi < a.Hi && wi >= 0 && wi < a.Wi;
         ra[j] = make_uint4(0, 0, 0, 0);
         if (ok) ra[j] = ldg16(X + (a_base[j] + (long)hi * a.Wi + wi) * a.ldx + c);
         a_ok_mask = ok ? (a_ok_mask | (1u << j)) : (a_ok_mask & ~(1u << j));
@@ -287,7 +298,7 @@ static int g_gemm_dbuf = 0;  // single LDS stage, 3 blocks/CU: measured faster o
 template <typename T>
 static int launch_conv_gemm_fwd(const ConvGemmArgs& a, hipStream_t stream) {
   const dim3 grid(a.tiles_m * a.tiles_n), block(GEMM_THREADS);
-  const bool fast = a.KH * a.KW == 1 && a.stride == 1 && a.pad == 0;
+  const bool fast = a.KH * a.KW == 1 && a.stride == 1 && a.pad == 0 && !a.tconv;
   if (fast) {
     if (g_gemm_dbuf) hipLaunchKernelGGL((conv_gemm_fwd_kernel<T, true, true>), grid, block, 0, stream, a);
     else hipLaunchKernelGGL((conv_gemm_fwd_kernel<T, true, false>), grid, block, 0, stream, a);
@@ -314,7 +325,8 @@ extern "C" int seg_conv_gemm_fwd(int dtype, const void* x, long ldx, int N, int 
                                  const float* pro_shift, const float* bias, void* y, long ldy,
                                  int Ho, int Wo, int out_H, int out_W, int out_s,
                                  float* stat_partial, const void* ep_x, long ldep,
-                                 const float* ep_c0, const float* ep_c1, void* stream) {
+                                 const float* ep_c0, const float* ep_c1, int tconv,
+                                 void* stream) {
   using namespace seg;
   const int vec = dtype == DT_BF16 ? 8 : 4;
   SEG_REQUIRE(dtype == DT_F32 || dtype == DT_BF16, "conv_gemm_fwd: bad dtype %d", dtype);
@@ -333,7 +345,7 @@ extern "C" int seg_conv_gemm_fwd(int dtype, const void* x, long ldx, int N, int 
   a.ldx = ldx; a.ldy = ldy;
   a.N = N; a.Hi = Hi; a.Wi = Wi; a.C = C; a.Ho = Ho; a.Wo = Wo; a.O = O;
   a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad; a.dil = dil;
-  a.pro_mode = pro_mode;
+  a.pro_mode = pro_mode; a.tconv = tconv;
   a.M = N * Ho * Wo; a.K = KH * KW * C;
   a.out_H = out_H; a.out_W = out_W; a.out_s = out_s;
   a.tiles_m = (a.M + BM - 1) / BM; a.tiles_n = (O + BN - 1) / BN;

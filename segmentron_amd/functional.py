@@ -109,16 +109,17 @@ def flush_bn_counters():
         del _PENDING_COUNTERS[:]
 
 
-def bn_input_backward(g, x, bn, relu, chan_mul=None, inplace=False):
-    """g = dLoss/d(act(x)*chan_mul)  ->  (dLoss/dx_raw, dgamma, dbeta)."""
+def bn_input_backward(g, x, bn, relu, chan_mul=None, inplace=False, elem_mul=None):
+    """g = dLoss/d(act(x)*chan_mul*elem_mul)  ->  (dLoss/dx_raw, dgamma, dbeta)."""
     mode = (PRO_AFFINE if bn is not None else PRO_NONE) | (PRO_RELU if relu else 0)
     if bn is None:
-        if not relu and chan_mul is None:
+        if not relu and chan_mul is None and elem_mul is None:
             return g, None, None
-        dx = K.bn_bwd_apply(g, x, (mode, None, None), chan_mul=chan_mul, out=g if inplace else None)
+        dx = K.bn_bwd_apply(g, x, (mode, None, None), chan_mul=chan_mul,
+                            out=g if inplace else None, elem_mul=elem_mul)
         return dx, None, None
     pro = (mode, bn.scale, bn.shift)
-    partial = K.bn_bwd_reduce_partial(g, x, pro, chan_mul)
+    partial = K.bn_bwd_reduce_partial(g, x, pro, chan_mul, elem_mul)
     if bn.group is None:
         dgamma, dbeta, c0, c1 = K.bn_bwd_finalize_p(partial, bn.count, bn.mean, bn.invstd,
                                                     bn.gamma)
@@ -127,7 +128,8 @@ def bn_input_backward(g, x, bn, relu, chan_mul=None, inplace=False):
         dgamma, dbeta, c0, c1 = K.bn_bwd_finalize(sums, bn.count, bn.mean, bn.invstd, bn.gamma)
     if not bn.training:
         c0 = c1 = None
-    dx = K.bn_bwd_apply(g, x, pro, c0, c1, chan_mul, out=g if inplace else None)
+    dx = K.bn_bwd_apply(g, x, pro, c0, c1, chan_mul, out=g if inplace else None,
+                        elem_mul=elem_mul)
     if bn.group is not None:
         dgamma, dbeta = parallel.local_param_grads(dgamma, dbeta, bn.group)
     return dx, dgamma, dbeta
@@ -170,6 +172,16 @@ def pack_conv_weight_dgrad(w, opad, dtype):
         out.copy_(w.detach().reshape(O, Cw).t())  # one transposing, casting copy
         return out
     p = w.detach().flip(2, 3).permute(1, 2, 3, 0)
+    if opad != O:
+        p = torch.nn.functional.pad(p, (0, opad - O))
+    return p.reshape(Cw, KH * KW * opad).to(dtype).contiguous()
+
+
+def pack_conv_weight_tconv(w, opad, dtype):
+    """-> [Cw, KH*KW*opad] (taps NOT flipped): weights of the transposed-stride gather that
+    computes the data gradient of a strided KxK convolution."""
+    O, Cw, KH, KW = w.shape
+    p = w.detach().permute(1, 2, 3, 0)
     if opad != O:
         p = torch.nn.functional.pad(p, (0, opad - O))
     return p.reshape(Cw, KH * KW * opad).to(dtype).contiguous()
@@ -249,8 +261,11 @@ class _ConvFn(torch.autograd.Function):
             elif KH == 1 and KW == 1 and s.pad == 0:
                 g, _ = K.conv_gemm(dy_full, wt, Cw, 1, 1, 1, 0, 1,
                                    scatter=(x.shape[1], x.shape[2], s.stride))
-            else:
-                raise NotImplementedError("data gradient of a strided KxK convolution")
+            else:  # strided KxK: transposed-stride gather through the same MFMA kernel
+                wt = cached_pack(weight, ("tconv", Op, dt),
+                                 lambda: pack_conv_weight_tconv(weight, Op, dt))
+                g, _ = K.conv_gemm(dy_full, wt, Cw, KH, KW, s.stride, s.pad, s.dil,
+                                   tconv_out_hw=(x.shape[1], x.shape[2]))
             dx, dgamma, dbeta = bn_input_backward(g, x, s.bn_in, s.relu, inplace=True)
         return dx, dgamma, dbeta, dW, dbias, None
 
@@ -382,7 +397,8 @@ class _DwFn(torch.autograd.Function):
 
 
 class ApplySpec:
-    def __init__(self, a, r=None, chan_mul=None, post_relu=False, out=None):
+    def __init__(self, a, r=None, chan_mul=None, post_relu=False, out=None, elem_mul=None):
+        self.elem_mul = elem_mul
         self.bn_x, self.relu_x, self.pro_x = a.bn, a.relu, a.pro
         if r is not None:
             self.bn_r, self.relu_r, self.pro_r = r.bn, r.relu, r.pro
@@ -396,7 +412,8 @@ class _ApplyFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, gx, bx, r, gr, br, spec):
-        y = K.bn_apply(x, spec.pro_x, r, spec.pro_r, spec.chan_mul, spec.post_relu, spec.out)
+        y = K.bn_apply(x, spec.pro_x, r, spec.pro_r, spec.chan_mul, spec.post_relu, spec.out,
+                       spec.elem_mul)
         ctx.spec = spec
         ctx.has_r = r is not None
         if spec.post_relu:
@@ -413,7 +430,8 @@ class _ApplyFn(torch.autograd.Function):
             g = K.bn_bwd_apply(g, y, (PRO_RELU, None, None))
         else:
             x, r = ctx.saved_tensors
-        dx, dgx, dbx = bn_input_backward(g, x, s.bn_x, s.relu_x, s.chan_mul, inplace=False)
+        dx, dgx, dbx = bn_input_backward(g, x, s.bn_x, s.relu_x, s.chan_mul, inplace=False,
+                                         elem_mul=s.elem_mul)
         dr = dgr = dbr = None
         if ctx.has_r and ctx.needs_input_grad[3]:
             dr, dgr, dbr = bn_input_backward(g, r, s.bn_r, s.relu_r, None, inplace=False)
@@ -486,6 +504,47 @@ class _GapFn(torch.autograd.Function):
         return K.bilinear(gs, (H, W), None, None, True)
 
 
+class PoolSpec:
+    def __init__(self, a, k, stride, pad):
+        self.bn, self.relu, self.pro = a.bn, a.relu, a.pro
+        self.k, self.stride, self.pad = k, stride, pad
+
+
+class _MaxPoolFn(torch.autograd.Function):
+    """nn.MaxPool2d on a deferred activation (resnet.py:119)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, spec):
+        y, idx = K.maxpool(x, spec.k, spec.stride, spec.pad, spec.pro)
+        ctx.spec = spec
+        ctx.save_for_backward(x, idx)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, idx = ctx.saved_tensors
+        s = ctx.spec
+        ga = K.maxpool_bwd(g, idx, (x.shape[1], x.shape[2]), s.k, s.stride, s.pad)
+        dx, dgamma, dbeta = bn_input_backward(ga, x, s.bn, s.relu, inplace=True)
+        return dx, dgamma, dbeta, None
+
+
+class _AdaptivePoolFn(torch.autograd.Function):
+    """nn.AdaptiveAvgPool2d(o) of a materialised tensor -> [N,o,o,C] (module.py:89)."""
+
+    @staticmethod
+    def forward(ctx, x, o):
+        N, H, W, C = x.shape
+        ctx.meta = (H, W)
+        sums = K.adaptive_avgpool_sums(x, o)
+        areas = K.adaptive_bin_areas(H, W, o, x.device)
+        return (sums / areas.view(1, o, o, 1)).to(x.dtype)  # tiny [N,o,o,C] host-side scale+cast
+
+    @staticmethod
+    def backward(ctx, g):
+        return K.adaptive_avgpool_bwd(g.contiguous(), ctx.meta), None
+
+
 class _CatFn(torch.autograd.Function):
     """torch.cat(dim=channel) without a copy: producers already wrote their channel slices of
     `buf`; backward hands each producer the matching slice VIEW of the gradient."""
@@ -547,12 +606,14 @@ def dwconv_bn(act, conv, bn, out=None):
     return Act(y, finish_bn(bn, spec.partial, N * Ho * Wo))
 
 
-def materialize(act, residual=None, chan_mul=None, post_relu=False, out=None):
-    """-> plain NHWC tensor = act(x)*chan_mul (+ act(residual))."""
+def materialize(act, residual=None, chan_mul=None, post_relu=False, out=None, elem_mul=None,
+                force=False):
+    """-> plain NHWC tensor = act(x)*chan_mul*elem_mul (+ act(residual)).  `force` copies even a
+    plain tensor (into `out`)."""
     if act.bn is None and not act.relu and residual is None and chan_mul is None and out is None \
-            and not post_relu:
+            and not post_relu and elem_mul is None and not force:
         return act.t
-    spec = ApplySpec(act, residual, chan_mul, post_relu, out)
+    spec = ApplySpec(act, residual, chan_mul, post_relu, out, elem_mul)
     gx, bx = act.params
     if residual is None:
         return _ApplyFn.apply(act.t, gx, bx, None, None, None, spec)
@@ -572,6 +633,22 @@ def logits_to_nchw(x, out_hw, align_corners=True):
 
 def global_avg_pool(x):
     return _GapFn.apply(x)
+
+
+def max_pool(act, k, stride, pad):
+    g, b = act.params
+    return _MaxPoolFn.apply(act.t, g, b, PoolSpec(act, k, stride, pad))
+
+
+def adaptive_avg_pool(x, o):
+    return _AdaptivePoolFn.apply(x, o)
+
+
+def dropout_mask(shape, p, dtype, device):
+    """nn.Dropout multiplier mask/(1-p) in the activation dtype (mask generation is host
+    plumbing; it is applied inside seg_bn_apply / seg_bn_bwd_*)."""
+    keep = torch.rand(shape, device=device) >= p
+    return (keep.to(torch.float32) / (1.0 - p)).to(dtype)
 
 
 def concat_alias(buf, parts):

@@ -80,12 +80,15 @@ def conv_out_size(Hi, k, stride, pad, dil):
 
 
 def conv_gemm(x, w_packed, O, KH, KW, stride, pad, dil, pro=None, bias=None, out=None,
-              want_stats=False, scatter=None, ep=None):
+              want_stats=False, scatter=None, ep=None, tconv_out_hw=None):
     """x NHWC; w_packed [O, KH*KW*C] in x.dtype.  Returns (y, stat_partial|None).
     scatter=(out_H, out_W, s): write output pixel (ho,wo) at (ho*s, wo*s) of a zero-filled
     [N,out_H,out_W,O] tensor (data gradient of a strided 1x1 conv)."""
     N, Hi, Wi, C, ldx = nhwc(x)
-    Ho, Wo = conv_out_size(Hi, KH, stride, pad, dil), conv_out_size(Wi, KW, stride, pad, dil)
+    if tconv_out_hw is not None:  # transposed-stride gather: x is dy, the output is dx
+        Ho, Wo = tconv_out_hw
+    else:
+        Ho, Wo = conv_out_size(Hi, KH, stride, pad, dil), conv_out_size(Wi, KW, stride, pad, dil)
     mode, ps, pt = _pro(pro)
     if scatter is None:
         oH, oW, os_ = Ho, Wo, 1
@@ -108,7 +111,8 @@ def conv_gemm(x, w_packed, O, KH, KW, stride, pad, dil, pro=None, bias=None, out
         ldep = nhwc(ep_x)[4]
     LIB.call("seg_conv_gemm_fwd", _DT[x.dtype], _p(x), ldx, N, Hi, Wi, C, _p(w_packed), O, KH, KW,
              stride, pad, dil, mode, _p(ps), _p(pt), _p(bias), _p(out), ldy, Ho, Wo, oH, oW, os_,
-             _p(partial), _p(ep_x), ldep, _p(ep_c0), _p(ep_c1), _stream())
+             _p(partial), _p(ep_x), ldep, _p(ep_c0), _p(ep_c1),
+             1 if tconv_out_hw is not None else 0, _stream())
     return out, partial
 
 
@@ -218,7 +222,8 @@ def bn_eval_affine(gamma, beta, rm, rv, eps):
     return out[0], out[1]
 
 
-def bn_apply(x, pro_x=None, r=None, pro_r=None, chan_mul=None, post_relu=False, out=None):
+def bn_apply(x, pro_x=None, r=None, pro_r=None, chan_mul=None, post_relu=False, out=None,
+             elem_mul=None):
     N, H, W, C, ldx = nhwc(x)
     mx, sx, tx = _pro(pro_x)
     mr, sr, tr = _pro(pro_r)
@@ -226,12 +231,14 @@ def bn_apply(x, pro_x=None, r=None, pro_r=None, chan_mul=None, post_relu=False, 
         out = torch.empty((N, H, W, C), dtype=x.dtype, device=x.device)
     ldy = nhwc(out)[4]
     ldr = nhwc(r)[4] if r is not None else 0
+    ldm = nhwc(elem_mul)[4] if elem_mul is not None else 0
     LIB.call("seg_bn_apply", _DT[x.dtype], _p(x), ldx, mx, _p(sx), _p(tx), _p(r), ldr, mr, _p(sr),
-             _p(tr), _p(chan_mul), H * W, int(post_relu), _p(out), ldy, N * H * W, C, _stream())
+             _p(tr), _p(chan_mul), H * W, _p(elem_mul), ldm, int(post_relu), _p(out), ldy,
+             N * H * W, C, _stream())
     return out
 
 
-def bn_bwd_reduce_partial(g, x, pro, chan_mul=None):
+def bn_bwd_reduce_partial(g, x, pro, chan_mul=None, elem_mul=None):
     """-> fp32 [grid_y, 2C] per-block (sum g', sum g'*x)."""
     N, H, W, C, ldg = nhwc(g)
     ldx = nhwc(x)[4]
@@ -239,8 +246,9 @@ def bn_bwd_reduce_partial(g, x, pro, chan_mul=None):
     M = N * H * W
     gy = LIB.query("seg_bn_bwd_grid_y", _DT[g.dtype], C, M)
     partial = torch.empty((gy, 2 * C), dtype=torch.float32, device=g.device)
+    ldm = nhwc(elem_mul)[4] if elem_mul is not None else 0
     LIB.call("seg_bn_bwd_reduce", _DT[g.dtype], _p(g), ldg, _p(x), ldx, mode, _p(s), _p(t),
-             _p(chan_mul), H * W, M, C, _p(partial), gy, _stream())
+             _p(chan_mul), H * W, _p(elem_mul), ldm, M, C, _p(partial), gy, _stream())
     return partial
 
 
@@ -284,15 +292,17 @@ def bn_bwd_finalize(sums, count, mean, invstd, gamma):
     return out[0], out[1], out[2], out[3]  # dgamma, dbeta, c0, c1
 
 
-def bn_bwd_apply(g, x, pro, c0=None, c1=None, chan_mul=None, out=None):
+def bn_bwd_apply(g, x, pro, c0=None, c1=None, chan_mul=None, out=None, elem_mul=None):
     N, H, W, C, ldg = nhwc(g)
     ldx = nhwc(x)[4]
     mode, s, t = _pro(pro)
     if out is None:
         out = torch.empty((N, H, W, C), dtype=g.dtype, device=g.device)
     lddx = nhwc(out)[4]
+    ldm = nhwc(elem_mul)[4] if elem_mul is not None else 0
     LIB.call("seg_bn_bwd_apply", _DT[g.dtype], _p(g), ldg, _p(x), ldx, mode, _p(s), _p(t), _p(c0),
-             _p(c1), _p(chan_mul), H * W, _p(out), lddx, N * H * W, C, _stream())
+             _p(c1), _p(chan_mul), H * W, _p(elem_mul), ldm, _p(out), lddx, N * H * W, C,
+             _stream())
     return out
 
 
@@ -325,6 +335,56 @@ def fold_bwd_finalize(dsdt, count, mean, invstd, gamma, scale):
     LIB.call("seg_fold_bwd_finalize", _p(dsdt), float(count), _p(mean), _p(invstd), _p(gamma),
              _p(scale), _p(out[0]), _p(out[1]), _p(out[2]), _p(out[3]), C, _stream())
     return out[0], out[1], out[2], out[3]  # dgamma, dbeta, c0, c1
+
+
+# ----------------------------------------------------------------------------- pooling
+def maxpool(x, k, stride, pad, pro=None):
+    """-> (y, idx uint8): y = maxpool(act(x)), -inf padding."""
+    N, Hi, Wi, C, ldx = nhwc(x)
+    Ho, Wo = (Hi + 2 * pad - k) // stride + 1, (Wi + 2 * pad - k) // stride + 1
+    mode, ps, pt = _pro(pro)
+    y = torch.empty((N, Ho, Wo, C), dtype=x.dtype, device=x.device)
+    idx = torch.empty((N, Ho, Wo, C), dtype=torch.uint8, device=x.device)
+    LIB.call("seg_maxpool_fwd", _DT[x.dtype], _p(x), ldx, N, Hi, Wi, C, k, stride, pad, mode,
+             _p(ps), _p(pt), _p(y), C, Ho, Wo, _p(idx), _stream())
+    return y, idx
+
+
+def maxpool_bwd(gy, idx, in_hw, k, stride, pad):
+    N, Ho, Wo, C, ldgy = nhwc(gy)
+    Hi, Wi = in_hw
+    gx = torch.empty((N, Hi, Wi, C), dtype=gy.dtype, device=gy.device)
+    LIB.call("seg_maxpool_bwd", _DT[gy.dtype], _p(gx), C, N, Hi, Wi, C, k, stride, pad, _p(gy),
+             ldgy, Ho, Wo, _p(idx), _stream())
+    return gx
+
+
+def adaptive_avgpool_sums(x, o):
+    """-> fp32 [N, o, o, C] bin SUMS (caller divides by the bin areas)."""
+    N, H, W, C, ldx = nhwc(x)
+    chunks = LIB.query("seg_adaptive_avgpool_chunks", H, W, o)
+    partial = torch.empty((chunks, N * o * o * C), dtype=torch.float32, device=x.device)
+    LIB.call("seg_adaptive_avgpool_partial", _DT[x.dtype], _p(x), ldx, N, H, W, C, o, _p(partial),
+             chunks, _stream())
+    sums = partial[0] if chunks == 1 else colsum(partial, f64=False)
+    return sums.view(N, o, o, C)
+
+
+def adaptive_avgpool_bwd(gy, in_hw):
+    N, o, _, C, ldgy = nhwc(gy)
+    H, W = in_hw
+    gx = torch.empty((N, H, W, C), dtype=gy.dtype, device=gy.device)
+    LIB.call("seg_adaptive_avgpool_bwd", _DT[gy.dtype], _p(gx), C, N, H, W, C, o, _p(gy), ldgy,
+             _stream())
+    return gx
+
+
+def adaptive_bin_areas(H, W, o, device):
+    """[o, o] fp32 areas of ATen's adaptive-pool bins."""
+    import math
+    hs = [math.ceil((i + 1) * H / o) - (i * H) // o for i in range(o)]
+    ws = [math.ceil((j + 1) * W / o) - (j * W) // o for j in range(o)]
+    return torch.tensor([[float(a * b) for b in ws] for a in hs], device=device)
 
 
 # ----------------------------------------------------------------------------- resize

@@ -4,7 +4,7 @@ import torch.nn as nn
 
 from .. import functional as F
 from ..config import cfg
-from ..modules import SeparableConv2d, _ASPP, _ConvBNReLU
+from ..modules import SeparableConv2d, _ASPP, _ConvBNReLU, _FCNHead
 from .model_zoo import MODEL_REGISTRY
 from .segbase import SegBaseModel
 
@@ -25,15 +25,18 @@ class DeepLabV3Plus(SegBaseModel):
             c1_channels, c4_channels = 256, 2048
         self.head = _DeepLabHead(self.nclass, c1_channels=c1_channels, c4_channels=c4_channels)
         if self.aux:
-            raise NotImplementedError("SOLVER.AUX (_FCNHead on c3) is a next-row, see DESIGN.md")
+            self.auxlayer = _FCNHead(728, self.nclass)
         self.__setattr__("decoder", ["head", "auxlayer"] if self.aux else ["head"])
 
     def forward(self, x):
         size = x.shape[2:]
         c1, _, c3, c4 = self.encoder(x)
         y = self.head(c4, c1)  # NHWC logits at c1 resolution
+        outputs = [F.logits_to_nchw(y, size, align_corners=True)]
+        if self.aux:
+            outputs.append(F.logits_to_nchw(self.auxlayer(c3), size, align_corners=True))
         F.flush_bn_counters()
-        return (F.logits_to_nchw(y, size, align_corners=True),)
+        return tuple(outputs)
 
 
 class _DeepLabHead(nn.Module):

@@ -6,9 +6,70 @@ import torch.nn as nn
 
 from .. import functional as F
 from ..config import cfg
-from .basic import SeparableConv2d
+from .basic import SeparableConv2d, _ConvBNReLU
 
-__all__ = ["_ASPP"]
+__all__ = ["_ASPP", "_FCNHead", "PyramidPooling"]
+
+
+class _FCNHead(nn.Module):
+    """3x3 conv C -> C/4 + BN + ReLU + Dropout(0.1) + 1x1 -> nclass (module.py:13-26).
+    Returns NHWC logits (a view of a channel-padded buffer)."""
+
+    def __init__(self, in_channels, channels, norm_layer=nn.BatchNorm2d):
+        super().__init__()
+        inter = in_channels // 4
+        self.block = nn.Sequential(
+            nn.Conv2d(in_channels, inter, 3, padding=1, bias=False),
+            norm_layer(inter),
+            nn.ReLU(inplace=True),
+            nn.Dropout(0.1),
+            nn.Conv2d(inter, channels, 1))
+        self.channels = channels
+
+    def forward(self, act):
+        return head_tail(act, self.block[0], self.block[1], self.block[3], self.block[4],
+                         self.training, self.channels)
+
+
+def head_tail(act, conv, bn, dropout, classifier, training, nclass):
+    """conv -> BN -> ReLU -> Dropout -> 1x1 classifier (+bias), shared by _FCNHead / _PSPHead."""
+    a = F.conv_bn(act, conv, bn)
+    a.relu = True
+    p = dropout.p
+    if training and p > 0.0:
+        mask = F.dropout_mask(a.t.shape, p, a.t.dtype, a.t.device)
+        a = F.Act(F.materialize(a, elem_mul=mask))
+    N, H, W, _ = a.shape
+    vec = 8 if a.t.dtype == torch.bfloat16 else 4
+    pitch = (nclass + 2 * vec - 1) // vec * vec
+    out = torch.empty((N, H, W, pitch), dtype=a.t.dtype, device=a.t.device)[..., :nclass]
+    return F.conv_bn(a, classifier, None, out=out).t
+
+
+class PyramidPooling(nn.Module):
+    """Adaptive pools (1,2,3,6) -> 1x1 C -> C/4 + BN + ReLU -> bilinear up -> concat with x
+    (module.py:82-97).  Every branch writes its slice of one [N,H,W,2C] buffer."""
+
+    def __init__(self, in_channels, sizes=(1, 2, 3, 6), norm_layer=nn.BatchNorm2d, **kwargs):
+        super().__init__()
+        out_channels = int(in_channels / 4)
+        self.sizes = tuple(sizes)
+        self.avgpools = nn.ModuleList([nn.AdaptiveAvgPool2d(s) for s in sizes])
+        self.convs = nn.ModuleList([_ConvBNReLU(in_channels, out_channels, 1,
+                                                norm_layer=norm_layer) for _ in sizes])
+        self.in_channels, self.out_channels = in_channels, out_channels
+
+    def forward(self, act):
+        x = F.materialize(act)
+        N, H, W, C = x.shape
+        oc = self.out_channels
+        buf = torch.empty((N, H, W, C + oc * len(self.sizes)), dtype=x.dtype, device=x.device)
+        parts = [F.materialize(F.Act(x), out=buf[..., :C], force=True)]
+        for i, (size, conv) in enumerate(zip(self.sizes, self.convs)):
+            pooled = F.adaptive_avg_pool(x, size)
+            parts.append(F.bilinear(conv(F.Act(pooled)), (H, W),
+                                    out=buf[..., C + i * oc:C + (i + 1) * oc]))
+        return F.Act(F.concat_alias(buf, parts))
 
 
 class _ASPP(nn.Module):

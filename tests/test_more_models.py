@@ -1,0 +1,188 @@
+"""FCN / PSPNet on ResNet backbones (BASELINE configs C1, C4; resnet50 fixtures):
+CPU  — the oracle reproduces the fixtures generated from the reference; the module tree has the
+       reference's state_dict schema;
+GPU  — the HIP fp32 path matches the reference fixture (eval logits 1e-3 + argmax, train loss /
+       logits 1e-3, gradients as accurate w.r.t. the fp64 oracle as the CPU fp32 path)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+from oracle import synth, torch_ref
+
+CASES = {
+    "c1": dict(model="FCN", backbone="resnet50", os=16, aux=False, fn="fcn_resnet", hw=(65, 97),
+               aux_weight=0.4),
+    "c4": dict(model="PSPNet", backbone="resnet50", os=8, aux=True, fn="pspnet_resnet", hw=(49, 65),
+               aux_weight=0.4),
+}
+
+
+def _state(tag):
+    keys = json.load(open(os.path.join(GOLDEN, tag + "_state_keys.json")))["keys"]
+    sd = synth.synth_state_dict([(k, tuple(s)) for k, s in keys], seed=0)
+    calib = np.load(os.path.join(GOLDEN, tag + "_bn_calib.npz"))
+    for k in calib.files:
+        sd[k] = torch.from_numpy(calib[k])
+    for k in sd:
+        if k.endswith("num_batches_tracked"):
+            sd[k] = torch.zeros((), dtype=torch.long)
+    return sd
+
+
+def _cfg(tag):
+    from segmentron_amd.config import cfg, reset_cfg
+    c = CASES[tag]
+    reset_cfg()
+    cfg.update_from_list(["DATASET.NAME", "cityscape", "MODEL.MODEL_NAME", c["model"],
+                          "MODEL.BACKBONE", c["backbone"], "MODEL.OUTPUT_STRIDE", str(c["os"]),
+                          "SOLVER.AUX", str(c["aux"]), "SOLVER.AUX_WEIGHT", str(c["aux_weight"]),
+                          "TRAIN.BACKBONE_PRETRAINED", "False"])
+    cfg.PHASE = "test"
+    cfg.check_and_freeze()
+    return cfg
+
+
+def _oracle(tag, sd, x, training, dtype=torch.float32, y=None):
+    c = CASES[tag]
+    s = {k: (v.to(dtype) if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+    s = torch_ref.clone_state(s, requires_grad=training)
+    net = torch_ref.OracleNet(s, training=training, output_stride=c["os"], aux=c["aux"], drop_p=0.0)
+    outs = getattr(net, c["fn"])(x.to(dtype))
+    if not training:
+        return outs, None, None
+    loss = torch_ref.mix_softmax_ce(outs, y, aux_weight=c["aux_weight"])
+    loss.backward()
+    return outs, loss.item(), {k: v.grad for k, v in s.items() if v.grad is not None}
+
+
+@pytest.mark.parametrize("tag", list(CASES))
+def test_oracle_reproduces_reference_fixture(tag):
+    sd = _state(tag)
+    H, W = CASES[tag]["hw"]
+    x = synth.synth_images(2, H, W, seed=0)
+    y = synth.synth_targets(2, H, W, seed=0)
+    with torch.no_grad():
+        outs, _, _ = _oracle(tag, sd, x, False)
+    g = np.load(os.path.join(GOLDEN, tag + "_eval.npz"))
+    assert torch.allclose(outs[0], torch.from_numpy(g["logits"]), rtol=1e-4, atol=1e-4)
+    outs, loss, grads = _oracle(tag, sd, x, True, y=y)
+    t = np.load(os.path.join(GOLDEN, tag + "_train.npz"))
+    assert abs(loss - float(t["loss"])) < 1e-5
+    for k, n in zip([str(k) for k in t["grad_norm_keys"]], t["grad_norms"]):
+        assert abs(float(grads[k].double().norm()) - n) <= 1e-3 * max(n, 1e-6) + 1e-9, k
+
+
+@pytest.mark.parametrize("tag", list(CASES))
+def test_state_dict_schema(tag):
+    import segmentron_amd
+    from segmentron_amd.config import reset_cfg
+    _cfg(tag)
+    model = segmentron_amd.get_segmentation_model()
+    ref = json.load(open(os.path.join(GOLDEN, tag + "_state_keys.json")))
+    assert [(k, list(v.shape)) for k, v in model.state_dict().items()] == \
+        [(k, list(s)) for k, s in ref["keys"]]
+    assert sum(p.numel() for p in model.parameters()) == ref["n_params"]
+    reset_cfg()
+
+
+def test_fcn_resnet18_fails_like_the_reference():
+    """the FCN head hard-codes 2048 input channels (fcn.py:16)."""
+    import segmentron_amd
+    from segmentron_amd.config import cfg, reset_cfg
+    reset_cfg()
+    cfg.update_from_list(["DATASET.NAME", "cityscape", "MODEL.MODEL_NAME", "FCN", "MODEL.BACKBONE",
+                          "resnet18", "TRAIN.BACKBONE_PRETRAINED", "False"])
+    cfg.PHASE = "test"
+    cfg.check_and_freeze()
+    model = segmentron_amd.get_segmentation_model()
+    assert model.head.block[0].in_channels == 2048 and model.encoder.last_inp_channels == 512
+    reset_cfg()
+
+
+def _rel(a, b):
+    return ((a.double() - b.double()).abs().max() / b.double().abs().max()).item()
+
+
+def _build_hip(tag, dtype, train):
+    import segmentron_amd
+    _cfg(tag)
+    segmentron_amd.set_compute_dtype(dtype)
+    model = segmentron_amd.get_segmentation_model()
+    sd = _state(tag)
+    model.load_state_dict(sd, strict=True)
+    model = model.cuda().train(train)
+    for m in model.modules():
+        if isinstance(m, (torch.nn.Dropout, torch.nn.Dropout2d)):
+            m.p = 0.0
+    return model, sd
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", list(CASES))
+def test_hip_eval_fp32_matches_reference_fixture(tag):
+    model, _ = _build_hip(tag, torch.float32, False)
+    H, W = CASES[tag]["hw"]
+    x = synth.synth_images(2, H, W, seed=0)
+    with torch.no_grad():
+        outs = model(x.cuda())
+    assert len(outs) == (2 if CASES[tag]["aux"] else 1)
+    logits = outs[0].cpu()
+    g = np.load(os.path.join(GOLDEN, tag + "_eval.npz"))
+    rel = _rel(logits, torch.from_numpy(g["logits"]))
+    print("%s eval fp32 max-rel vs reference fixture: %.3e" % (tag, rel))
+    assert rel < 1e-3
+    assert (logits.argmax(1).numpy() == g["argmax"]).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", list(CASES))
+def test_hip_train_fp32_matches_reference(tag):
+    c = CASES[tag]
+    model, sd = _build_hip(tag, torch.float32, True)
+    H, W = c["hw"]
+    x = synth.synth_images(2, H, W, seed=0)
+    y = synth.synth_targets(2, H, W, seed=0)
+    outs = model(x.cuda())
+    loss = torch.nn.functional.cross_entropy(outs[0], y.cuda(), ignore_index=-1)
+    for o in outs[1:]:
+        loss = loss + c["aux_weight"] * torch.nn.functional.cross_entropy(o, y.cuda(), ignore_index=-1)
+    loss.backward()
+    t = np.load(os.path.join(GOLDEN, tag + "_train.npz"))
+    rel = _rel(outs[0].detach().cpu(), torch.from_numpy(t["logits"]))
+    print("%s train fp32: loss %.6f (fixture %.6f) logits max-rel %.3e" % (tag, loss.item(), float(t["loss"]), rel))
+    assert abs(loss.item() - float(t["loss"])) < 1e-3 * float(t["loss"]) and rel < 1e-3
+    _, _, g64 = _oracle(tag, sd, x, True, torch.float64, y)
+    _, _, g32 = _oracle(tag, sd, x, True, torch.float32, y)
+    params = dict(model.named_parameters())
+    nh = nc = den = 0.0
+    worst = (0.0, "")
+    for k, t64 in g64.items():
+        assert params[k].grad is not None, k
+        gh = params[k].grad.detach().cpu().double()
+        assert torch.isfinite(gh).all(), k
+        eh, ec, n64 = (gh - t64).norm().item(), (g32[k].double() - t64).norm().item(), t64.norm().item()
+        nh, nc, den = nh + eh ** 2, nc + ec ** 2, den + n64 ** 2
+        bound = 4 * ec + 1e-3 * n64 if n64 > 10 * ec else 20 * ec + 1e-12
+        worst = max(worst, (eh / max(bound, 1e-30), k))
+    print("%s gradients vs fp64 oracle: global rel err HIP %.3e, CPU-fp32 %.3e; worst ratio %.2f (%s)"
+          % (tag, (nh / den) ** 0.5, (nc / den) ** 0.5, worst[0], worst[1]))
+    assert (nh / den) ** 0.5 <= 3 * (nc / den) ** 0.5 + 1e-4
+    assert worst[0] <= 1.0, worst
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", list(CASES))
+def test_hip_bf16_runs_and_is_finite(tag):
+    model, _ = _build_hip(tag, torch.bfloat16, True)
+    H, W = CASES[tag]["hw"]
+    x = synth.synth_images(2, H, W, seed=0)
+    y = synth.synth_targets(2, H, W, seed=0)
+    outs = model(x.cuda())
+    loss = sum(torch.nn.functional.cross_entropy(o, y.cuda(), ignore_index=-1) for o in outs)
+    loss.backward()
+    assert torch.isfinite(loss)
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)

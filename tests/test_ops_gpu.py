@@ -359,3 +359,74 @@ def test_fold_linear_bn_into_pointwise_matches_autograd(dtype):
     assert_close(dgamma.cpu(), gr.grad, torch.float32, "folded dgamma", fac=50)
     assert_close(dbeta.cpu(), br.grad, torch.float32, "folded dbeta", fac=50)
     assert_close(to_cpu_nchw(dx), xr.grad, dtype, "folded dx", fac=3)
+
+
+# ------------------------------------------------------------------------------ pooling / misc
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+def test_maxpool_fwd_bwd(dtype):
+    N, C, H, W = 2, 40, 17, 21
+    x = quant(rnd((N, C, H, W), 1), dtype)
+    pro, s, t = _pro(3, C, 4)
+    xa = _act_ref(x, 3, s, t).double().requires_grad_()
+    ref = TF.max_pool2d(xa, 3, 2, 1)
+    y, idx = K().maxpool(to_dev_nhwc(x, dtype), 3, 2, 1, pro)
+    assert_close(to_cpu_nchw(y), ref.detach(), dtype, "maxpool fwd")
+    g = quant(rnd(tuple(ref.shape), 2), dtype)
+    ref.backward(g.double())
+    gx = K().maxpool_bwd(to_dev_nhwc(g, dtype), idx, (H, W), 3, 2, 1)
+    # ties (ReLU zeros) may pick a different-but-equal winner than ATen only if the scan order
+    # differed; it does not: compare exactly up to rounding
+    assert_close(to_cpu_nchw(gx), xa.grad, dtype, "maxpool bwd")
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+@pytest.mark.parametrize("o", [1, 2, 3, 6])
+def test_adaptive_avgpool_fwd_bwd(o, dtype):
+    N, C, H, W = 2, 48, 13, 17  # not divisible by 2/3/6 -> overlapping bins
+    x = quant(rnd((N, C, H, W), 1), dtype).double().requires_grad_()
+    ref = TF.adaptive_avg_pool2d(x, o)
+    xd = to_dev_nhwc(x.detach().float(), dtype)
+    sums = K().adaptive_avgpool_sums(xd, o)
+    areas = K().adaptive_bin_areas(H, W, o, sums.device)
+    got = (sums / areas.view(1, o, o, 1)).cpu().permute(0, 3, 1, 2)
+    assert_close(got, ref.detach(), torch.float32, "adaptive pool fwd", fac=5)
+    g = quant(rnd(tuple(ref.shape), 2), dtype)
+    ref.backward(g.double())
+    gx = K().adaptive_avgpool_bwd(to_dev_nhwc(g, dtype), (H, W))
+    assert_close(to_cpu_nchw(gx), x.grad, dtype, "adaptive pool bwd")
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+@pytest.mark.parametrize("case", [(2, 15, 19, 32, 64, 3, 2, 1, 1), (1, 14, 18, 16, 32, 3, 2, 2, 2),
+                                  (2, 12, 12, 64, 32, 3, 1, 1, 1)])
+def test_strided_dense_conv_dgrad_via_transposed_gather(case, dtype):
+    N, H, W, C, O, k, stride, pad, dil = case
+    x = rnd((N, C, H, W), 1).double().requires_grad_()
+    w = quant(rnd((O, C, k, k), 2, 0.1), dtype)
+    y = TF.conv2d(x, w.double(), None, stride, pad, dil)
+    dy = quant(rnd(tuple(y.shape), 3), dtype)
+    y.backward(dy.double())
+    wt = F().pack_conv_weight_tconv(w.to(DEV), O, dtype)
+    g, _ = K().conv_gemm(to_dev_nhwc(dy, dtype), wt, C, k, k, stride, pad, dil, tconv_out_hw=(H, W))
+    assert_close(to_cpu_nchw(g), x.grad, dtype, "tconv dgrad")
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+def test_elementwise_dropout_mask_forward_backward(dtype):
+    N, C, H, W = 2, 40, 7, 9
+    x = quant(rnd((N, C, H, W), 1), dtype)
+    gamma, beta = torch.rand(C) + 0.5, rnd((C,), 3, 0.2)
+    mask = quant((torch.rand(N, C, H, W) > 0.3).float() / 0.7, dtype)
+    xr = x.double().requires_grad_()
+    y = torch.relu(TF.batch_norm(xr, None, None, gamma.double(), beta.double(), True, 0.1, 1e-5)) * mask.double()
+    g = quant(rnd((N, C, H, W), 5), dtype)
+    y.backward(g.double())
+    sums = torch.cat([x.double().sum((0, 2, 3)), (x.double() ** 2).sum((0, 2, 3))]).to(DEV)
+    gd, bd = gamma.to(DEV), beta.to(DEV)
+    mean, invstd, scale, shift = K().bn_finalize(sums, N * H * W, gd, bd, 1e-5, 0.1, None, None)
+    md = to_dev_nhwc(mask, dtype)
+    got = K().bn_apply(to_dev_nhwc(x, dtype), (3, scale, shift), elem_mul=md)
+    assert_close(to_cpu_nchw(got), y.detach(), dtype, "dropout fwd")
+    bn = F().BNState(gd, bd, mean, invstd, scale, shift, float(N * H * W), True)
+    dx, _, _ = F().bn_input_backward(to_dev_nhwc(g, dtype), to_dev_nhwc(x, dtype), bn, True, elem_mul=md)
+    assert_close(to_cpu_nchw(dx), xr.grad, dtype, "dropout bwd", fac=3)
