@@ -134,8 +134,10 @@ def test_hip_eval_fp32_matches_reference_fixture(tag):
     g = np.load(os.path.join(GOLDEN, tag + "_eval.npz"))
     rel = _rel(logits, torch.from_numpy(g["logits"]))
     print("%s eval fp32 max-rel vs reference fixture: %.3e" % (tag, rel))
+    mism = (logits.argmax(1).numpy() != g["argmax"]).mean()
+    print("%s argmax mismatch fraction %.2e" % (tag, mism))
     assert rel < 1e-3
-    assert (logits.argmax(1).numpy() == g["argmax"]).all()
+    assert mism == 0.0
 
 
 @pytest.mark.gpu
@@ -160,6 +162,7 @@ def test_hip_train_fp32_matches_reference(tag):
     params = dict(model.named_parameters())
     nh = nc = den = 0.0
     worst = (0.0, "")
+    allw = []
     for k, t64 in g64.items():
         assert params[k].grad is not None, k
         gh = params[k].grad.detach().cpu().double()
@@ -168,6 +171,11 @@ def test_hip_train_fp32_matches_reference(tag):
         nh, nc, den = nh + eh ** 2, nc + ec ** 2, den + n64 ** 2
         bound = 4 * ec + 1e-3 * n64 if n64 > 10 * ec else 20 * ec + 1e-12
         worst = max(worst, (eh / max(bound, 1e-30), k))
+        allw.append((eh / max(bound, 1e-30), k, eh, ec, n64))
+    for w in sorted(allw, reverse=True)[:8]:
+        print("   %-50s ratio %.2f err_hip %.3e err_cpu32 %.3e |g64| %.3e" % (w[1], w[0], w[2], w[3], w[4]))
+    if True:
+        pass
     print("%s gradients vs fp64 oracle: global rel err HIP %.3e, CPU-fp32 %.3e; worst ratio %.2f (%s)"
           % (tag, (nh / den) ** 0.5, (nc / den) ** 0.5, worst[0], worst[1]))
     assert (nh / den) ** 0.5 <= 3 * (nc / den) ** 0.5 + 1e-4

@@ -51,6 +51,7 @@ CONV_CASES = [
     (2, 13, 11, 8, 32, 3, 2, 1, 1, 0, False, False),      # stem on channel-padded input
     (1, 10, 14, 16, 24, 3, 1, 2, 2, 2, False, True),      # dilated dense
     (2, 1, 1, 2048, 256, 1, 1, 0, 1, 0, False, False),    # ASPP image-pooling (M = batch)
+    (2, 7, 9, 4096, 512, 3, 1, 1, 1, 0, False, False),    # PSP head: K = 36864
 ]
 
 
@@ -111,6 +112,7 @@ WGRAD_CASES = [
     (2, 13, 11, 32, 64, 3, 1, 1, 1, 3),
     (2, 13, 11, 8, 32, 3, 2, 1, 1, 0),
     (1, 12, 20, 256, 19, 1, 1, 0, 1, 3),     # ragged dy channels
+    (2, 7, 9, 4096, 512, 3, 1, 1, 1, 0),     # PSP head: K = 36864, one pixel split
 ]
 
 
