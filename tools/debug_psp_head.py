@@ -31,7 +31,7 @@ y = head(F.Act(x_dev))  # NHWC [N,H,W,19]
 y.backward(g.float().permute(0, 2, 3, 1).contiguous().cuda())
 
 # reference
-osd = {("head." + k): v.double() for k, v in sd.items()}
+osd = {("head." + k): (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
 osd = torch_ref.clone_state(osd, requires_grad=True)
 net = torch_ref.OracleNet(osd, training=True, drop_p=0.0)
 xr = c4.clone().requires_grad_()
