@@ -26,6 +26,17 @@ N, H, W = 2, 7, 9
 c4 = torch.relu(torch.randn(N, 2048, H, W, dtype=torch.float64))
 g = torch.randn(N, 19, H, W, dtype=torch.float64)
 
+from segmentron_amd import hip_ops as K  # noqa: E402
+calls = []
+_orig = K.bn_bwd_reduce_partial
+
+
+def _rec(g, x, pro, chan_mul=None, elem_mul=None):
+    calls.append((g.clone(), x.clone(), pro))
+    return _orig(g, x, pro, chan_mul, elem_mul)
+
+
+K.bn_bwd_reduce_partial = _rec
 x_dev = c4.float().permute(0, 2, 3, 1).contiguous().cuda().requires_grad_()
 y = head(F.Act(x_dev))  # NHWC [N,H,W,19]
 y.backward(g.float().permute(0, 2, 3, 1).contiguous().cuda())
@@ -44,7 +55,10 @@ cat = torch.cat(feats, 1)
 cat.retain_grad()
 z = net.conv(cat, "head.block.0", 1, 1)
 z.retain_grad()
-yr = net.conv(torch.relu(net.bn(z, "head.block.1")), "head.block.4")
+bno = net.bn(z, "head.block.1")
+act = torch.relu(bno)
+act.retain_grad()
+yr = net.conv(act, "head.block.4")
 yr.backward(g)
 
 
@@ -56,3 +70,12 @@ print("fwd", rel(y.detach().permute(0, 3, 1, 2), yr.detach()))
 print("d c4", rel(x_dev.grad.permute(0, 3, 1, 2), xr.grad))
 for k, p in head.named_parameters():
     print("%-28s %.3e" % (k, rel(p.grad, osd["head." + k].grad)))
+
+g0, x0, pro0 = calls[0]
+print("first BN-backward call: g shape", tuple(g0.shape), "mode", pro0[0])
+print("  g vs ref act.grad", rel(g0.permute(0, 3, 1, 2), act.grad), " x vs ref z", rel(x0.permute(0, 3, 1, 2), z.detach()))
+zm = z.detach().mean((0, 2, 3)); zv = z.detach().var((0, 2, 3), unbiased=False)
+sc_ref = osd["head.head.block.1.weight"].detach() / torch.sqrt(zv + 1e-5) if "head.head.block.1.weight" in osd else osd["head.block.1.weight"].detach() / torch.sqrt(zv + 1e-5)
+print("  scale vs ref", rel(pro0[1], sc_ref))
+colsum_g = g0.double().cpu().sum((0, 1, 2))
+print("  colsum(g) vs ref", rel(colsum_g, act.grad.sum((0, 2, 3))))
