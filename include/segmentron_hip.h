@@ -15,7 +15,8 @@
  *   - dtype: 0 = float32, 1 = bfloat16 (element type of activations / packed weights);
  *     BatchNorm parameters, statistics and all accumulation are float32 / float64
  *   - pro_mode ("prologue"): the producer's BatchNorm(+ReLU) applied on the fly to an input:
- *     0 none, 1 relu(x), 2 x*scale[c]+shift[c], 3 relu(x*scale[c]+shift[c])
+ *     0 none, 1 relu(x), 2 x*scale[c]+shift[c], 3 relu(x*scale[c]+shift[c]); +4 = ReLU6 clamp
+ *     (5 = relu6(x), 7 = relu6(x*scale[c]+shift[c]))
  *   - `stream` is a hipStream_t; all launches are asynchronous on it; no host synchronisation,
  *     no allocation, no global mutable state (re-entrant, graph-capturable)
  *   - return value 0 = ok; otherwise seg_last_error() (thread-local) describes the failure.

@@ -3,6 +3,7 @@
 
     python oracle/gen_golden_more.py c1     # FCN resnet50 (OS16)            -> tests/golden/c1_*
     python oracle/gen_golden_more.py c4     # PSPNet resnet50 (OS8, aux)     -> tests/golden/c4_*
+    python oracle/gen_golden_more.py c2     # DeepLabv3+ mobilenet_v2        -> tests/golden/c2_*
 
 One process per model (the reference cfg singleton freezes).  resnet50 is used instead of
 resnet101 to keep the fixtures small — same blocks, same code path (BASELINE C1 as written,
@@ -30,6 +31,8 @@ CASES = {
                fn="fcn_resnet", os=16, aux=False, hw=(65, 97), eps_enc=None),
     "c4": dict(yaml="configs/cityscapes_pspnet_resnet.yaml", over=["MODEL.BACKBONE", "resnet50"],
                fn="pspnet_resnet", os=8, aux=True, hw=(49, 65), eps_enc=None),
+    "c2": dict(yaml="configs/cityscapes_deeplabv3_plus_mobilenet.yaml", over=[],
+               fn="deeplab_mobilenet", os=16, aux=False, hw=(65, 97), eps_enc=None),
 }
 
 

@@ -264,6 +264,60 @@ def _pspnet_resnet(self, x):
     return tuple(outs)
 
 
+# ---------------------------------------------------------------------- MobileNetV2
+def _inverted_residual(self, x, p, stride, dilation, expand):
+    """InvertedResidual — segmentron/modules/basic.py:139-163."""
+    y, i = x, 0
+    if expand:
+        y = self.conv_bn_relu(y, p + ".conv.0", relu6=True)
+        i = 1
+    c = y.shape[1]
+    y = self.conv_bn_relu(y, p + ".conv.%d" % i, stride, dilation, dilation, groups=c, relu6=True)
+    y = self.bn(self.conv(y, p + ".conv.%d" % (i + 1)), p + ".conv.%d" % (i + 2))
+    if stride == 1 and x.shape[1] == y.shape[1]:
+        return x + y
+    return y
+
+
+def _mobilenet_v2(self, x, prefix="encoder"):
+    """MobileNetV2 — segmentron/models/backbones/mobilenet.py:55-143 (dilation only on the first
+    block of a dilated group, :125 vs :128)."""
+    os_ = self.output_stride
+    dil = {32: (1, 1), 16: (1, 2), 8: (2, 4)}[os_]
+    setting = [[1, 16, 1, 1], [6, 24, 2, 2], [6, 32, 3, 2], [6, 64, 4, 2], [6, 96, 3, 1],
+               [6, 160, 3, 2], [6, 320, 1, 1]]
+    groups = [(setting[0:1], 1), (setting[1:2], 1), (setting[2:3], 1), (setting[3:5], dil[0]),
+              (setting[5:], dil[1])]
+    p = prefix + "."
+    x = self.conv_bn_relu(x, p + "conv1", 2, 1, relu6=True)
+    outs = []
+    for gi, (sets, d) in enumerate(groups):
+        j = 0
+        for t, c, n, s_ in sets:
+            stride = s_ if d == 1 else 1
+            x = _inverted_residual(self, x, p + "block%d.%d" % (gi + 1, j), stride, d, t != 1)
+            j += 1
+            for _ in range(n - 1):
+                x = _inverted_residual(self, x, p + "block%d.%d" % (gi + 1, j), 1, 1, t != 1)
+                j += 1
+        if gi > 0:
+            outs.append(x)
+    return tuple(outs)
+
+
+def _deeplab_mobilenet(self, x):
+    """DeepLabV3Plus.forward with USE_ASPP False / ENABLE_DECODER False
+    (configs/cityscapes_deeplabv3_plus_mobilenet.yaml:21-23; deeplabv3_plus.py:66-75)."""
+    size = x.shape[2:]
+    _, _, _, c4 = _mobilenet_v2(self, x)
+    y = self.separable_conv(c4, "head.block.0", relu_first=False)
+    y = self.separable_conv(y, "head.block.1", relu_first=False)
+    y = self.conv(y, "head.block.2")
+    return (F.interpolate(y, size, mode="bilinear", align_corners=True),)
+
+
+OracleNet.mobilenet_v2 = _mobilenet_v2
+OracleNet.deeplab_mobilenet = _deeplab_mobilenet
 OracleNet.resnet = _resnet
 OracleNet.fcn_resnet = _fcn_resnet
 OracleNet.pspnet_resnet = _pspnet_resnet

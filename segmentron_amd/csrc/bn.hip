@@ -131,6 +131,10 @@ __device__ __forceinline__ void act_regs(float* f, int mode, const float* sc, co
 #pragma unroll
     for (int k = 0; k < VEC; ++k) f[k] = fmaxf(f[k], 0.f);
   }
+  if (mode & PRO_CLAMP6) {
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) f[k] = fminf(f[k], 6.f);
+  }
 }
 
 template <typename T>
@@ -214,7 +218,8 @@ __device__ __forceinline__ void masked_grad(const BwdArgs& a, const T* G, const 
 #pragma unroll
     for (int k = 0; k < VEC; ++k) {
       const float y = (a.mode & PRO_AFFINE) ? fmaf(x[k], sc[k], sh[k]) : x[k];
-      g[k] = y > 0.f ? g[k] : 0.f;
+      const bool on = y > 0.f && (!(a.mode & PRO_CLAMP6) || y < 6.f);  // ReLU / ReLU6 derivative
+      g[k] = on ? g[k] : 0.f;
     }
   }
 }

@@ -15,7 +15,8 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 enum { DT_F32 = 0, DT_BF16 = 1 };
 // prologue applied to a conv / elementwise input:  v = x*scale[c] + shift[c]  (if AFFINE), then relu
-enum { PRO_NONE = 0, PRO_RELU = 1, PRO_AFFINE = 2, PRO_AFFINE_RELU = 3 };
+enum { PRO_NONE = 0, PRO_RELU = 1, PRO_AFFINE = 2, PRO_AFFINE_RELU = 3, PRO_CLAMP6 = 4 };
+// PRO_CLAMP6 (with PRO_RELU): ReLU6 = min(max(v,0),6)  (segmentron/modules/basic.py:71)
 
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) {
   return __uint_as_float(((uint32_t)v) << 16);
@@ -137,6 +138,10 @@ __device__ __forceinline__ void apply_prologue(float* f, int mode, const float* 
   if (mode & PRO_RELU) {
 #pragma unroll
     for (int i = 0; i < N; ++i) f[i] = fmaxf(f[i], 0.f);
+  }
+  if (mode & PRO_CLAMP6) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) f[i] = fminf(f[i], 6.f);
   }
 }
 

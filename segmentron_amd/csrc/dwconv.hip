@@ -60,6 +60,10 @@ __device__ __forceinline__ void dw_act(float* f, int mode, const float* sc, cons
 #pragma unroll
     for (int i = 0; i < VEC; ++i) f[i] = fmaxf(f[i], 0.f);
   }
+  if (mode & PRO_CLAMP6) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) f[i] = fminf(f[i], 6.f);
+  }
 }
 
 // FAST: stride 1, dilation 1 (59 of the 68 xception dw layers, and every stride-1 data
@@ -518,7 +522,10 @@ __global__ __launch_bounds__(DW_THREADS) void dwconv_bwd_fused_kernel(const DwBw
       if (w0 + j < a.W) {
         if (a.pro_mode & PRO_RELU) {
 #pragma unroll
-          for (int i = 0; i < VEC; ++i) g[j][i] = xa[j][i] > 0.f ? g[j][i] : 0.f;
+          for (int i = 0; i < VEC; ++i) {
+            const bool on = xa[j][i] > 0.f && (!(a.pro_mode & PRO_CLAMP6) || xa[j][i] < 6.f);
+            g[j][i] = on ? g[j][i] : 0.f;
+          }
         }
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {

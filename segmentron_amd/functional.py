@@ -33,8 +33,12 @@ class BNState:
         self.count, self.training, self.group = count, training, group
 
 
+RELU, RELU6 = 1, 5  # values of `Act.relu`: prologue / mask bits (ReLU6 = relu + clamp-at-6)
+
+
 class Act:
-    """NHWC activation with a pending BatchNorm affine and/or ReLU."""
+    """NHWC activation with a pending BatchNorm affine and/or ReLU (`relu` in {0/False, 1/True,
+    RELU6})."""
     __slots__ = ("t", "bn", "relu")
 
     def __init__(self, t, bn=None, relu=False):
@@ -42,7 +46,7 @@ class Act:
 
     @property
     def pro(self):
-        mode = (PRO_AFFINE if self.bn is not None else PRO_NONE) | (PRO_RELU if self.relu else 0)
+        mode = (PRO_AFFINE if self.bn is not None else PRO_NONE) | int(self.relu)
         if self.bn is None:
             return (mode, None, None)
         return (mode, self.bn.scale, self.bn.shift)
@@ -54,7 +58,7 @@ class Act:
         return self.bn.gamma, self.bn.beta
 
     def with_relu(self):
-        return Act(self.t, self.bn, True)
+        return Act(self.t, self.bn, self.relu or True)
 
     @property
     def shape(self):
@@ -111,7 +115,7 @@ def flush_bn_counters():
 
 def bn_input_backward(g, x, bn, relu, chan_mul=None, inplace=False, elem_mul=None):
     """g = dLoss/d(act(x)*chan_mul*elem_mul)  ->  (dLoss/dx_raw, dgamma, dbeta)."""
-    mode = (PRO_AFFINE if bn is not None else PRO_NONE) | (PRO_RELU if relu else 0)
+    mode = (PRO_AFFINE if bn is not None else PRO_NONE) | int(relu)
     if bn is None:
         if not relu and chan_mul is None and elem_mul is None:
             return g, None, None

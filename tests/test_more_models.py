@@ -1,4 +1,4 @@
-"""FCN / PSPNet on ResNet backbones (BASELINE configs C1, C4; resnet50 fixtures):
+"""FCN / PSPNet on ResNet backbones and DeepLabv3+ on MobileNetV2 (BASELINE configs C1, C4, C2):
 CPU  — the oracle reproduces the fixtures generated from the reference; the module tree has the
        reference's state_dict schema;
 GPU  — the HIP fp32 path matches the reference fixture (eval logits 1e-3 + argmax, train loss /
@@ -18,6 +18,10 @@ CASES = {
                aux_weight=0.4),
     "c4": dict(model="PSPNet", backbone="resnet50", os=8, aux=True, fn="pspnet_resnet", hw=(49, 65),
                aux_weight=0.4),
+    "c2": dict(model="DeepLabV3_Plus", backbone="mobilenet_v2", os=16, aux=False,
+               fn="deeplab_mobilenet", hw=(65, 97), aux_weight=0.4,
+               over=["MODEL.DEEPLABV3_PLUS.USE_ASPP", "False",
+                     "MODEL.DEEPLABV3_PLUS.ENABLE_DECODER", "False"]),
 }
 
 
@@ -40,7 +44,7 @@ def _cfg(tag):
     cfg.update_from_list(["DATASET.NAME", "cityscape", "MODEL.MODEL_NAME", c["model"],
                           "MODEL.BACKBONE", c["backbone"], "MODEL.OUTPUT_STRIDE", str(c["os"]),
                           "SOLVER.AUX", str(c["aux"]), "SOLVER.AUX_WEIGHT", str(c["aux_weight"]),
-                          "TRAIN.BACKBONE_PRETRAINED", "False"])
+                          "TRAIN.BACKBONE_PRETRAINED", "False"] + c.get("over", []))
     cfg.PHASE = "test"
     cfg.check_and_freeze()
     return cfg
