@@ -193,6 +193,15 @@ int seg_bilinear_fwd(int dtype, const void* x, long ldx, int N, int Hi, int Wi, 
                      void* stream);
 int seg_bilinear_bwd(int dtype, void* gx, long ldgx, int N, int Hi, int Wi, int C, const void* gy,
                      long ldgy, int Ho, int Wo, int align_corners, void* stream);
+/* nn.Upsample(scale_factor=2^shift, mode='nearest') fused with the running sum of HRNet's
+ * cross-resolution fuse (segmentron/models/backbones/hrnet.py:186,215-229):
+ * y = post_relu?( act_x(x) + act_r(r[n, h>>shift, w>>shift]) ); backward of r = block sums. */
+int seg_nearest_add(int dtype, const void* x, long ldx, int mode_x, const float* sx,
+                    const float* tx, const void* r, long ldr, int mode_r, const float* sr,
+                    const float* tr, int shift, int post_relu, void* y, long ldy, int N, int H,
+                    int W, int C, void* stream);
+int seg_nearest_sum_bwd(int dtype, const void* g, long ldg, int N, int H, int W, int C, int shift,
+                        void* gr, long ldgr, void* stream);
 /* Model boundary: NHWC logits (C valid channels, pitch ldx) -> NCHW float32 [N,C,Ho,Wo] and back. */
 int seg_upsample_to_nchw(int dtype, const void* x, long ldx, int N, int Hi, int Wi, int C,
                          float* out, int Ho, int Wo, int align_corners, void* stream);

@@ -4,6 +4,7 @@
     python oracle/gen_golden_more.py c1     # FCN resnet50 (OS16)            -> tests/golden/c1_*
     python oracle/gen_golden_more.py c4     # PSPNet resnet50 (OS8, aux)     -> tests/golden/c4_*
     python oracle/gen_golden_more.py c2     # DeepLabv3+ mobilenet_v2        -> tests/golden/c2_*
+    python oracle/gen_golden_more.py c5     # HRNet hrnet_w18_small_v1       -> tests/golden/c5_*
 
 One process per model (the reference cfg singleton freezes).  resnet50 is used instead of
 resnet101 to keep the fixtures small — same blocks, same code path (BASELINE C1 as written,
@@ -33,6 +34,9 @@ CASES = {
                fn="pspnet_resnet", os=8, aux=True, hw=(49, 65), eps_enc=None),
     "c2": dict(yaml="configs/cityscapes_deeplabv3_plus_mobilenet.yaml", over=[],
                fn="deeplab_mobilenet", os=16, aux=False, hw=(65, 97), eps_enc=None),
+    # HRNet needs H, W divisible by 32 (nearest x2 upsamples must meet the stride-2 conv sizes)
+    "c5": dict(yaml="configs/cityscapes_hrnet_w18_small_v1.yaml", over=[], fn="hrnet_seg", os=16,
+               aux=False, hw=(64, 128), eps_enc=None, mom=0.01),
 }
 
 
@@ -80,7 +84,8 @@ def main(tag):
             sd[k] = torch.zeros((), dtype=torch.long)
     model.load_state_dict(sd, strict=True)
 
-    kw = dict(output_stride=c["os"], aux=c["aux"], eps_encoder=c["eps_enc"], drop_p=0.0)
+    kw = dict(output_stride=c["os"], aux=c["aux"], eps_encoder=c["eps_enc"], drop_p=0.0,
+              momentum=c.get("mom"))
     model.eval()
     with torch.no_grad():
         outs = model(x)
@@ -107,13 +112,24 @@ def main(tag):
     worst = max((osd[k].grad - g).abs().max().item() for k, g in grads.items())
     assert worst == 0.0, "oracle backward differs from the reference: %g" % worst
     print(tag, "train loss %.6f; oracle == reference bit-for-bit (fwd + %d grads)" % (loss.item(), len(grads)))
+    # running statistics after the train step (momentum / unbiased-variance / conv-bias paths)
+    msd, stat_err = model.state_dict(), 0.0
+    for k in msd:
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            stat_err = max(stat_err, (msd[k] - osd[k].detach()).abs().max().item())
+    assert stat_err == 0.0, "oracle running stats differ from the reference: %g" % stat_err
     names = list(grads)
+    stat_keys = [k for k in msd if k.endswith("running_mean")]
+    stat_keys = stat_keys[:2] + stat_keys[-2:]
+    stat_keys += [k[:-4] + "var" for k in stat_keys]
     payload = {"loss": np.float64(loss.item()), "logits": outs[0].detach().numpy(),
                "grad_norm_keys": np.array(names),
                "grad_norms": np.array([float(grads[k].double().norm()) for k in names])}
     for k in names[:2] + names[len(names) // 2:len(names) // 2 + 2] + names[-2:]:
         if grads[k].numel() <= 300000:
             payload["grad::" + k] = grads[k].numpy()
+    for k in stat_keys:
+        payload["stat::" + k] = msd[k].numpy()
     np.savez_compressed(os.path.join(GOLD, tag + "_train.npz"), **payload)
 
 

@@ -316,6 +316,127 @@ def _deeplab_mobilenet(self, x):
     return (F.interpolate(y, size, mode="bilinear", align_corners=True),)
 
 
+def _hr_block(self, x, p):
+    """BasicBlock / Bottleneck of HRNet (always stride 1) — backbones/hrnet.py:25-95."""
+    sd = self.sd
+    if (p + ".conv3.weight") in sd:
+        out = F.relu(self.bn(self.conv(x, p + ".conv1"), p + ".bn1"))
+        out = F.relu(self.bn(self.conv(out, p + ".conv2", 1, 1), p + ".bn2"))
+        out = self.bn(self.conv(out, p + ".conv3"), p + ".bn3")
+    else:
+        out = F.relu(self.bn(self.conv(x, p + ".conv1", 1, 1), p + ".bn1"))
+        out = self.bn(self.conv(out, p + ".conv2", 1, 1), p + ".bn2")
+    residual = x
+    if (p + ".downsample.0.weight") in sd:
+        residual = self.bn(self.conv(x, p + ".downsample.0"), p + ".downsample.1")
+    return F.relu(out + residual)
+
+
+def _hr_blocks(self, x, p):
+    j = 0
+    while (p + ".%d.conv1.weight" % j) in self.sd:
+        x = _hr_block(self, x, p + ".%d" % j)
+        j += 1
+    return x
+
+
+def _hr_down_chain(self, x, p, relu_last):
+    """Sequential of (3x3 stride-2 conv, BN[, ReLU]) — hrnet.py:190-207 / :350-359."""
+    k = 0
+    while (p + ".%d.0.weight" % k) in self.sd:
+        x = self.bn(self.conv(x, p + ".%d.0" % k, 2, 1), p + ".%d.1" % k)
+        last = (p + ".%d.0.weight" % (k + 1)) not in self.sd
+        if relu_last or not last:
+            x = F.relu(x)
+        k += 1
+    return x
+
+
+def _hr_module(self, xs, p):
+    """HighResolutionModule.forward — hrnet.py:211-229."""
+    sd = self.sd
+    nb = len(xs)
+    xs = [_hr_blocks(self, xs[i], p + ".branches.%d" % i) for i in range(nb)]
+    if nb == 1:
+        return xs
+    fused = []
+    for i in range(nb):
+        q = p + ".fuse_layers.%d" % i
+        if not any((q + ".%d.0.weight" % j) in sd or (q + ".%d.0.0.weight" % j) in sd
+                   for j in range(nb)):
+            break  # multi_scale_output=False: only row 0 exists
+        y = None
+        for j in range(nb):
+            if j == i:
+                t = xs[j]
+            elif j > i:
+                t = self.bn(self.conv(xs[j], q + ".%d.0" % j), q + ".%d.1" % j)
+                t = F.interpolate(t, scale_factor=2 ** (j - i), mode="nearest")
+            else:
+                t = _hr_down_chain(self, xs[j], q + ".%d" % j, relu_last=False)
+            y = t if y is None else y + t
+        fused.append(F.relu(y))
+    return fused
+
+
+def _hr_stage(self, xs, p):
+    m = 0
+    while (p + ".%d.branches.0.0.conv1.weight" % m) in self.sd:
+        xs = _hr_module(self, xs, p + ".%d" % m)
+        m += 1
+    return xs
+
+
+def _hr_transition(self, prev, p, nb):
+    """HighResolutionNet.forward's transition step — hrnet.py:438-458: a present transition is
+    applied to the LAST (coarsest) previous branch, an absent one passes branch i through."""
+    sd = self.sd
+    out = []
+    for i in range(nb):
+        q = p + ".%d" % i
+        if (q + ".0.weight") in sd:      # Sequential(conv3x3, bn, relu)
+            out.append(F.relu(self.bn(self.conv(prev[-1], q + ".0", 1, 1), q + ".1")))
+        elif (q + ".0.0.weight") in sd:  # chain of stride-2 convs
+            out.append(_hr_down_chain(self, prev[-1], q, relu_last=True))
+        else:
+            out.append(prev[i])
+    return out
+
+
+def _hrnet(self, x, prefix="encoder"):
+    """HighResolutionNet.forward — backbones/hrnet.py:429-480."""
+    sd = self.sd
+    p = prefix + "."
+    x = F.relu(self.bn(self.conv(x, p + "conv1", 2, 1), p + "bn1"))
+    x = F.relu(self.bn(self.conv(x, p + "conv2", 2, 1), p + "bn2"))
+    x = _hr_blocks(self, x, p + "layer1")
+    ys = [x]
+    for s in (2, 3, 4):
+        nb = 0
+        while (p + "stage%d.0.branches.%d.0.conv1.weight" % (s, nb)) in sd:
+            nb += 1
+        xs = _hr_transition(self, ys, p + "transition%d" % (s - 1), nb)
+        ys = _hr_stage(self, xs, p + "stage%d" % s)
+    return tuple(ys)
+
+
+def _hrnet_seg(self, x):
+    """HighResolutionNet (model 'HRNet') + _HRNetHead — models/hrnet_seg.py:23-60."""
+    size = x.shape[2:]
+    ys = _hrnet(self, x)
+    hw = ys[0].shape[2:]
+    feats = [ys[0]] + [F.interpolate(t, size=hw, mode="bilinear", align_corners=False)
+                       for t in ys[1:]]
+    q = "hrnet_head.last_layer"
+    y = torch.cat(feats, 1)
+    y = F.relu(self.bn(self.conv(y, q + ".0"), q + ".1"))
+    k = self.sd[q + ".3.weight"].shape[-1]
+    y = self.conv(y, q + ".3", 1, 1 if k == 3 else 0)
+    return [F.interpolate(y, size=size, mode="bilinear", align_corners=False)]
+
+
+OracleNet.hrnet = _hrnet
+OracleNet.hrnet_seg = _hrnet_seg
 OracleNet.mobilenet_v2 = _mobilenet_v2
 OracleNet.deeplab_mobilenet = _deeplab_mobilenet
 OracleNet.resnet = _resnet

@@ -234,6 +234,85 @@ __global__ __launch_bounds__(RS_THREADS) void nchw_to_nhwc_pad_kernel(const floa
   }
 }
 
+// ---- HRNet cross-resolution fuse (segmentron/models/backbones/hrnet.py:167-229):
+//   y[n,h,w,:] = post_relu?( act_x(x[n,h,w,:]) + act_r(r[n, h>>s, w>>s, :]) )
+// i.e. nn.Upsample(scale_factor=2^s, mode='nearest') of a deferred (conv1x1+BN) tensor fused with
+// the running sum; backward of the upsampled operand = f x f block sums.
+struct AddUpArgs {
+  const void* x; const void* r; void* y;
+  const float* sx; const float* tx; const float* sr; const float* tr;
+  long ldx, ldr, ldy;
+  int N, H, W, C, CV, mode_x, mode_r, shift, post_relu;
+};
+
+__device__ __forceinline__ int rs_fast_div(int s, int d, float inv) {
+  int q = (int)((float)s * inv);
+  if (q * d > s) --q;
+  if ((q + 1) * d <= s) ++q;
+  return q;
+}
+
+template <typename T>
+__global__ __launch_bounds__(RS_THREADS) void nearest_add_kernel(const AddUpArgs a) {
+  constexpr int VEC = Vec<T>::N;
+  const T* __restrict__ X = reinterpret_cast<const T*>(a.x);
+  const T* __restrict__ R = reinterpret_cast<const T*>(a.r);
+  T* __restrict__ Y = reinterpret_cast<T*>(a.y);
+  const int total = a.N * a.H * a.W * a.CV;
+  const int Hr = a.H >> a.shift, Wr = a.W >> a.shift;
+  const float inv_cv = 1.f / (float)a.CV, inv_w = 1.f / (float)a.W, inv_h = 1.f / (float)a.H;
+  for (int i = blockIdx.x * RS_THREADS + threadIdx.x; i < total; i += gridDim.x * RS_THREADS) {
+    const int p = rs_fast_div(i, a.CV, inv_cv);
+    const int c0 = (i - p * a.CV) * VEC;
+    const int t = rs_fast_div(p, a.W, inv_w);
+    const int w = p - t * a.W;
+    const int n = rs_fast_div(t, a.H, inv_h);
+    const int h = t - n * a.H;
+    float f[VEC], g[VEC];
+    Vec<T>::unpack(ldg16(X + (long)p * a.ldx + c0), f);
+    apply_prologue<VEC>(f, a.mode_x, a.sx, a.tx, c0);
+    const long pr = ((long)n * Hr + (h >> a.shift)) * Wr + (w >> a.shift);
+    Vec<T>::unpack(ldg16(R + pr * a.ldr + c0), g);
+    apply_prologue<VEC>(g, a.mode_r, a.sr, a.tr, c0);
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      f[k] += g[k];
+      if (a.post_relu) f[k] = fmaxf(f[k], 0.f);
+    }
+    stg16(Y + (long)p * a.ldy + c0, Vec<T>::pack(f));
+  }
+}
+
+// gr[n,hr,wr,:] = sum_{dh,dw < 2^s} g[n, (hr<<s)+dh, (wr<<s)+dw, :]      (H, W: size of g)
+template <typename T>
+__global__ __launch_bounds__(RS_THREADS) void nearest_sum_bwd_kernel(const AddUpArgs a) {
+  constexpr int VEC = Vec<T>::N;
+  const T* __restrict__ G = reinterpret_cast<const T*>(a.x);
+  T* __restrict__ GR = reinterpret_cast<T*>(a.y);
+  const int Hr = a.H >> a.shift, Wr = a.W >> a.shift, f = 1 << a.shift;
+  const int total = a.N * Hr * Wr * a.CV;
+  const float inv_cv = 1.f / (float)a.CV, inv_w = 1.f / (float)Wr, inv_h = 1.f / (float)Hr;
+  for (int i = blockIdx.x * RS_THREADS + threadIdx.x; i < total; i += gridDim.x * RS_THREADS) {
+    const int p = rs_fast_div(i, a.CV, inv_cv);
+    const int c0 = (i - p * a.CV) * VEC;
+    const int t = rs_fast_div(p, Wr, inv_w);
+    const int wr = p - t * Wr;
+    const int n = rs_fast_div(t, Hr, inv_h);
+    const int hr = t - n * Hr;
+    float acc[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
+    for (int dh = 0; dh < f; ++dh)
+      for (int dw = 0; dw < f; ++dw) {
+        float g[VEC];
+        Vec<T>::unpack(ldg16(G + (((long)n * a.H + (hr << a.shift) + dh) * a.W + (wr << a.shift) + dw) * a.ldx + c0), g);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[k] += g[k];
+      }
+    stg16(GR + (long)p * a.ldy + c0, Vec<T>::pack(acc));
+  }
+}
+
 static int rs_grid(long total) {
   long g = (total + RS_THREADS - 1) / RS_THREADS;
   if (g > 8192) g = 8192;
@@ -348,4 +427,50 @@ extern "C" int seg_nchw_to_nhwc_pad(int dtype, const float* x, int N, int Cin, i
     hipLaunchKernelGGL((nchw_to_nhwc_pad_kernel<float>), dim3(grid), dim3(RS_THREADS), 0,
                        (hipStream_t)stream, x, reinterpret_cast<float*>(y), N, Cin, HW);
   return check_launch("nchw_to_nhwc_pad");
+}
+
+// y = post_relu?( act_x(x) + act_r(nearest_up_{2^shift}(r)) ); x,y: [N,H,W,C], r: [N,H>>shift,W>>shift,C]
+extern "C" int seg_nearest_add(int dtype, const void* x, long ldx, int mode_x, const float* sx,
+                               const float* tx, const void* r, long ldr, int mode_r,
+                               const float* sr, const float* tr, int shift, int post_relu, void* y,
+                               long ldy, int N, int H, int W, int C, void* stream) {
+  using namespace seg;
+  const int vec = dtype == DT_BF16 ? 8 : 4;
+  SEG_REQUIRE(dtype == DT_F32 || dtype == DT_BF16, "nearest_add: bad dtype %d", dtype);
+  SEG_REQUIRE(C % vec == 0 && ldx % vec == 0 && ldr % vec == 0 && ldy % vec == 0,
+              "nearest_add: C/ld must be multiples of %d", vec);
+  SEG_REQUIRE(shift >= 0 && shift < 8 && (H % (1 << shift)) == 0 && (W % (1 << shift)) == 0,
+              "nearest_add: H=%d W=%d not divisible by 2^%d", H, W, shift);
+  SEG_REQUIRE((long)N * H * W * (C / vec) < (1L << 31), "nearest_add: too large");
+  AddUpArgs a;
+  a.x = x; a.r = r; a.y = y; a.sx = sx; a.tx = tx; a.sr = sr; a.tr = tr;
+  a.ldx = ldx; a.ldr = ldr; a.ldy = ldy; a.N = N; a.H = H; a.W = W; a.C = C; a.CV = C / vec;
+  a.mode_x = mode_x; a.mode_r = mode_r; a.shift = shift; a.post_relu = post_relu;
+  const int grid = rs_grid((long)N * H * W * a.CV);
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL((nearest_add_kernel<bf16_t>), dim3(grid), dim3(RS_THREADS), 0, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL((nearest_add_kernel<float>), dim3(grid), dim3(RS_THREADS), 0, (hipStream_t)stream, a);
+  return check_launch("nearest_add");
+}
+
+// gr [N,H>>shift,W>>shift,C] = 2^shift x 2^shift block sums of g [N,H,W,C]
+extern "C" int seg_nearest_sum_bwd(int dtype, const void* g, long ldg, int N, int H, int W, int C,
+                                   int shift, void* gr, long ldgr, void* stream) {
+  using namespace seg;
+  const int vec = dtype == DT_BF16 ? 8 : 4;
+  SEG_REQUIRE(dtype == DT_F32 || dtype == DT_BF16, "nearest_sum_bwd: bad dtype %d", dtype);
+  SEG_REQUIRE(C % vec == 0 && ldg % vec == 0 && ldgr % vec == 0, "nearest_sum_bwd: C/ld");
+  SEG_REQUIRE(shift >= 0 && shift < 8 && (H % (1 << shift)) == 0 && (W % (1 << shift)) == 0,
+              "nearest_sum_bwd: size not divisible");
+  AddUpArgs a;
+  a.x = g; a.r = nullptr; a.y = gr; a.sx = a.tx = a.sr = a.tr = nullptr;
+  a.ldx = ldg; a.ldr = 0; a.ldy = ldgr; a.N = N; a.H = H; a.W = W; a.C = C; a.CV = C / vec;
+  a.mode_x = 0; a.mode_r = 0; a.shift = shift; a.post_relu = 0;
+  const int grid = rs_grid((long)N * (H >> shift) * (W >> shift) * a.CV);
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL((nearest_sum_bwd_kernel<bf16_t>), dim3(grid), dim3(RS_THREADS), 0, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL((nearest_sum_bwd_kernel<float>), dim3(grid), dim3(RS_THREADS), 0, (hipStream_t)stream, a);
+  return check_launch("nearest_sum_bwd");
 }

@@ -216,6 +216,7 @@ class ConvSpec:
         self.stride, self.pad, self.dil = stride, pad, dil
         self.out, self.want_stats = out, want_stats
         self.partial = None
+        self.drop_bias = False
 
 
 class _ConvFn(torch.autograd.Function):
@@ -226,8 +227,11 @@ class _ConvFn(torch.autograd.Function):
         O, Cw, KH, KW = weight.shape
         cx, dt = x.shape[-1], x.dtype
         wp = cached_pack(weight, ("fwd", cx, dt), lambda: pack_conv_weight(weight, cx, dt))
+        # conv bias followed by a training-mode BatchNorm (hrnet_seg.py:22-29): the statistics
+        # come from the accumulators, so the bias is left out of the stored tensor — BN cancels
+        # it exactly; it only re-enters running_mean (finish_bn mean_offset), its gradient is 0
         y, spec.partial = K.conv_gemm(x, wp, O, KH, KW, spec.stride, spec.pad, spec.dil, spec.pro,
-                                      bias, spec.out, spec.want_stats)
+                                      None if spec.drop_bias else bias, spec.out, spec.want_stats)
         ctx.spec = spec
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
@@ -253,7 +257,9 @@ class _ConvFn(torch.autograd.Function):
         else:
             dW = dWp.view(O, KH, KW, Cx)[..., :Cw].permute(0, 3, 1, 2).contiguous()
         dbias = None
-        if ctx.has_bias:
+        if ctx.has_bias and s.drop_bias:
+            dbias = torch.zeros(O, dtype=torch.float32, device=dy.device)
+        elif ctx.has_bias:
             dbias = K.bn_bwd_reduce(dy_full, dy_full, (PRO_NONE, None, None))[:O].float()
         dx = dgamma = dbeta = None
         if ctx.needs_input_grad[0]:
@@ -442,6 +448,44 @@ class _ApplyFn(torch.autograd.Function):
         return dx, dgx, dbx, dr, dgr, dbr, None
 
 
+class AddUpSpec:
+    def __init__(self, a, r, shift, post_relu, out=None):
+        self.bn_x, self.relu_x, self.pro_x = a.bn, a.relu, a.pro
+        self.bn_r, self.relu_r, self.pro_r = r.bn, r.relu, r.pro
+        self.shift, self.post_relu, self.out = shift, post_relu, out
+
+
+class _AddUpFn(torch.autograd.Function):
+    """post_relu?(act(x) + nearest_upsample_{2^shift}(act(r))): one term of HRNet's
+    cross-resolution fuse sum (segmentron/models/backbones/hrnet.py:215-229)."""
+
+    @staticmethod
+    def forward(ctx, x, gx, bx, r, gr, br, spec):
+        y = K.nearest_add(x, spec.pro_x, r, spec.pro_r, spec.shift, spec.post_relu, spec.out)
+        ctx.spec = spec
+        if spec.post_relu:
+            ctx.save_for_backward(x, r, y)
+        else:
+            ctx.save_for_backward(x, r)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        s = ctx.spec
+        if s.post_relu:
+            x, r, y = ctx.saved_tensors
+            g = K.bn_bwd_apply(g, y, (PRO_RELU, None, None))
+        else:
+            x, r = ctx.saved_tensors
+        dx = dgx = dbx = dr = dgr = dbr = None
+        if ctx.needs_input_grad[3]:
+            g_r = K.nearest_sum_bwd(g, s.shift)
+            dr, dgr, dbr = bn_input_backward(g_r, r, s.bn_r, s.relu_r, inplace=True)
+        if ctx.needs_input_grad[0]:
+            dx, dgx, dbx = bn_input_backward(g, x, s.bn_x, s.relu_x, inplace=False)
+        return dx, dgx, dbx, dr, dgr, dbr, None
+
+
 class ResizeSpec:
     def __init__(self, a, out_hw, chan_mul=None, align_corners=True, out=None):
         self.bn, self.relu, self.pro = a.bn, a.relu, a.pro
@@ -592,8 +636,9 @@ def conv_bn(act, conv, bn=None, out=None):
         y = _FoldConvFn.apply(x, g, b, conv.weight, spec)
         offset = spec.mean_offset if batch_stats else None
     else:
+        spec.drop_bias = batch_stats and conv.bias is not None
         y = _ConvFn.apply(x, g, b, conv.weight, conv.bias, spec)
-        offset = None
+        offset = conv.bias.detach() if spec.drop_bias else None
     if bn is None:
         return Act(y)
     N, Ho, Wo, _ = y.shape
@@ -623,6 +668,13 @@ def materialize(act, residual=None, chan_mul=None, post_relu=False, out=None, el
         return _ApplyFn.apply(act.t, gx, bx, None, None, None, spec)
     gr, br = residual.params
     return _ApplyFn.apply(act.t, gx, bx, residual.t, gr, br, spec)
+
+
+def add_upsampled(act, up, shift, post_relu=False, out=None):
+    """-> plain NHWC tensor = post_relu?(act(x) + nearest_upsample_{2^shift}(up))."""
+    gx, bx = act.params
+    gr, br = up.params
+    return _AddUpFn.apply(act.t, gx, bx, up.t, gr, br, AddUpSpec(act, up, shift, post_relu, out))
 
 
 def bilinear(act, out_hw, chan_mul=None, align_corners=True, out=None):

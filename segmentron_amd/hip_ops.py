@@ -238,6 +238,31 @@ def bn_apply(x, pro_x=None, r=None, pro_r=None, chan_mul=None, post_relu=False, 
     return out
 
 
+def nearest_add(x, pro_x, r, pro_r, shift, post_relu=False, out=None):
+    """y = post_relu?(act_x(x) + act_r(nearest_upsample_{2^shift}(r)))  (hrnet.py:186,215-229)"""
+    N, H, W, C, ldx = nhwc(x)
+    Nr, Hr, Wr, Cr, ldr = nhwc(r)
+    if (Nr, Hr << shift, Wr << shift, Cr) != (N, H, W, C):
+        raise ValueError("nearest_add: %s is not %s upsampled by 2^%d"
+                         % (tuple(x.shape), tuple(r.shape), shift))
+    mx, sx, tx = _pro(pro_x)
+    mr, sr, tr = _pro(pro_r)
+    if out is None:
+        out = torch.empty((N, H, W, C), dtype=x.dtype, device=x.device)
+    LIB.call("seg_nearest_add", _DT[x.dtype], _p(x), ldx, mx, _p(sx), _p(tx), _p(r), ldr, mr,
+             _p(sr), _p(tr), shift, int(post_relu), _p(out), nhwc(out)[4], N, H, W, C, _stream())
+    return out
+
+
+def nearest_sum_bwd(g, shift):
+    """gradient of nearest_upsample_{2^shift}: 2^shift x 2^shift block sums."""
+    N, H, W, C, ldg = nhwc(g)
+    out = torch.empty((N, H >> shift, W >> shift, C), dtype=g.dtype, device=g.device)
+    LIB.call("seg_nearest_sum_bwd", _DT[g.dtype], _p(g), ldg, N, H, W, C, shift, _p(out), C,
+             _stream())
+    return out
+
+
 def bn_bwd_reduce_partial(g, x, pro, chan_mul=None, elem_mul=None):
     """-> fp32 [grid_y, 2C] per-block (sum g', sum g'*x)."""
     N, H, W, C, ldg = nhwc(g)

@@ -432,3 +432,70 @@ def test_elementwise_dropout_mask_forward_backward(dtype):
     bn = F().BNState(gd, bd, mean, invstd, scale, shift, float(N * H * W), True)
     dx, _, _ = F().bn_input_backward(to_dev_nhwc(g, dtype), to_dev_nhwc(x, dtype), bn, True, elem_mul=md)
     assert_close(to_cpu_nchw(dx), xr.grad, dtype, "dropout bwd", fac=3)
+
+
+# ------------------------------------------------------------------------------ HRNet fuse
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+@pytest.mark.parametrize("shift", [1, 2, 3])
+@pytest.mark.parametrize("post_relu", [False, True])
+def test_nearest_upsample_add_fwd_bwd(shift, post_relu, dtype):
+    """y = relu?(act(x) + nn.Upsample(2^shift, 'nearest')(bn(r)))  (hrnet.py:186,215-229)."""
+    N, C, Hr, Wr = 2, 32, 3, 5
+    H, W = Hr << shift, Wr << shift
+    x = quant(rnd((N, C, H, W), 1), dtype)
+    r = quant(rnd((N, C, Hr, Wr), 2), dtype)
+    pro_r, s, t = _pro(2, C, 5)
+    xa = x.double().requires_grad_()
+    ra = r.double().requires_grad_()
+    up = TF.interpolate(_act_ref(ra, 2, s.double(), t.double()), scale_factor=2 ** shift, mode="nearest")
+    ref = torch.relu(xa) + up
+    if post_relu:
+        ref = torch.relu(ref)
+    xd, rd = to_dev_nhwc(x, dtype), to_dev_nhwc(r, dtype)
+    y = K().nearest_add(xd, (1, None, None), rd, pro_r, shift, post_relu)
+    assert_close(to_cpu_nchw(y), ref.detach(), dtype, "nearest_add fwd")
+    g = quant(rnd(tuple(ref.shape), 3), dtype)
+    ref.backward(g.double())
+    gd = to_dev_nhwc(g, dtype)
+    if post_relu:
+        gd = K().bn_bwd_apply(gd, y, (1, None, None))
+    gr = K().nearest_sum_bwd(gd, shift)
+    # d/d(bn(r)) — the BN affine backward itself is covered by test_bn_backward_matches_autograd
+    want = ra.grad / s.double().view(1, -1, 1, 1)
+    assert_close(to_cpu_nchw(gr), want, dtype, "nearest_sum_bwd", fac=4)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+def test_conv_bias_before_training_batchnorm_is_dropped_exactly(dtype):
+    """conv(+bias) -> training BN (hrnet_seg.py:22-29): the stored tensor omits the bias, the BN
+    output, the running_mean (which sees the bias) and all gradients match autograd."""
+    import torch.nn as nn
+    N, C, O, H, W = 2, 48, 40, 9, 11
+    conv = nn.Conv2d(C, O, 1, bias=True)
+    bn = nn.BatchNorm2d(O, momentum=0.01)
+    with torch.no_grad():
+        conv.weight.copy_(quant(rnd((O, C, 1, 1), 1, 0.2), dtype))
+        conv.bias.copy_(rnd((O,), 2, 1.0))
+        bn.weight.copy_(torch.rand(O, generator=torch.Generator().manual_seed(3)) + 0.5)
+        bn.bias.copy_(rnd((O,), 4, 0.3))
+    x = quant(rnd((N, C, H, W), 5), dtype)
+    import copy
+    conv_r, bn_r = copy.deepcopy(conv).double(), copy.deepcopy(bn).double()
+    xr = x.double().requires_grad_()
+    ref = torch.relu(bn_r(conv_r(xr)))
+    g = quant(rnd(tuple(ref.shape), 6), dtype)
+    ref.backward(g.double())
+    conv, bn = conv.to(DEV), bn.to(DEV)
+    xd = to_dev_nhwc(x, dtype).requires_grad_()
+    a = F().conv_bn(F().Act(xd), conv, bn)
+    a.relu = True
+    y = F().materialize(a)
+    assert_close(to_cpu_nchw(y.detach()), ref.detach(), dtype, "conv+bias+bn fwd", fac=4)
+    y.backward(to_dev_nhwc(g, dtype))
+    assert_close(bn.running_mean.cpu(), bn_r.running_mean, torch.float32, "running_mean", fac=50)
+    assert_close(bn.running_var.cpu(), bn_r.running_var, torch.float32, "running_var", fac=50)
+    assert_close(to_cpu_nchw(xd.grad), xr.grad, dtype, "dx", fac=8)
+    assert_close(conv.weight.grad.cpu(), conv_r.weight.grad, dtype, "dW", fac=8)
+    assert_close(bn.weight.grad.cpu(), bn_r.weight.grad, dtype, "dgamma", fac=8)
+    assert conv.bias.grad is not None and float(conv.bias.grad.abs().max()) == 0.0
+    assert float(conv_r.bias.grad.abs().max()) < 1e-9
