@@ -32,11 +32,14 @@ static float host_scale(int in, int out, int align) {
   return (float)in / (float)out;
 }
 // candidate output range [lo, hi] whose taps may touch input index i
-__device__ __forceinline__ void cand_range(float scale, int i, int out, int& lo, int& hi) {
+// (align_corners=False: src = scale*(dst+0.5)-0.5, so index i is touched up to
+//  dst < (i+1.5)/scale - 0.5 — half a source pixel further than in the aligned mapping)
+__device__ __forceinline__ void cand_range(float scale, int i, int out, int align, int& lo,
+                                           int& hi) {
   if (scale <= 0.f) { lo = 0; hi = out - 1; return; }
   const float inv = 1.f / scale;
   lo = (int)floorf(((float)i - 1.f) * inv) - 1;
-  hi = (int)ceilf(((float)i + 1.f) * inv) + 1;
+  hi = (int)ceilf(((float)i + (align ? 1.f : 1.5f)) * inv) + 1;
   if (lo < 0) lo = 0;
   if (hi > out - 1) hi = out - 1;
 }
@@ -117,8 +120,8 @@ __global__ __launch_bounds__(RS_THREADS) void bilinear_bwd_kernel(const ResizeAr
     const int n = (int)(p / a.Hi);
     const int c0 = cv * VEC;
     int hlo, hhi, wlo, whi;
-    cand_range(a.sh, hi, a.Ho, hlo, hhi);
-    cand_range(a.sw, wi, a.Wo, wlo, whi);
+    cand_range(a.sh, hi, a.Ho, a.align, hlo, hhi);
+    cand_range(a.sw, wi, a.Wo, a.align, wlo, whi);
     float acc[VEC];
 #pragma unroll
     for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
@@ -192,8 +195,8 @@ __global__ __launch_bounds__(RS_THREADS) void upsample_to_nchw_bwd_kernel(
     const int hi = (int)(p % a.Hi);
     const int n = (int)(p / a.Hi);
     int hlo, hhi, wlo, whi;
-    cand_range(a.sh, hi, a.Ho, hlo, hhi);
-    cand_range(a.sw, wi, a.Wo, wlo, whi);
+    cand_range(a.sh, hi, a.Ho, a.align, hlo, hhi);
+    cand_range(a.sw, wi, a.Wo, a.align, wlo, whi);
     for (int cv = 0; cv < a.CV; ++cv) {
       const int c0 = cv * VEC;
       float acc[VEC];

@@ -23,7 +23,7 @@ CASES = {
                over=["MODEL.DEEPLABV3_PLUS.USE_ASPP", "False",
                      "MODEL.DEEPLABV3_PLUS.ENABLE_DECODER", "False"]),
     "c5": dict(model="HRNet", backbone="hrnet_w18_small_v1", os=16, aux=False, fn="hrnet_seg",
-               hw=(64, 128), aux_weight=0.4, momentum=0.01,
+               hw=(64, 128), aux_weight=0.4, momentum=0.01, tie_delta=1e-5,
                yaml="configs/cityscapes_hrnet_w18_small_v1.yaml"),
 }
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -56,7 +56,29 @@ def _cfg(tag):
     return cfg
 
 
-def _oracle(tag, sd, x, training, dtype=torch.float32, y=None):
+class _shifted_relu:
+    """Run the oracle with ReLU(x) = x * (x > shift): `shift` = +-delta flips every ReLU whose
+    pre-activation lies within delta of zero — the oracle's own sensitivity to near-ties."""
+
+    def __init__(self, shift):
+        self.shift = shift
+
+    def __enter__(self):
+        import torch.nn.functional as TF
+        self.TF, self.orig = TF, TF.relu
+        if self.shift:
+            TF.relu = lambda t, inplace=False: t * (t > self.shift)
+
+    def __exit__(self, *a):
+        self.TF.relu = self.orig
+
+
+def _oracle(tag, sd, x, training, dtype=torch.float32, y=None, relu_shift=0.0):
+    with _shifted_relu(relu_shift):
+        return _oracle_impl(tag, sd, x, training, dtype, y)
+
+
+def _oracle_impl(tag, sd, x, training, dtype=torch.float32, y=None):
     c = CASES[tag]
     s = {k: (v.to(dtype) if v.is_floating_point() else v.clone()) for k, v in sd.items()}
     s = torch_ref.clone_state(s, requires_grad=training)
@@ -191,7 +213,18 @@ def test_hip_train_fp32_matches_reference(tag):
             ref = torch.from_numpy(t[k])
             assert (msd[k[6:]].cpu() - ref).abs().max().item() <= 1e-3 * ref.abs().max().item() + 1e-6, k
     params = dict(model.named_parameters())
-    nh = nc = den = 0.0
+    # Near-tie ReLUs: a pre-activation within fp32 rounding of zero may land on the other side in
+    # a different (equally valid) fp32 evaluation order; one flip at HRNet's 4x8 / 2x4 branches
+    # moves every upstream gradient by percents (c5, seed 0: stage4 row 2, channel 46 has
+    # pre-activation -7.6e-7 in fp64, -6.9e-6 in the reference's own fp32 run).  The oracle's
+    # sensitivity to flipping ITS near-ties (|x| < delta) bounds what such flips may cost.
+    sens = {k: 0.0 for k in g64}
+    if c.get("tie_delta"):
+        for sh in (c["tie_delta"], -c["tie_delta"]):
+            _, _, gs = _oracle(tag, sd, x, True, torch.float64, y, relu_shift=sh)
+            for k in g64:
+                sens[k] += (gs[k] - g64[k]).norm().item()
+    nh = nc = den = ns = 0.0
     worst = (0.0, "")
     allw = []
     for k, t64 in g64.items():
@@ -199,17 +232,20 @@ def test_hip_train_fp32_matches_reference(tag):
         gh = params[k].grad.detach().cpu().double()
         assert torch.isfinite(gh).all(), k
         eh, ec, n64 = (gh - t64).norm().item(), (g32[k].double() - t64).norm().item(), t64.norm().item()
-        nh, nc, den = nh + eh ** 2, nc + ec ** 2, den + n64 ** 2
+        nh, nc, den, ns = nh + eh ** 2, nc + ec ** 2, den + n64 ** 2, ns + sens[k] ** 2
         bound = 4 * ec + 1e-3 * n64 if n64 > 10 * ec else 20 * ec + 1e-12
+        bound += sens[k]
         worst = max(worst, (eh / max(bound, 1e-30), k))
         allw.append((eh / max(bound, 1e-30), k, eh, ec, n64))
     for w in sorted(allw, reverse=True)[:8]:
         print("   %-50s ratio %.2f err_hip %.3e err_cpu32 %.3e |g64| %.3e" % (w[1], w[0], w[2], w[3], w[4]))
-    if True:
-        pass
+    if os.environ.get("SEG_DEBUG_GRADS"):
+        for w in allw:
+            print("   ALL %-50s ratio %.2f err_hip %.3e |g64| %.3e" % (w[1], w[0], w[2], w[4]))
     print("%s gradients vs fp64 oracle: global rel err HIP %.3e, CPU-fp32 %.3e; worst ratio %.2f (%s)"
           % (tag, (nh / den) ** 0.5, (nc / den) ** 0.5, worst[0], worst[1]))
-    assert (nh / den) ** 0.5 <= 3 * (nc / den) ** 0.5 + 1e-4
+    print("%s near-tie sensitivity of the fp64 oracle (global rel): %.3e" % (tag, (ns / den) ** 0.5))
+    assert (nh / den) ** 0.5 <= 3 * (nc / den) ** 0.5 + 1e-4 + (ns / den) ** 0.5
     # Per tensor: as accurate as the CPU fp32 path (4x its distance to fp64 + 1e-3).  PSPNet's
     # pyramid applies training-mode BatchNorm over only N*o*o = 2..72 pooled samples, which
     # amplifies fp32 rounding in the forward (~8e-5 at the head conv output, every kernel checked
@@ -234,3 +270,71 @@ def test_hip_bf16_runs_and_is_finite(tag):
     loss.backward()
     assert torch.isfinite(loss)
     assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nb", [2, 3, 4])
+def test_hrnet_module_and_head_gradients_tight(nb):
+    """One HighResolutionModule (+ transition-style deferred input + the head's bilinear
+    align_corners=False concat) on random inputs vs the fp64 oracle: forward, input gradients and
+    every parameter gradient to 1e-4 — the whole-model check above can only be as tight as the
+    net's ReLU near-ties allow, this one has none."""
+    import copy
+
+    import torch.nn as nn
+    import torch.nn.functional as TF
+
+    import segmentron_amd
+    from segmentron_amd import functional as F
+    from segmentron_amd.models.backbones import hrnet as HR
+    segmentron_amd.set_compute_dtype(torch.float32)
+    ch = [16, 32, 64, 128][:nb]
+    mod = HR.HighResolutionModule(nb, HR.BasicBlock, [2] * nb, list(ch), list(ch), "SUM", True)
+    sd = synth.synth_like(mod.state_dict(), seed=3)
+    mod.load_state_dict(sd)
+    mod = mod.cuda().train()
+    gen = torch.Generator().manual_seed(11)
+    N, H, W = 2, 16, 32
+    xs = [torch.randn(N, c, H >> i, W >> i, generator=gen) for i, c in enumerate(ch)]
+    gcat = torch.randn(N, sum(ch), H, W, generator=gen)
+    tconv = nn.Conv2d(ch[-2], ch[-1], 3, 2, 1, bias=False)
+    tbn = nn.BatchNorm2d(ch[-1])
+    tconv_o, tbn_o = copy.deepcopy(tconv).double(), copy.deepcopy(tbn).double()
+    tconv, tbn = tconv.cuda(), tbn.cuda()
+    # fp64 oracle
+    osd = torch_ref.clone_state({("m." + k): (v.double() if v.is_floating_point() else v)
+                                 for k, v in sd.items()}, requires_grad=True)
+    net = torch_ref.OracleNet(osd, training=True)
+    xo = [t.double().requires_grad_() for t in xs]
+    xin = list(xo)
+    xin[-1] = torch.relu(tbn_o(tconv_o(xo[-2])))  # like transitionN: conv s2 + BN + ReLU
+    yo = torch_ref._hr_module(net, xin, "m")
+    cat_o = torch.cat([yo[0]] + [TF.interpolate(t, size=(H, W), mode="bilinear", align_corners=False)
+                                 for t in yo[1:]], 1)
+    (cat_o * gcat.double()).sum().backward()
+    # HIP
+    xh = [t.permute(0, 2, 3, 1).contiguous().cuda().requires_grad_() for t in xs]
+    ain = [F.Act(t) for t in xh]
+    a = F.conv_bn(ain[-2], tconv, tbn)
+    a.relu = True
+    ain[-1] = a
+    yh = mod(ain)
+    buf = torch.empty((N, H, W, sum(ch)), device="cuda")
+    parts = [F.materialize(yh[0], out=buf[..., :ch[0]], force=True)]
+    o = ch[0]
+    for a, c in zip(yh[1:], ch[1:]):
+        parts.append(F.bilinear(a, (H, W), align_corners=False, out=buf[..., o:o + c]))
+        o += c
+    cat_h = F.concat_alias(buf, parts)
+
+    def rel(a, b):
+        return ((a.double() - b).norm() / b.norm()).item()
+
+    assert rel(cat_h.detach().cpu().permute(0, 3, 1, 2), cat_o.detach()) < 1e-5
+    (cat_h * gcat.permute(0, 2, 3, 1).contiguous().cuda()).sum().backward()
+    for i in range(nb - 1):
+        assert rel(xh[i].grad.cpu().permute(0, 3, 1, 2), xo[i].grad) < 1e-4, i
+    for k, p in mod.named_parameters():
+        assert rel(p.grad.cpu(), osd["m." + k].grad) < 1e-4, k
+    assert rel(tconv.weight.grad.cpu(), tconv_o.weight.grad) < 1e-4
+    assert rel(tbn.weight.grad.cpu(), tbn_o.weight.grad) < 1e-4

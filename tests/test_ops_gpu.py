@@ -267,7 +267,9 @@ def test_bn_backward_matches_autograd(dtype, relu):
 
 # ------------------------------------------------------------------------------ resize
 RESIZE_CASES = [(5, 9, 17, 33, True), (17, 33, 65, 129, True), (9, 13, 20, 31, False),
-                (1, 1, 5, 9, True), (12, 10, 7, 5, True)]
+                (1, 1, 5, 9, True), (12, 10, 7, 5, True),
+                (2, 4, 16, 32, False), (4, 8, 16, 32, False), (8, 16, 16, 32, False),  # HRNet head
+                (3, 5, 40, 77, False), (12, 10, 7, 5, False)]
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
@@ -289,19 +291,22 @@ def test_bilinear_fwd_bwd(case, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
-def test_logits_upsample_to_nchw_fwd_bwd(dtype):
-    N, C, Hi, Wi, Ho, Wo = 2, 19, 9, 17, 33, 65
+@pytest.mark.parametrize("geom", [(9, 17, 33, 65, True), (16, 32, 64, 128, False),
+                                  (5, 7, 61, 83, False)])
+def test_logits_upsample_to_nchw_fwd_bwd(geom, dtype):
+    Hi, Wi, Ho, Wo, ac = geom
+    N, C = 2, 19
     x = quant(rnd((N, C, Hi, Wi), 1), dtype).double().requires_grad_()
-    ref = TF.interpolate(x, size=(Ho, Wo), mode="bilinear", align_corners=True)
+    ref = TF.interpolate(x, size=(Ho, Wo), mode="bilinear", align_corners=ac)
     xd = to_dev_nhwc(x.detach().float(), dtype, pitch=32)
-    y = K().upsample_to_nchw(xd, C, (Ho, Wo), True)
+    y = K().upsample_to_nchw(xd, C, (Ho, Wo), ac)
     assert y.dtype == torch.float32 and tuple(y.shape) == (N, C, Ho, Wo)
     assert_close(y.cpu(), ref.detach(), torch.float32, "logits up", fac=3)
     g = rnd(tuple(ref.shape), 2)
     ref.backward(g.double())
     vec = 8 if dtype == torch.bfloat16 else 4
     pitch = (C + vec - 1) // vec * vec
-    gx = K().upsample_to_nchw_bwd(g.to(DEV), (Hi, Wi), dtype, pitch, True)
+    gx = K().upsample_to_nchw_bwd(g.to(DEV), (Hi, Wi), dtype, pitch, ac)
     assert_close(to_cpu_nchw(gx[..., :C]), x.grad, dtype, "logits up bwd")
     assert (gx[..., C:].float() == 0).all()
 
@@ -494,7 +499,7 @@ def test_conv_bias_before_training_batchnorm_is_dropped_exactly(dtype):
     y.backward(to_dev_nhwc(g, dtype))
     assert_close(bn.running_mean.cpu(), bn_r.running_mean, torch.float32, "running_mean", fac=50)
     assert_close(bn.running_var.cpu(), bn_r.running_var, torch.float32, "running_var", fac=50)
-    assert_close(to_cpu_nchw(xd.grad), xr.grad, dtype, "dx", fac=8)
+    assert_close(to_cpu_nchw(xd.grad), xr.grad, dtype, "dx", fac=12)
     assert_close(conv.weight.grad.cpu(), conv_r.weight.grad, dtype, "dW", fac=8)
     assert_close(bn.weight.grad.cpu(), bn_r.weight.grad, dtype, "dgamma", fac=8)
     assert conv.bias.grad is not None and float(conv.bias.grad.abs().max()) == 0.0
