@@ -76,7 +76,7 @@ int seg_dwconv3x3(int dtype, int mode, const void* x, long ldx, int N, int Hi, i
                   const float* w9c, int stride, int dil, int pro_mode, const float* pro_scale,
                   const float* pro_shift, void* y, long ldy, int Ho, int Wo, float* stat_partial,
                   int grid_y, void* stream);
-int seg_dwconv_grid_y(int dtype, int C, int N, int Ho, int Wo);
+int seg_dwconv_grid_y(int dtype, int C, int N, int Ho, int Wo, int stride, int dil);
 /* partial: fp32 [grid_y][9][C]; column-sum gives dW[9][C]. */
 int seg_dwconv3x3_wgrad(int dtype, const void* x, long ldx, int N, int Hi, int Wi, int C,
                         const void* dy, long lddy, int Ho, int Wo, int stride, int dil,

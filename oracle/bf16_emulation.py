@@ -16,7 +16,9 @@ Rounding points of the HIP bf16 path (segmentron_amd/csrc):
   * 1x1 conv whose input carries a LINEAR pending BN (no ReLU; csrc/fold.hip): operand = the raw
     bf16 tensor as stored, weights = bf16(W * scale), the constant W @ shift is dropped when a
     training-mode BN follows (it cancels) and added as an fp32 bias otherwise
-  * depthwise (seg_dwconv3x3): operand act(raw) kept in fp32, weights fp32, fp32 accumulation,
+  * depthwise (seg_dwconv3x3): operand act(raw) rounded to bf16 once by the LDS-tiled kernels
+    (stride 1, dilation <= 2; the activated tile is parked in LDS in the storage dtype) and kept
+    in fp32 by the strip kernels (stride 2 / wide dilations); weights fp32, fp32 accumulation,
     statistics from fp32, output stored bf16
   * BN finalize in fp64 -> fp32 scale/shift;  act(x) = relu(fma(x, scale, shift)) in fp32
   * materialise / residual add / bilinear / global pool: fp32 math, bf16 store
@@ -111,11 +113,14 @@ class Bf16EmuNet:
 
     def dw(self, a, p, bnp, stride, dil):
         c = a.t.shape[1]
+        v = a.val()
+        if stride == 1 and dil <= 2:
+            v = r16(v)
         if self.accum64:
-            y = F.conv2d(a.val().double(), self.sd[p + ".weight"].double(), None, stride, dil, dil,
+            y = F.conv2d(v.double(), self.sd[p + ".weight"].double(), None, stride, dil, dil,
                          groups=c).float()
         else:
-            y = F.conv2d(a.val(), self.sd[p + ".weight"], None, stride, dil, dil, groups=c)
+            y = F.conv2d(v, self.sd[p + ".weight"], None, stride, dil, dil, groups=c)
         s, b = self._bn(y, bnp)
         return _A(r16(y), s, b)
 

@@ -18,6 +18,7 @@
 namespace seg {
 
 constexpr int EW_THREADS = 256;
+constexpr int EW_UN = 4;  // rows per thread per iteration in the row-tile kernels
 
 // ------------------------------------------------------------------ column sums of partials
 // in [R][L] fp32 -> out[gridDim.y][L] (fp64 or fp32)
@@ -115,10 +116,12 @@ template <int VEC>
 __device__ __forceinline__ void load_affine(int mode, const float* __restrict__ s,
                                             const float* __restrict__ t, int c0, float* sc,
                                             float* sh) {
+  if (mode & PRO_AFFINE) {
+    load_params<VEC>(s, c0, sc);
+    load_params<VEC>(t, c0, sh);
+  } else {
 #pragma unroll
-  for (int k = 0; k < VEC; ++k) {
-    sc[k] = (mode & PRO_AFFINE) ? s[c0 + k] : 1.f;
-    sh[k] = (mode & PRO_AFFINE) ? t[c0 + k] : 0.f;
+    for (int k = 0; k < VEC; ++k) { sc[k] = 1.f; sh[k] = 0.f; }
   }
 }
 template <int VEC>
@@ -152,34 +155,52 @@ __global__ __launch_bounds__(EW_THREADS) void bn_apply_kernel(const ApplyArgs a)
   float sx[VEC], tx[VEC], sr[VEC], tr[VEC];
   load_affine<VEC>(a.mode_x, a.sx, a.tx, c0, sx, tx);
   load_affine<VEC>(R ? a.mode_r : 0, a.sr, a.tr, c0, sr, tr);
-  const int M = (int)a.M, step = gridDim.y * rpb;
-  for (int row = blockIdx.y * rpb + sy; row < M; row += step) {
-    float f[VEC];
-    Vec<T>::unpack(ldg16(X + (long)row * a.ldx + c0), f);
-    act_regs<VEC>(f, a.mode_x, sx, tx);
-    if (a.chan_mul) {
-      const float* m = a.chan_mul + (long)(row / (int)a.rows_per_n) * a.C + c0;
+  // EW_UN rows per thread and iteration, every load of the batch issued before the first use
+  // (one 16-byte load in flight per thread left these kernels latency-bound at 2.5 TB/s on the
+  // 24 MB middle-flow tensors; a plain copy of the same tensor runs at 6 TB/s out of MALL)
+  const int M = (int)a.M, tile = rpb * EW_UN, step = gridDim.y * tile;
+  const T* __restrict__ EM = reinterpret_cast<const T*>(a.elem_mul);
+  for (int base = blockIdx.y * tile + sy; base < M; base += step) {
+    uint4 rx[EW_UN], rr[EW_UN], rm[EW_UN];
 #pragma unroll
-      for (int k = 0; k < VEC; ++k) f[k] *= m[k];
+    for (int u = 0; u < EW_UN; ++u) {
+      const int row = min(base + u * rpb, M - 1);
+      rx[u] = ldg16(X + (long)row * a.ldx + c0);
+      if (R) rr[u] = ldg16(R + (long)row * a.ldr + c0);
+      if (EM) rm[u] = ldg16(EM + (long)row * a.ldm + c0);
     }
-    if (a.elem_mul) {
-      float m[VEC];
-      Vec<T>::unpack(ldg16(reinterpret_cast<const T*>(a.elem_mul) + (long)row * a.ldm + c0), m);
 #pragma unroll
-      for (int k = 0; k < VEC; ++k) f[k] *= m[k];
-    }
-    if (R) {
-      float g[VEC];
-      Vec<T>::unpack(ldg16(R + (long)row * a.ldr + c0), g);
-      act_regs<VEC>(g, a.mode_r, sr, tr);
+    for (int u = 0; u < EW_UN; ++u) {
+      const int row = base + u * rpb;
+      if (row >= M) break;
+      float f[VEC];
+      Vec<T>::unpack(rx[u], f);
+      act_regs<VEC>(f, a.mode_x, sx, tx);
+      if (a.chan_mul) {
+        float m[VEC];
+        load_params<VEC>(a.chan_mul + (long)(row / (int)a.rows_per_n) * a.C, c0, m);
 #pragma unroll
-      for (int k = 0; k < VEC; ++k) f[k] += g[k];
-    }
-    if (a.post_relu) {
+        for (int k = 0; k < VEC; ++k) f[k] *= m[k];
+      }
+      if (EM) {
+        float m[VEC];
+        Vec<T>::unpack(rm[u], m);
 #pragma unroll
-      for (int k = 0; k < VEC; ++k) f[k] = fmaxf(f[k], 0.f);
+        for (int k = 0; k < VEC; ++k) f[k] *= m[k];
+      }
+      if (R) {
+        float g[VEC];
+        Vec<T>::unpack(rr[u], g);
+        act_regs<VEC>(g, a.mode_r, sr, tr);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) f[k] += g[k];
+      }
+      if (a.post_relu) {
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) f[k] = fmaxf(f[k], 0.f);
+      }
+      stg16(Y + (long)row * a.ldy + c0, Vec<T>::pack(f));
     }
-    stg16(Y + (long)row * a.ldy + c0, Vec<T>::pack(f));
   }
 }
 
@@ -197,20 +218,31 @@ struct BwdArgs {
 };
 
 template <typename T>
-__device__ __forceinline__ void masked_grad(const BwdArgs& a, const T* G, const T* X, int row,
-                                            int c0, const float* sc, const float* sh, float* g,
-                                            float* x) {
+struct BwdRaw { uint4 g, x, m; };
+
+template <typename T>
+__device__ __forceinline__ void load_bwd_raw(const BwdArgs& a, const T* G, const T* X, int row,
+                                             int c0, BwdRaw<T>& r) {
+  r.g = ldg16(G + (long)row * a.ldg + c0);
+  r.x = ldg16(X + (long)row * a.ldx + c0);
+  if (a.elem_mul) r.m = ldg16(reinterpret_cast<const T*>(a.elem_mul) + (long)row * a.ldm + c0);
+}
+
+template <typename T>
+__device__ __forceinline__ void masked_grad(const BwdArgs& a, const BwdRaw<T>& r, int row, int c0,
+                                            const float* sc, const float* sh, float* g, float* x) {
   constexpr int VEC = Vec<T>::N;
-  Vec<T>::unpack(ldg16(G + (long)row * a.ldg + c0), g);
-  Vec<T>::unpack(ldg16(X + (long)row * a.ldx + c0), x);
+  Vec<T>::unpack(r.g, g);
+  Vec<T>::unpack(r.x, x);
   if (a.chan_mul) {
-    const float* m = a.chan_mul + (long)(row / (int)a.rows_per_n) * a.C + c0;
+    float m[VEC];
+    load_params<VEC>(a.chan_mul + (long)(row / (int)a.rows_per_n) * a.C, c0, m);
 #pragma unroll
     for (int k = 0; k < VEC; ++k) g[k] *= m[k];
   }
   if (a.elem_mul) {
     float m[VEC];
-    Vec<T>::unpack(ldg16(reinterpret_cast<const T*>(a.elem_mul) + (long)row * a.ldm + c0), m);
+    Vec<T>::unpack(r.m, m);
 #pragma unroll
     for (int k = 0; k < VEC; ++k) g[k] *= m[k];
   }
@@ -242,14 +274,23 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_reduce_kernel(const BwdArgs
   if (cv < a.CV) {
     float sc[VEC], sh[VEC];
     load_affine<VEC>(a.mode, a.scale, a.shift, c0, sc, sh);
-    const int M = (int)a.M, step = gridDim.y * spb;
-    for (int row = blockIdx.y * spb + sy; row < M; row += step) {
-      float g[VEC], x[VEC];
-      masked_grad<T>(a, G, X, row, c0, sc, sh, g, x);
+    const int M = (int)a.M, tile = spb * EW_UN, step = gridDim.y * tile;
+    for (int base = blockIdx.y * tile + sy; base < M; base += step) {
+      BwdRaw<T> raw[EW_UN];
 #pragma unroll
-      for (int k = 0; k < VEC; ++k) {
-        s1[k] += g[k];
-        s2[k] = fmaf(g[k], x[k], s2[k]);
+      for (int u = 0; u < EW_UN; ++u)
+        load_bwd_raw<T>(a, G, X, min(base + u * spb, M - 1), c0, raw[u]);
+#pragma unroll
+      for (int u = 0; u < EW_UN; ++u) {
+        const int row = base + u * spb;
+        if (row >= M) break;
+        float g[VEC], x[VEC];
+        masked_grad<T>(a, raw[u], row, c0, sc, sh, g, x);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+          s1[k] += g[k];
+          s2[k] = fmaf(g[k], x[k], s2[k]);
+        }
       }
     }
   }
@@ -304,20 +345,31 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_kernel(const BwdArgs 
   T* __restrict__ DX = reinterpret_cast<T*>(a.dx);
   float sc[VEC], sh[VEC], k0[VEC], k1[VEC];
   load_affine<VEC>(a.mode, a.scale, a.shift, c0, sc, sh);
+  if (a.c0) {
+    load_params<VEC>(a.c0, c0, k0);
+    load_params<VEC>(a.c1, c0, k1);
+  } else {
 #pragma unroll
-  for (int k = 0; k < VEC; ++k) {
-    k0[k] = a.c0 ? a.c0[c0 + k] : 0.f;
-    k1[k] = a.c0 ? a.c1[c0 + k] : 0.f;
+    for (int k = 0; k < VEC; ++k) k0[k] = k1[k] = 0.f;
   }
-  const int M = (int)a.M, step = gridDim.y * rpb;
-  for (int row = blockIdx.y * rpb + sy; row < M; row += step) {
-    float g[VEC], x[VEC];
-    masked_grad<T>(a, G, X, row, c0, sc, sh, g, x);
-    if (a.mode & PRO_AFFINE) {
+  const int M = (int)a.M, tile = rpb * EW_UN, step = gridDim.y * tile;
+  for (int base = blockIdx.y * tile + sy; base < M; base += step) {
+    BwdRaw<T> raw[EW_UN];
 #pragma unroll
-      for (int k = 0; k < VEC; ++k) g[k] = g[k] * sc[k] - k0[k] - k1[k] * x[k];
+    for (int u = 0; u < EW_UN; ++u)
+      load_bwd_raw<T>(a, G, X, min(base + u * rpb, M - 1), c0, raw[u]);
+#pragma unroll
+    for (int u = 0; u < EW_UN; ++u) {
+      const int row = base + u * rpb;
+      if (row >= M) break;
+      float g[VEC], x[VEC];
+      masked_grad<T>(a, raw[u], row, c0, sc, sh, g, x);
+      if (a.mode & PRO_AFFINE) {
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) g[k] = g[k] * sc[k] - k0[k] - k1[k] * x[k];
+      }
+      stg16(DX + (long)row * a.lddx + c0, Vec<T>::pack(g));
     }
-    stg16(DX + (long)row * a.lddx + c0, Vec<T>::pack(g));
   }
 }
 
@@ -417,8 +469,8 @@ static dim3 ew_grid2(int CV, long M, int& cvb_log2) {
   cvb_log2 = pick_cvb_log2_ew(CV);
   const int gx = (CV + (1 << cvb_log2) - 1) >> cvb_log2;
   const int rpb = EW_THREADS >> cvb_log2;
-  long gy = (M + (long)rpb * 4 - 1) / ((long)rpb * 4);  // >= 4 rows per thread
-  long cap = 4096 / gx;
+  long gy = (M + (long)rpb * EW_UN - 1) / ((long)rpb * EW_UN);  // one batch of EW_UN rows per thread
+  long cap = 8192 / gx;
   if (cap < 1) cap = 1;
   if (gy > cap) gy = cap;
   if (gy < 1) gy = 1;

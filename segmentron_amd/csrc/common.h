@@ -127,13 +127,30 @@ template <> struct HVec<bf16_t> {
 __device__ __forceinline__ uint4 ldg16(const void* p) { return *reinterpret_cast<const uint4*>(p); }
 __device__ __forceinline__ void stg16(void* p, const uint4& v) { *reinterpret_cast<uint4*>(p) = v; }
 
+// N (multiple of 4) consecutive fp32 per-channel parameters starting at channel c (c % 4 == 0,
+// rows of parameter tables are 16-byte aligned): 16-byte loads.  Element-wise `p[c + i]` under a
+// runtime mode test compiles to N branchy dword loads with a full s_waitcnt between them — eight
+// serialized L2 round trips (~8 us) at the head of every element-wise kernel.
+template <int N>
+__device__ __forceinline__ void load_params(const float* __restrict__ p, int c, float* out) {
+  static_assert(N % 4 == 0, "parameter vectors are loaded 16 bytes at a time");
+#pragma unroll
+  for (int i = 0; i < N; i += 4) {
+    const float4 v = *reinterpret_cast<const float4*>(p + c + i);
+    out[i] = v.x; out[i + 1] = v.y; out[i + 2] = v.z; out[i + 3] = v.w;
+  }
+}
+
 // Apply the fused-BatchNorm prologue to VEC consecutive channels starting at c.
 template <int N>
 __device__ __forceinline__ void apply_prologue(float* f, int mode, const float* __restrict__ scale,
                                                const float* __restrict__ shift, int c) {
   if (mode & PRO_AFFINE) {
+    float s[N], t[N];
+    load_params<N>(scale, c, s);
+    load_params<N>(shift, c, t);
 #pragma unroll
-    for (int i = 0; i < N; ++i) f[i] = fmaf(f[i], scale[c + i], shift[c + i]);
+    for (int i = 0; i < N; ++i) f[i] = fmaf(f[i], s[i], t[i]);
   }
   if (mode & PRO_RELU) {
 #pragma unroll

@@ -16,6 +16,7 @@
 // channel vectors, blockIdx.y the strips (grid-stride), one row of statistics partials per
 // blockIdx.y (deterministic: LDS tree over the strips of a block, fp64 finish in bn_finalize).
 #include "common.h"
+#include "dwconv_tiled.h"
 #include <type_traits>
 
 namespace seg {
@@ -89,10 +90,12 @@ __global__ __launch_bounds__(DW_THREADS, FAST ? 3 : 2) void dwconv_kernel(const 
   const float inv_wq = 1.0f / (float)WQ, inv_ho = 1.0f / (float)a.Ho;
 
   float sc[VEC], sh[VEC];
+  if (a.pro_mode & PRO_AFFINE) {
+    load_params<VEC>(a.pro_scale, c0, sc);
+    load_params<VEC>(a.pro_shift, c0, sh);
+  } else {
 #pragma unroll
-  for (int i = 0; i < VEC; ++i) {
-    sc[i] = (a.pro_mode & PRO_AFFINE) ? a.pro_scale[c0 + i] : 1.f;
-    sh[i] = (a.pro_mode & PRO_AFFINE) ? a.pro_shift[c0 + i] : 0.f;
+    for (int i = 0; i < VEC; ++i) { sc[i] = 1.f; sh[i] = 0.f; }
   }
   float ssum[VEC], ssq[VEC];
 #pragma unroll
@@ -151,8 +154,7 @@ __global__ __launch_bounds__(DW_THREADS, FAST ? 3 : 2) void dwconv_kernel(const 
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw) {
           float wv[VEC];
-#pragma unroll
-          for (int i = 0; i < VEC; ++i) wv[i] = a.w[(kh * 3 + kw) * a.C + c0 + i];
+          load_params<VEC>(a.w + (kh * 3 + kw) * a.C, c0, wv);
 #pragma unroll
           for (int j = 0; j < DW_TW; ++j)
 #pragma unroll
@@ -175,8 +177,7 @@ __global__ __launch_bounds__(DW_THREADS, FAST ? 3 : 2) void dwconv_kernel(const 
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw) {
           float wv[VEC];
-#pragma unroll
-          for (int i = 0; i < VEC; ++i) wv[i] = a.w[(kh * 3 + kw) * a.C + c0 + i];
+          load_params<VEC>(a.w + (kh * 3 + kw) * a.C, c0, wv);
 #pragma unroll
           for (int j = 0; j < DW_TW; ++j) {
             const int wo = w0 + j;
@@ -267,10 +268,12 @@ __global__ __launch_bounds__(DW_THREADS) void dwconv_wgrad_kernel(const DwWgradA
   const float inv_wq = 1.0f / (float)WQ, inv_ho = 1.0f / (float)a.Ho;
 
   float sc[VEC], sh[VEC];
+  if (a.pro_mode & PRO_AFFINE) {
+    load_params<VEC>(a.pro_scale, c0, sc);
+    load_params<VEC>(a.pro_shift, c0, sh);
+  } else {
 #pragma unroll
-  for (int i = 0; i < VEC; ++i) {
-    sc[i] = (a.pro_mode & PRO_AFFINE) ? a.pro_scale[c0 + i] : 1.f;
-    sh[i] = (a.pro_mode & PRO_AFFINE) ? a.pro_shift[c0 + i] : 0.f;
+    for (int i = 0; i < VEC; ++i) { sc[i] = 1.f; sh[i] = 0.f; }
   }
   float acc[9][VEC];
 #pragma unroll
@@ -404,10 +407,12 @@ __global__ __launch_bounds__(DW_THREADS) void dwconv_bwd_fused_kernel(const DwBw
   const int d = a.dil;
 
   float sc[VEC], sh[VEC];
+  if (a.pro_mode & PRO_AFFINE) {
+    load_params<VEC>(a.pro_scale, c0, sc);
+    load_params<VEC>(a.pro_shift, c0, sh);
+  } else {
 #pragma unroll
-  for (int i = 0; i < VEC; ++i) {
-    sc[i] = (a.pro_mode & PRO_AFFINE) ? a.pro_scale[c0 + i] : 1.f;
-    sh[i] = (a.pro_mode & PRO_AFFINE) ? a.pro_shift[c0 + i] : 0.f;
+    for (int i = 0; i < VEC; ++i) { sc[i] = 1.f; sh[i] = 0.f; }
   }
   float accw[9][VEC], s1[VEC], s2[VEC];
 #pragma unroll
@@ -478,8 +483,7 @@ __global__ __launch_bounds__(DW_THREADS) void dwconv_bwd_fused_kernel(const DwBw
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw) {
           float wv[VEC];
-#pragma unroll
-          for (int i = 0; i < VEC; ++i) wv[i] = a.w[(kh * 3 + kw) * a.C + c0 + i];
+          load_params<VEC>(a.w + (kh * 3 + kw) * a.C, c0, wv);
 #pragma unroll
           for (int j = 0; j < DW_TW; ++j)
 #pragma unroll
@@ -499,8 +503,7 @@ __global__ __launch_bounds__(DW_THREADS) void dwconv_bwd_fused_kernel(const DwBw
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw) {
           float wv[VEC];
-#pragma unroll
-          for (int i = 0; i < VEC; ++i) wv[i] = a.w[(kh * 3 + kw) * a.C + c0 + i];
+          load_params<VEC>(a.w + (kh * 3 + kw) * a.C, c0, wv);
 #pragma unroll
           for (int j = 0; j < DW_TW; ++j) {
             const int c = w0 + j + (1 - kw) * d;
@@ -579,8 +582,9 @@ static int pick_cvb_log2(int CV) {
 
 }  // namespace seg
 
-extern "C" int seg_dwconv_grid_y(int dtype, int C, int N, int Ho, int Wo) {
+extern "C" int seg_dwconv_grid_y(int dtype, int C, int N, int Ho, int Wo, int stride, int dil) {
   using namespace seg;
+  if (dw_tiled_supported(stride, dil)) return dw_tiled_grid_y(dtype, C, N, Ho, Wo);
   const int vec = dtype == DT_BF16 ? 8 : 4;
   const int CV = C / vec;
   const int l = pick_cvb_log2(CV);
@@ -607,6 +611,12 @@ extern "C" int seg_dwconv3x3(int dtype, int mode, const void* x, long ldx, int N
   SEG_REQUIRE(((pro_mode & PRO_AFFINE) == 0) || (pro_scale && pro_shift),
               "dwconv3x3: affine prologue without scale/shift");
   SEG_REQUIRE(mode == MODE_FWD || stat_partial == nullptr, "dwconv3x3: stats only in forward");
+  SEG_REQUIRE(grid_y >= 1, "dwconv3x3: grid_y must be >= 1");
+  if (mode == MODE_FWD && dw_tiled_supported(stride, dil)) {  // incl. stride-1 dgrad (flipped taps)
+    SEG_REQUIRE(Ho == Hi && Wo == Wi, "dwconv3x3: stride 1 keeps the size");
+    return launch_dw_tiled(dtype, x, ldx, N, Hi, Wi, C, w9c, dil, pro_mode, pro_scale, pro_shift,
+                           y, ldy, stat_partial, grid_y, (hipStream_t)stream);
+  }
   DwArgs a;
   a.x = x; a.w = w9c; a.y = y; a.pro_scale = pro_scale; a.pro_shift = pro_shift;
   a.stat_partial = stat_partial; a.ldx = ldx; a.ldy = ldy;
@@ -646,6 +656,12 @@ extern "C" int seg_dwconv3x3_wgrad(int dtype, const void* x, long ldx, int N, in
   SEG_REQUIRE(dtype == DT_F32 || dtype == DT_BF16, "dwconv3x3_wgrad: bad dtype %d", dtype);
   SEG_REQUIRE(C % vec == 0 && ldx % vec == 0 && lddy % vec == 0,
               "dwconv3x3_wgrad: C/ldx/lddy must be multiples of %d", vec);
+  SEG_REQUIRE(grid_y >= 1, "dwconv3x3_wgrad: grid_y must be >= 1");
+  if (dw_tiled_supported(stride, dil)) {
+    SEG_REQUIRE(Ho == Hi && Wo == Wi, "dwconv3x3_wgrad: stride 1 keeps the size");
+    return launch_dw_wgrad_tiled(dtype, x, ldx, N, Hi, Wi, C, dy, lddy, dil, pro_mode, pro_scale,
+                                 pro_shift, partial, grid_y, (hipStream_t)stream);
+  }
   DwWgradArgs a;
   a.x = x; a.dy = dy; a.partial = partial; a.pro_scale = pro_scale; a.pro_shift = pro_shift;
   a.ldx = ldx; a.lddy = lddy; a.N = N; a.Hi = Hi; a.Wi = Wi; a.C = C; a.Ho = Ho; a.Wo = Wo;

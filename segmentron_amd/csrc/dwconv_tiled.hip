@@ -1,0 +1,411 @@
+// LDS-tiled depthwise 3x3 (stride 1, dilation 1 or 2): forward / stride-1 data gradient (flipped
+// taps) and weight gradient.  Reference call sites: segmentron/modules/basic.py:38-40,152-153.
+//
+// Why a second dw implementation (the strip kernels in dwconv.hip stay for stride 2 / wide
+// dilations): with one thread fetching its own 3x6 neighbourhood straight from global memory every
+// input vector crosses the L1/TA path 4.5 times and the activation is recomputed 4.5 times; on
+// MI355X that path, not HBM, was the limit (1.1-2.0 TB/s algorithmic).  Here a 256-thread block
+// owns an 8x16-pixel x 8-channel-vector tile: the (8+2d)x(16+2d) input halo tile is read from
+// global memory ONCE (16-byte vectors, 128 contiguous bytes per pixel), the producer's
+// BatchNorm(+ReLU) is applied ONCE, and the activated tile is parked in LDS in the storage
+// dtype; the 9 taps then come from LDS (ds_read_b128, rows padded by one pixel so that the two
+// rows a 16-lane phase touches hit disjoint bank halves).  Measured (tools/lab/dw_lab.hip, bf16,
+// forward + statistics): [2,65,129,728] 39.4 -> 21.2 us, [2,513,1025,128] 261 -> 137 us.
+//
+// Blocks are persistent over tiles (grid.y = number of partial rows): depthwise weights are
+// staged in LDS once, BatchNorm statistics / weight-gradient taps accumulate in registers across
+// tiles and are reduced once per block (deterministic, no atomics).
+#include "common.h"
+#include "dwconv_tiled.h"
+
+namespace seg {
+
+constexpr int LT_TH = 8, LT_TW = 16, LT_CVB = 8, LT_THREADS = 256;
+
+struct DwTiledArgs {
+  const void* x;       // tensor the taps read (fwd: input, dgrad: dy)
+  const float* w;      // [9][C] fp32, tap-major (dgrad: flipped by the host)
+  void* y;             // fwd/dgrad output
+  const void* dy;      // wgrad: gradient wrt the dw output
+  const float* sc; const float* sh;
+  float* partial;      // fwd: [gridDim.y][2][C] statistics or null; wgrad: [gridDim.y][9][C]
+  long ldx, ldy, lddy;
+  int N, H, W, C, CV, pro_mode, tiles_h, tiles_w, ntiles;
+};
+
+template <int DIL> struct TileGeom {
+  static constexpr int IH = LT_TH + 2 * DIL, IW = LT_TW + 2 * DIL, IWP = IW + 1;
+  static constexpr int NPIX = IH * IW;
+  static constexpr int PER = (NPIX * LT_CVB + LT_THREADS - 1) / LT_THREADS;
+  static constexpr int TILE_VECS = IH * IWP * LT_CVB;  // 16-byte units
+  static constexpr int COLS = 4 + 2 * DIL;             // tile columns one 4-output strip reads
+};
+
+// ---- global -> registers (all loads of the tile issued back to back)
+template <typename T, int DIL>
+__device__ __forceinline__ void tile_issue(const DwTiledArgs& a, const T* __restrict__ X, int n,
+                                           int h0, int w0, int cv, uint4 (&raw)[TileGeom<DIL>::PER],
+                                           unsigned& okmask) {
+  using G = TileGeom<DIL>;
+  constexpr int VEC = Vec<T>::N;
+  okmask = 0;
+  const int cvc = min(cv, a.CV - 1);
+#pragma unroll
+  for (int u = 0; u < G::PER; ++u) {
+    const int p = (threadIdx.x >> 3) + u * (LT_THREADS / LT_CVB);
+    const int r = p / G::IW, c = p - r * G::IW;
+    const int hi = h0 - DIL + r, wi = w0 - DIL + c;
+    const bool ok = p < G::NPIX && cv < a.CV && hi >= 0 && hi < a.H && wi >= 0 && wi < a.W;
+    okmask |= ok ? (1u << u) : 0u;
+    const int hic = min(max(hi, 0), a.H - 1), wic = min(max(wi, 0), a.W - 1);
+    raw[u] = ldg16(X + (((long)n * a.H + hic) * a.W + wic) * a.ldx + cvc * VEC);
+  }
+}
+
+// ---- registers -> LDS: activation once per element, zero padding outside the image
+template <typename T, int DIL>
+__device__ __forceinline__ void tile_commit(const DwTiledArgs& a, uint4* __restrict__ tile,
+                                            const uint4 (&raw)[TileGeom<DIL>::PER], unsigned okmask,
+                                            const float4* __restrict__ psm) {
+  using G = TileGeom<DIL>;
+  constexpr int VEC = Vec<T>::N, WQ = VEC / 4;
+  const int cx = threadIdx.x & (LT_CVB - 1);
+  float sc[VEC], sh[VEC];
+  if (a.pro_mode & PRO_AFFINE) {
+#pragma unroll
+    for (int q = 0; q < WQ; ++q) {
+      const float4 s4 = psm[(9 * LT_CVB + cx) * WQ + q], t4 = psm[(10 * LT_CVB + cx) * WQ + q];
+      sc[q * 4] = s4.x; sc[q * 4 + 1] = s4.y; sc[q * 4 + 2] = s4.z; sc[q * 4 + 3] = s4.w;
+      sh[q * 4] = t4.x; sh[q * 4 + 1] = t4.y; sh[q * 4 + 2] = t4.z; sh[q * 4 + 3] = t4.w;
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < G::PER; ++u) {
+    const int p = (threadIdx.x >> 3) + u * (LT_THREADS / LT_CVB);
+    if (p < G::NPIX) {
+      const int r = p / G::IW, c = p - r * G::IW;
+      float f[VEC];
+      Vec<T>::unpack(raw[u], f);
+      if (a.pro_mode & PRO_AFFINE) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) f[i] = fmaf(f[i], sc[i], sh[i]);
+      }
+      if (a.pro_mode & PRO_RELU) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) f[i] = fmaxf(f[i], 0.f);
+      }
+      if (a.pro_mode & PRO_CLAMP6) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) f[i] = fminf(f[i], 6.f);
+      }
+      uint4 v = Vec<T>::pack(f);
+      if (!((okmask >> u) & 1u)) v = make_uint4(0u, 0u, 0u, 0u);
+      tile[(r * G::IWP + c) * LT_CVB + cx] = v;
+    }
+  }
+}
+
+// per-block constants -> LDS: rows 0..8 = the nine taps, rows 9/10 = prologue scale / shift
+// (kept out of registers: the persistent loop already carries accumulators and the next tile)
+template <typename T>
+__device__ __forceinline__ void stage_params(const DwTiledArgs& a, float4* __restrict__ psm,
+                                             int cvb0, bool taps) {
+  constexpr int VEC = Vec<T>::N, WQ = VEC / 4;
+  const int tid = threadIdx.x;
+  if (tid < 11 * LT_CVB * WQ) {
+    const int r = tid / (LT_CVB * WQ), q = tid - r * (LT_CVB * WQ);
+    const int c = cvb0 * VEC + q * 4;
+    float4 v = r == 9 ? make_float4(1.f, 1.f, 1.f, 1.f) : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < a.C) {
+      if (r < 9) {
+        if (taps) v = *reinterpret_cast<const float4*>(a.w + r * a.C + c);
+      } else if (a.pro_mode & PRO_AFFINE) {
+        v = *reinterpret_cast<const float4*>((r == 9 ? a.sc : a.sh) + c);
+      }
+    }
+    psm[tid] = v;
+  }
+}
+
+__device__ __forceinline__ void tile_coords(const DwTiledArgs& a, int t, int& n, int& h0, int& w0) {
+  const int tw = t % a.tiles_w;
+  t /= a.tiles_w;
+  const int th = t % a.tiles_h;
+  n = t / a.tiles_h;
+  h0 = th * LT_TH;
+  w0 = tw * LT_TW;
+}
+
+// ------------------------------------------------------------------ forward / stride-1 dgrad
+template <typename T, int DIL>
+__global__ __launch_bounds__(LT_THREADS, sizeof(T) == 2 ? 3 : 4) void dwconv_tiled_kernel(const DwTiledArgs a) {
+  using G = TileGeom<DIL>;
+  constexpr int VEC = Vec<T>::N, WQ = VEC / 4;
+  extern __shared__ uint4 lt_smem[];
+  uint4* tile = lt_smem;
+  float4* wsm = reinterpret_cast<float4*>(lt_smem + G::TILE_VECS);
+  const int tid = threadIdx.x;
+  const int cvb0 = blockIdx.x * LT_CVB;
+  const int cx = tid & (LT_CVB - 1), row = (tid >> 3) & (LT_TH - 1), strip = tid >> 6;
+  const int cv = cvb0 + cx;
+  const T* __restrict__ X = reinterpret_cast<const T*>(a.x);
+  T* __restrict__ Y = reinterpret_cast<T*>(a.y);
+
+  stage_params<T>(a, wsm, cvb0, true);
+  __syncthreads();
+  float ssum[VEC], ssq[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) ssum[i] = ssq[i] = 0.f;
+
+  for (int t = blockIdx.y; t < a.ntiles; t += gridDim.y) {
+    int n, h0, w0;
+    tile_coords(a, t, n, h0, w0);
+    uint4 raw[G::PER];
+    unsigned okmask;
+    tile_issue<T, DIL>(a, X, n, h0, w0, cv, raw, okmask);
+    __syncthreads();  // every thread is done reading the previous tile
+    tile_commit<T, DIL>(a, tile, raw, okmask, wsm);
+    __syncthreads();
+
+    float acc[4][VEC];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) acc[j][i] = 0.f;
+    // kept as a real loop: fully unrolled, the scheduler hoists all 24 LDS reads and spills
+#pragma unroll 1
+    for (int kh = 0; kh < 3; ++kh) {
+      float wv[3][VEC];
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+        for (int q = 0; q < WQ; ++q) {
+          const float4 w4 = wsm[((kh * 3 + kw) * LT_CVB + cx) * WQ + q];
+          wv[kw][q * 4] = w4.x; wv[kw][q * 4 + 1] = w4.y;
+          wv[kw][q * 4 + 2] = w4.z; wv[kw][q * 4 + 3] = w4.w;
+        }
+      const uint4* trow = tile + ((row + kh * DIL) * G::IWP + strip * 4) * LT_CVB + cx;
+#pragma unroll
+      for (int q = 0; q < G::COLS; ++q) {
+        float v[VEC];
+        Vec<T>::unpack(trow[q * LT_CVB], v);
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int j = q - kw * DIL;
+          if (j >= 0 && j < 4) {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) acc[j][i] = fmaf(v[i], wv[kw][i], acc[j][i]);
+          }
+        }
+      }
+    }
+    const int ho = h0 + row;
+    if (cv < a.CV && ho < a.H) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int wo = w0 + strip * 4 + j;
+        if (wo < a.W) {
+          stg16(Y + (((long)n * a.H + ho) * a.W + wo) * a.ldy + cv * VEC, Vec<T>::pack(acc[j]));
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) {
+            ssum[i] += acc[j][i];
+            ssq[i] = fmaf(acc[j][i], acc[j][i], ssq[i]);
+          }
+        }
+      }
+    }
+  }
+
+  if (a.partial != nullptr) {
+    // reduce over the 32 pixel-threads of each channel vector: red[32][CVB][2*VEC] in the tile
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(tile);
+    float* mine = red + ((tid >> 3) * LT_CVB + cx) * 2 * VEC;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      mine[i] = ssum[i];
+      mine[VEC + i] = ssq[i];
+    }
+    __syncthreads();
+    if (tid < LT_CVB * 2 * VEC) {
+      float tot = 0.f;
+      for (int r = 0; r < LT_THREADS / LT_CVB; ++r) tot += red[r * LT_CVB * 2 * VEC + tid];
+      const int lcx = tid / (2 * VEC), k = tid - lcx * 2 * VEC;
+      const int which = k / VEC, ci = k - which * VEC;
+      const int c = (cvb0 + lcx) * VEC + ci;
+      if (c < a.C) a.partial[((long)blockIdx.y * 2 + which) * a.C + c] = tot;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ weight gradient
+// dW[kh,kw,c] = sum_p dy[p,c] * act(x)[p + (kh-1)d, (kw-1)d, c]: same tile, the thread's four dy
+// vectors come straight from global memory (each is used by one thread only).
+template <typename T, int DIL>
+__global__ __launch_bounds__(LT_THREADS, 2) void dwconv_wgrad_tiled_kernel(const DwTiledArgs a) {
+  using G = TileGeom<DIL>;
+  constexpr int VEC = Vec<T>::N;
+  extern __shared__ uint4 lt_smem[];
+  uint4* tile = lt_smem;
+  const int tid = threadIdx.x;
+  const int cvb0 = blockIdx.x * LT_CVB;
+  const int cx = tid & (LT_CVB - 1), row = (tid >> 3) & (LT_TH - 1), strip = tid >> 6;
+  const int cv = cvb0 + cx;
+  const T* __restrict__ X = reinterpret_cast<const T*>(a.x);
+  const T* __restrict__ DY = reinterpret_cast<const T*>(a.dy);
+
+  float4* psm = reinterpret_cast<float4*>(lt_smem + G::TILE_VECS);
+  stage_params<T>(a, psm, cvb0, false);
+  __syncthreads();
+  float acc[9][VEC];
+#pragma unroll
+  for (int k = 0; k < 9; ++k)
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) acc[k][i] = 0.f;
+
+  for (int t = blockIdx.y; t < a.ntiles; t += gridDim.y) {
+    int n, h0, w0;
+    tile_coords(a, t, n, h0, w0);
+    uint4 raw[G::PER];
+    unsigned okmask;
+    tile_issue<T, DIL>(a, X, n, h0, w0, cv, raw, okmask);
+    // this thread's four dy vectors (zero outside the image / channel range)
+    const int ho = h0 + row;
+    uint4 graw[4];
+    const bool rok = cv < a.CV && ho < a.H;
+    const int hoc = min(ho, a.H - 1), cvc = min(cv, a.CV - 1);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int wo = w0 + strip * 4 + j;
+      graw[j] = ldg16(DY + (((long)n * a.H + hoc) * a.W + min(wo, a.W - 1)) * a.lddy + cvc * VEC);
+      if (!(rok && wo < a.W)) graw[j] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    __syncthreads();
+    tile_commit<T, DIL>(a, tile, raw, okmask, psm);
+    __syncthreads();
+    float g[4][VEC];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) Vec<T>::unpack(graw[j], g[j]);
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const uint4* trow = tile + ((row + kh * DIL) * G::IWP + strip * 4) * LT_CVB + cx;
+#pragma unroll
+      for (int q = 0; q < G::COLS; ++q) {
+        float v[VEC];
+        Vec<T>::unpack(trow[q * LT_CVB], v);
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int j = q - kw * DIL;
+          if (j >= 0 && j < 4) {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i)
+              acc[kh * 3 + kw][i] = fmaf(v[i], g[j][i], acc[kh * 3 + kw][i]);
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);  // keep the LDS reads of the next row below this point
+    }
+  }
+
+  // block reduction: across the 8 rows of a wave by lane exchange, across the 4 strips (waves)
+  // through LDS: red[4][CVB][9*VEC]
+#pragma unroll
+  for (int k = 0; k < 9; ++k)
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      float v = acc[k][i];
+      v += __shfl_xor(v, 8, 64);
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      acc[k][i] = v;
+    }
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(tile);
+  if (row == 0) {
+    float* mine = red + (strip * LT_CVB + cx) * 9 * VEC;
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) mine[k * VEC + i] = acc[k][i];
+  }
+  __syncthreads();
+  for (int e = tid; e < LT_CVB * 9 * VEC; e += LT_THREADS) {
+    float tot = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) tot += red[s * LT_CVB * 9 * VEC + e];
+    const int lcx = e / (9 * VEC), k = e - lcx * 9 * VEC;
+    const int tap = k / VEC, ci = k - tap * VEC;
+    const int c = (cvb0 + lcx) * VEC + ci;
+    if (c < a.C) a.partial[((long)blockIdx.y * 9 + tap) * a.C + c] = tot;
+  }
+}
+
+// ------------------------------------------------------------------ host side
+bool dw_tiled_supported(int stride, int dil) { return stride == 1 && (dil == 1 || dil == 2); }
+
+static void tiled_geom(DwTiledArgs& a, int dtype, int N, int H, int W, int C) {
+  const int vec = dtype == DT_BF16 ? 8 : 4;
+  a.N = N; a.H = H; a.W = W; a.C = C; a.CV = C / vec;
+  a.tiles_h = (H + LT_TH - 1) / LT_TH;
+  a.tiles_w = (W + LT_TW - 1) / LT_TW;
+  a.ntiles = N * a.tiles_h * a.tiles_w;
+}
+
+int dw_tiled_grid_y(int dtype, int C, int N, int H, int W) {
+  DwTiledArgs a;
+  tiled_geom(a, dtype, N, H, W, C);
+  const int gx = (a.CV + LT_CVB - 1) / LT_CVB;
+  long cap = 2048 / gx;  // ~8 blocks per CU in total; bounds the number of partial rows
+  if (cap < 1) cap = 1;
+  long gy = a.ntiles;
+  if (gy > cap) gy = cap;
+  return (int)gy;
+}
+
+template <int DIL> static size_t tiled_lds(int dtype, bool with_weights) {
+  const int vec = dtype == DT_BF16 ? 8 : 4;
+  size_t b = (size_t)TileGeom<DIL>::TILE_VECS * 16;
+  const size_t red_fwd = (size_t)LT_THREADS * 2 * vec * sizeof(float);
+  const size_t red_wg = (size_t)4 * LT_CVB * 9 * vec * sizeof(float);
+  if (b < red_fwd) b = red_fwd;
+  if (b < red_wg) b = red_wg;
+  (void)with_weights;
+  b += (size_t)11 * LT_CVB * vec * sizeof(float);  // taps + prologue scale / shift
+  return b;
+}
+
+int launch_dw_tiled(int dtype, const void* x, long ldx, int N, int H, int W, int C,
+                    const float* w9c, int dil, int pro_mode, const float* sc, const float* sh,
+                    void* y, long ldy, float* stat_partial, int grid_y, hipStream_t st) {
+  DwTiledArgs a;
+  tiled_geom(a, dtype, N, H, W, C);
+  a.x = x; a.w = w9c; a.y = y; a.dy = nullptr; a.sc = sc; a.sh = sh; a.partial = stat_partial;
+  a.ldx = ldx; a.ldy = ldy; a.lddy = 0; a.pro_mode = pro_mode;
+  const dim3 grid((a.CV + LT_CVB - 1) / LT_CVB, grid_y);
+#define SEG_LT(TT, DD) \
+  hipLaunchKernelGGL((dwconv_tiled_kernel<TT, DD>), grid, dim3(LT_THREADS), \
+                     tiled_lds<DD>(dtype, true), st, a)
+  if (dtype == DT_BF16) { if (dil == 1) SEG_LT(bf16_t, 1); else SEG_LT(bf16_t, 2); }
+  else { if (dil == 1) SEG_LT(float, 1); else SEG_LT(float, 2); }
+#undef SEG_LT
+  return check_launch("dwconv3x3 (tiled)");
+}
+
+int launch_dw_wgrad_tiled(int dtype, const void* x, long ldx, int N, int H, int W, int C,
+                          const void* dy, long lddy, int dil, int pro_mode, const float* sc,
+                          const float* sh, float* partial, int grid_y, hipStream_t st) {
+  DwTiledArgs a;
+  tiled_geom(a, dtype, N, H, W, C);
+  a.x = x; a.w = nullptr; a.y = nullptr; a.dy = dy; a.sc = sc; a.sh = sh; a.partial = partial;
+  a.ldx = ldx; a.ldy = 0; a.lddy = lddy; a.pro_mode = pro_mode;
+  const dim3 grid((a.CV + LT_CVB - 1) / LT_CVB, grid_y);
+#define SEG_LT(TT, DD) \
+  hipLaunchKernelGGL((dwconv_wgrad_tiled_kernel<TT, DD>), grid, dim3(LT_THREADS), \
+                     tiled_lds<DD>(dtype, false), st, a)
+  if (dtype == DT_BF16) { if (dil == 1) SEG_LT(bf16_t, 1); else SEG_LT(bf16_t, 2); }
+  else { if (dil == 1) SEG_LT(float, 1); else SEG_LT(float, 2); }
+#undef SEG_LT
+  return check_launch("dwconv3x3_wgrad (tiled)");
+}
+
+}  // namespace seg

@@ -151,7 +151,7 @@ def dwconv(x, w9c, stride, dil, pro=None, out=None, want_stats=False):
     if out is None:
         out = torch.empty((N, Ho, Wo, C), dtype=x.dtype, device=x.device)
     ldy = nhwc(out)[4]
-    gy = LIB.query("seg_dwconv_grid_y", _DT[x.dtype], C, N, Ho, Wo)
+    gy = LIB.query("seg_dwconv_grid_y", _DT[x.dtype], C, N, Ho, Wo, stride, dil)
     partial = torch.empty((gy, 2, C), dtype=torch.float32, device=x.device) if want_stats else None
     LIB.call("seg_dwconv3x3", _DT[x.dtype], 0, _p(x), ldx, N, Hi, Wi, C, _p(w9c), stride, dil,
              mode, _p(ps), _p(pt), _p(out), ldy, Ho, Wo, _p(partial), gy, _stream())
@@ -163,7 +163,7 @@ def dwconv_dgrad(dy, w9c, stride, dil, in_hw):
     N, Ho, Wo, C, lddy = nhwc(dy)
     Hi, Wi = in_hw
     dx = torch.empty((N, Hi, Wi, C), dtype=dy.dtype, device=dy.device)
-    gy = LIB.query("seg_dwconv_grid_y", _DT[dy.dtype], C, N, Hi, Wi)
+    gy = LIB.query("seg_dwconv_grid_y", _DT[dy.dtype], C, N, Hi, Wi, stride, dil)
     if stride == 1:
         # stride-1 data gradient = the forward correlation with the taps flipped (same dilation,
         # pad = dil) -> reuses the forward kernel including its sliding-window fast path
@@ -182,7 +182,8 @@ def dwconv_bwd_fused(x, dy, w9c, dil, pro=None, want_bn=False):
     lddy = nhwc(dy)[4]
     mode, ps, pt = _pro(pro)
     g = torch.empty((N, H, W, C), dtype=x.dtype, device=x.device)
-    gy = LIB.query("seg_dwconv_grid_y", _DT[x.dtype], C, N, H, W)
+    # stride 0 = geometry of the strip kernels (the fused backward is one of them)
+    gy = LIB.query("seg_dwconv_grid_y", _DT[x.dtype], C, N, H, W, 0, dil)
     pw = torch.empty((gy, 9 * C), dtype=torch.float32, device=x.device)
     pb = torch.empty((gy, 2 * C), dtype=torch.float32, device=x.device) if want_bn else None
     LIB.call("seg_dwconv3x3_bwd_fused", _DT[x.dtype], _p(dy), lddy, _p(x), ldx, N, H, W, C,
@@ -195,7 +196,7 @@ def dwconv_wgrad(x, dy, stride, dil, pro=None):
     N, Hi, Wi, C, ldx = nhwc(x)
     _, Ho, Wo, _, lddy = nhwc(dy)
     mode, ps, pt = _pro(pro)
-    gy = LIB.query("seg_dwconv_grid_y", _DT[x.dtype], C, N, Ho, Wo)
+    gy = LIB.query("seg_dwconv_grid_y", _DT[x.dtype], C, N, Ho, Wo, stride, dil)
     partial = torch.empty((gy, 9 * C), dtype=torch.float32, device=x.device)
     LIB.call("seg_dwconv3x3_wgrad", _DT[x.dtype], _p(x), ldx, N, Hi, Wi, C, _p(dy), lddy, Ho, Wo,
              stride, dil, mode, _p(ps), _p(pt), _p(partial), gy, _stream())

@@ -19,7 +19,7 @@ CASES = {
     "c4": dict(model="PSPNet", backbone="resnet50", os=8, aux=True, fn="pspnet_resnet", hw=(49, 65),
                aux_weight=0.4),
     "c2": dict(model="DeepLabV3_Plus", backbone="mobilenet_v2", os=16, aux=False,
-               fn="deeplab_mobilenet", hw=(65, 97), aux_weight=0.4,
+               fn="deeplab_mobilenet", hw=(65, 97), aux_weight=0.4, tie_delta=1e-5,
                over=["MODEL.DEEPLABV3_PLUS.USE_ASPP", "False",
                      "MODEL.DEEPLABV3_PLUS.ENABLE_DECODER", "False"]),
     "c5": dict(model="HRNet", backbone="hrnet_w18_small_v1", os=16, aux=False, fn="hrnet_seg",
@@ -65,12 +65,16 @@ class _shifted_relu:
 
     def __enter__(self):
         import torch.nn.functional as TF
-        self.TF, self.orig = TF, TF.relu
+        self.TF, self.orig, self.orig6 = TF, TF.relu, TF.relu6
         if self.shift:
-            TF.relu = lambda t, inplace=False: t * (t > self.shift)
+            sh = self.shift
+            TF.relu = lambda t, inplace=False: t * (t > sh)
+            # ReLU6: both knees move (lower at 0, upper at 6)
+            TF.relu6 = lambda t, inplace=False: torch.where(t < 6 + sh, t * (t > sh),
+                                                            torch.full_like(t, 6.0))
 
     def __exit__(self, *a):
-        self.TF.relu = self.orig
+        self.TF.relu, self.TF.relu6 = self.orig, self.orig6
 
 
 def _oracle(tag, sd, x, training, dtype=torch.float32, y=None, relu_shift=0.0):

@@ -167,16 +167,21 @@ def test_dwconv_fwd_dgrad_wgrad(case, dtype):
     assert_close(to_cpu_nchw(y), ref.detach(), dtype, "dw y")
     sums = K().colsum(partial.view(partial.shape[0], -1)).cpu()
     r = ref.detach()
+    # bf16, tiled kernels (stride 1, dil <= 2): the activated operand is rounded to bf16 once (it
+    # is parked in LDS in the storage dtype), so the sums carry that rounding (2^-9 per term)
+    sfac = 5 if dtype == torch.float32 else 60
     assert_close(sums[:C], r.sum((0, 2, 3)), torch.float32, "dw sum",
-                 scale=r.abs().sum((0, 2, 3)).max().item(), fac=5)
-    assert_close(sums[C:], (r * r).sum((0, 2, 3)), torch.float32, "dw sumsq", fac=5)
+                 scale=r.abs().sum((0, 2, 3)).max().item(), fac=sfac)
+    assert_close(sums[C:], (r * r).sum((0, 2, 3)), torch.float32, "dw sumsq", fac=sfac)
     dy = quant(rnd(tuple(ref.shape), 3), dtype)
     ref.backward(dy.double())
     dyd = to_dev_nhwc(dy, dtype)
     g = K().dwconv_dgrad(dyd, w9c.flip(0).contiguous() if stride == 1 else w9c, stride, dil, (H, W))
     assert_close(to_cpu_nchw(g), xa.grad, dtype, "dw dgrad")
     dW = K().dwconv_wgrad(to_dev_nhwc(x, dtype), dyd, stride, dil, pro)
-    assert_close(dW.t().reshape(C, 1, 3, 3).cpu(), wd.grad, torch.float32, "dw wgrad", fac=20)
+    # (bf16 tiled kernels see the activation rounded to bf16, the fp64 reference does not)
+    assert_close(dW.t().reshape(C, 1, 3, 3).cpu(), wd.grad, torch.float32, "dw wgrad",
+                 fac=20 if dtype == torch.float32 else 100)
     if stride == 1:  # fused one-pass backward: masked dgrad + wgrad + BN-backward sums
         gf, dWf, pb = K().dwconv_bwd_fused(to_dev_nhwc(x, dtype), dyd, w9c, dil, pro, want_bn=True)
         mask = (xa.detach() > 0).double() if (mode & 1) else torch.ones_like(xa.detach())
