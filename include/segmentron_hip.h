@@ -69,15 +69,19 @@ int seg_conv_gemm_wgrad_config(int double_buffer);
 
 /* ---- nn.Conv2d, groups=C, 3x3, padding=dilation (depthwise) --------------------------------
  * Replaces segmentron/modules/basic.py:38-40 (SeparableConv2d.depthwise), :152-153.
- * w9c: fp32 [9][C] (tap-major).  mode 0: forward (x -> y).  mode 1: data gradient
+ * w9c: fp32 taps; w_layout 0 = [9][C] tap-major, bit 0 = torch's own [C,1,3,3] (no repacking,
+ * stride 1 / dilation <= 2 only), bit 1 = taps read reversed (stride-1 data gradient = forward
+ * correlation with flipped taps).  mode 0: forward (x -> y).  mode 1: data gradient
  * (x = dy with geometry N,Hi,Wi; y = dx with geometry Ho,Wo; same w9c, stride, dil).
  * stat_partial (forward only, nullable): [grid_y][2][C].  grid_y from seg_dwconv_grid_y. */
 int seg_dwconv3x3(int dtype, int mode, const void* x, long ldx, int N, int Hi, int Wi, int C,
-                  const float* w9c, int stride, int dil, int pro_mode, const float* pro_scale,
-                  const float* pro_shift, void* y, long ldy, int Ho, int Wo, float* stat_partial,
+                  const float* w9c, int w_layout, int stride, int dil, int pro_mode,
+                  const float* pro_scale, const float* pro_shift, void* y, long ldy, int Ho, int Wo, float* stat_partial,
                   int grid_y, void* stream);
 int seg_dwconv_grid_y(int dtype, int C, int N, int Ho, int Wo, int stride, int dil);
-/* partial: fp32 [grid_y][9][C]; column-sum gives dW[9][C]. */
+/* partial: fp32 [grid_y][9][C]; column-sum gives dW[9][C];
+ * seg_dwconv3x3_wgrad_finalize reduces it straight into torch's [C,1,3,3] layout. */
+int seg_dwconv3x3_wgrad_finalize(const float* partial, int R, int C, float* dw_c9, void* stream);
 int seg_dwconv3x3_wgrad(int dtype, const void* x, long ldx, int N, int Hi, int Wi, int C,
                         const void* dy, long lddy, int Ho, int Wo, int stride, int dil,
                         int pro_mode, const float* pro_scale, const float* pro_shift,

@@ -600,7 +600,7 @@ extern "C" int seg_dwconv_grid_y(int dtype, int C, int N, int Ho, int Wo, int st
 
 // mode: 0 forward, 1 dgrad (x = dy, y = dx; (N,Hi,Wi) is dy's geometry, (Ho,Wo) dx's)
 extern "C" int seg_dwconv3x3(int dtype, int mode, const void* x, long ldx, int N, int Hi, int Wi,
-                             int C, const float* w9c, int stride, int dil, int pro_mode,
+                             int C, const float* w9c, int w_layout, int stride, int dil, int pro_mode,
                              const float* pro_scale, const float* pro_shift, void* y, long ldy,
                              int Ho, int Wo, float* stat_partial, int grid_y, void* stream) {
   using namespace seg;
@@ -614,9 +614,10 @@ extern "C" int seg_dwconv3x3(int dtype, int mode, const void* x, long ldx, int N
   SEG_REQUIRE(grid_y >= 1, "dwconv3x3: grid_y must be >= 1");
   if (mode == MODE_FWD && dw_tiled_supported(stride, dil)) {  // incl. stride-1 dgrad (flipped taps)
     SEG_REQUIRE(Ho == Hi && Wo == Wi, "dwconv3x3: stride 1 keeps the size");
-    return launch_dw_tiled(dtype, x, ldx, N, Hi, Wi, C, w9c, dil, pro_mode, pro_scale, pro_shift,
-                           y, ldy, stat_partial, grid_y, (hipStream_t)stream);
+    return launch_dw_tiled(dtype, x, ldx, N, Hi, Wi, C, w9c, w_layout, dil, pro_mode, pro_scale,
+                           pro_shift, y, ldy, stat_partial, grid_y, (hipStream_t)stream);
   }
+  SEG_REQUIRE(w_layout == 0, "dwconv3x3: the strip kernels take tap-major [9][C] weights");
   DwArgs a;
   a.x = x; a.w = w9c; a.y = y; a.pro_scale = pro_scale; a.pro_shift = pro_shift;
   a.stat_partial = stat_partial; a.ldx = ldx; a.ldy = ldy;
@@ -722,4 +723,12 @@ extern "C" int seg_dwconv3x3_bwd_fused(int dtype, const void* dy, long lddy, con
     else hipLaunchKernelGGL((dwconv_bwd_fused_kernel<float, false>), grid, dim3(DW_THREADS), lds, st, a);
   }
   return check_launch("dwconv3x3_bwd_fused");
+}
+
+// dW [C][9] (= torch [C,1,3,3]) from the weight-gradient partials [R][9][C]
+extern "C" int seg_dwconv3x3_wgrad_finalize(const float* partial, int R, int C, float* dw_c9,
+                                            void* stream) {
+  using namespace seg;
+  SEG_REQUIRE(R >= 1 && C >= 1, "dwconv3x3_wgrad_finalize: bad R/C");
+  return launch_dw_wgrad_finalize(partial, R, C, dw_c9, (hipStream_t)stream);
 }

@@ -6,8 +6,10 @@ namespace seg {
 bool dw_tiled_supported(int stride, int dil);
 int dw_tiled_grid_y(int dtype, int C, int N, int H, int W);
 int launch_dw_tiled(int dtype, const void* x, long ldx, int N, int H, int W, int C,
-                    const float* w9c, int dil, int pro_mode, const float* sc, const float* sh,
-                    void* y, long ldy, float* stat_partial, int grid_y, hipStream_t st);
+                    const float* w, int w_layout, int dil, int pro_mode, const float* sc,
+                    const float* sh, void* y, long ldy, float* stat_partial, int grid_y,
+                    hipStream_t st);
+int launch_dw_wgrad_finalize(const float* partial, int R, int C, float* out, hipStream_t st);
 int launch_dw_wgrad_tiled(int dtype, const void* x, long ldx, int N, int H, int W, int C,
                           const void* dy, long lddy, int dil, int pro_mode, const float* sc,
                           const float* sh, float* partial, int grid_y, hipStream_t st);

@@ -24,7 +24,9 @@ constexpr int LT_TH = 8, LT_TW = 16, LT_CVB = 8, LT_THREADS = 256;
 
 struct DwTiledArgs {
   const void* x;       // tensor the taps read (fwd: input, dgrad: dy)
-  const float* w;      // [9][C] fp32, tap-major (dgrad: flipped by the host)
+  const float* w;      // fp32 taps: [9][C] tap-major (w_layout 0) or torch's [C][9] (bit 0);
+                       // bit 1: read tap 8-k for tap k (stride-1 data gradient)
+  int w_layout;
   void* y;             // fwd/dgrad output
   const void* dy;      // wgrad: gradient wrt the dw output
   const float* sc; const float* sh;
@@ -118,7 +120,14 @@ __device__ __forceinline__ void stage_params(const DwTiledArgs& a, float4* __res
     float4 v = r == 9 ? make_float4(1.f, 1.f, 1.f, 1.f) : make_float4(0.f, 0.f, 0.f, 0.f);
     if (c < a.C) {
       if (r < 9) {
-        if (taps) v = *reinterpret_cast<const float4*>(a.w + r * a.C + c);
+        if (taps) {
+          const int tap = (a.w_layout & 2) ? 8 - r : r;
+          if (a.w_layout & 1)
+            v = make_float4(a.w[(c + 0) * 9 + tap], a.w[(c + 1) * 9 + tap], a.w[(c + 2) * 9 + tap],
+                            a.w[(c + 3) * 9 + tap]);
+          else
+            v = *reinterpret_cast<const float4*>(a.w + tap * a.C + c);
+        }
       } else if (a.pro_mode & PRO_AFFINE) {
         v = *reinterpret_cast<const float4*>((r == 9 ? a.sc : a.sh) + c);
       }
@@ -340,6 +349,36 @@ __global__ __launch_bounds__(LT_THREADS, 2) void dwconv_wgrad_tiled_kernel(const
   }
 }
 
+// partial [R][9][C] -> dW [C][9] (torch's [C,1,3,3]): fixed-order fp64 column sums + transpose in
+// one launch (was: two-level colsum + a torch transpose copy)
+__global__ __launch_bounds__(256) void dw_wgrad_finalize_kernel(const float* __restrict__ part,
+                                                                int R, int C,
+                                                                float* __restrict__ out) {
+  // block = 8 columns x 32 row groups: short serial loops and 9C/8 blocks in flight
+  __shared__ double red[32][9];
+  const int cx = threadIdx.x & 7, ry = threadIdx.x >> 3;
+  const int col = blockIdx.x * 8 + cx;  // column of the [9*C] row: tap * C + c
+  const int L = 9 * C;
+  double acc = 0.0;
+  if (col < L)
+    for (int r = ry; r < R; r += 32) acc += (double)part[(long)r * L + col];
+  red[ry][cx] = acc;
+  __syncthreads();
+  if (ry == 0 && col < L) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) t += red[k][cx];
+    const int tap = col / C, c = col - tap * C;
+    out[c * 9 + tap] = (float)t;
+  }
+}
+
+int launch_dw_wgrad_finalize(const float* partial, int R, int C, float* out, hipStream_t st) {
+  hipLaunchKernelGGL(dw_wgrad_finalize_kernel, dim3((9 * C + 7) / 8), dim3(256), 0, st, partial,
+                     R, C, out);
+  return check_launch("dw_wgrad_finalize");
+}
+
 // ------------------------------------------------------------------ host side
 bool dw_tiled_supported(int stride, int dil) { return stride == 1 && (dil == 1 || dil == 2); }
 
@@ -375,11 +414,13 @@ template <int DIL> static size_t tiled_lds(int dtype, bool with_weights) {
 }
 
 int launch_dw_tiled(int dtype, const void* x, long ldx, int N, int H, int W, int C,
-                    const float* w9c, int dil, int pro_mode, const float* sc, const float* sh,
-                    void* y, long ldy, float* stat_partial, int grid_y, hipStream_t st) {
+                    const float* w, int w_layout, int dil, int pro_mode, const float* sc,
+                    const float* sh, void* y, long ldy, float* stat_partial, int grid_y,
+                    hipStream_t st) {
   DwTiledArgs a;
   tiled_geom(a, dtype, N, H, W, C);
-  a.x = x; a.w = w9c; a.y = y; a.dy = nullptr; a.sc = sc; a.sh = sh; a.partial = stat_partial;
+  a.w_layout = w_layout;
+  a.x = x; a.w = w; a.y = y; a.dy = nullptr; a.sc = sc; a.sh = sh; a.partial = stat_partial;
   a.ldx = ldx; a.ldy = ldy; a.lddy = 0; a.pro_mode = pro_mode;
   const dim3 grid((a.CV + LT_CVB - 1) / LT_CVB, grid_y);
 #define SEG_LT(TT, DD) \
@@ -396,6 +437,7 @@ int launch_dw_wgrad_tiled(int dtype, const void* x, long ldx, int N, int H, int 
                           const float* sh, float* partial, int grid_y, hipStream_t st) {
   DwTiledArgs a;
   tiled_geom(a, dtype, N, H, W, C);
+  a.w_layout = 0;
   a.x = x; a.w = nullptr; a.y = nullptr; a.dy = dy; a.sc = sc; a.sh = sh; a.partial = partial;
   a.ldx = ldx; a.ldy = 0; a.lddy = lddy; a.pro_mode = pro_mode;
   const dim3 grid((a.CV + LT_CVB - 1) / LT_CVB, grid_y);

@@ -355,8 +355,11 @@ class _DwFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, in_gamma, in_beta, weight, spec):
-        w9c = cached_pack(weight, "dw", lambda: pack_dw_weight(weight))
-        y, spec.partial = K.dwconv(x, w9c, spec.stride, spec.dil, spec.pro, spec.out,
+        if K.dw_tiled(spec.stride, spec.dil):
+            w = weight.detach()  # the tiled kernels read torch's [C,1,3,3] directly
+        else:
+            w = cached_pack(weight, "dw", lambda: pack_dw_weight(weight))
+        y, spec.partial = K.dwconv(x, w, spec.stride, spec.dil, spec.pro, spec.out,
                                    spec.want_stats)
         ctx.spec = spec
         ctx.save_for_backward(x, weight)
@@ -373,11 +376,12 @@ class _DwFn(torch.autograd.Function):
         big = x.numel() * x.element_size() >= (40 << 20)
         if s.stride == 1 and ctx.needs_input_grad[0] and big:
             # one pass over (dy, x): masked data gradient + weight-gradient partials + BN sums
-            # (tools/dw_bench.py: 397 vs 707 us on the 269 MB entry-flow tensors; on the 24 MB
-            # middle-flow tensors the three separate kernels are faster, 115 vs 131 us)
+            # (tools/dw_bench.py, 269 MB entry-flow tensor: 400 us vs 149 + 176 + 91 us for the
+            # tiled dgrad + wgrad + BN-reduce kernels; on small tensors the separate kernels win)
             bn = s.bn_in
             w9c = cached_pack(weight, "dw", lambda: pack_dw_weight(weight))
             g, dW9c, pb = K.dwconv_bwd_fused(x, dy, w9c, s.dil, s.pro, want_bn=bn is not None)
+            dW = dW9c.t().reshape(C, 1, 3, 3).contiguous()
             if bn is None:
                 dx = g  # plain / ReLU input: the masked gradient is final
             else:
@@ -394,15 +398,21 @@ class _DwFn(torch.autograd.Function):
                 # the ReLU mask is already in g: apply only the affine part of the BN backward
                 dx = K.bn_bwd_apply(g, x, (PRO_AFFINE, bn.scale, bn.shift), c0, c1, out=g)
         else:
-            dW9c = K.dwconv_wgrad(x, dy, s.stride, s.dil, s.pro)
+            tiled = K.dw_tiled(s.stride, s.dil)
+            if tiled:
+                dW = K.dwconv_wgrad(x, dy, s.stride, s.dil, s.pro, torch_layout=True)
+            else:
+                dW9c = K.dwconv_wgrad(x, dy, s.stride, s.dil, s.pro)
+                dW = dW9c.t().reshape(C, 1, 3, 3).contiguous()
             if ctx.needs_input_grad[0]:
-                if s.stride == 1:  # forward kernel with reversed taps
-                    w9c = cached_pack(weight, "dw_flip", lambda: pack_dw_weight(weight, True))
+                if tiled:
+                    w = weight.detach()  # reversed inside the kernel
+                elif s.stride == 1:  # forward kernel with reversed taps
+                    w = cached_pack(weight, "dw_flip", lambda: pack_dw_weight(weight, True))
                 else:
-                    w9c = cached_pack(weight, "dw", lambda: pack_dw_weight(weight))
-                g = K.dwconv_dgrad(dy, w9c, s.stride, s.dil, (x.shape[1], x.shape[2]))
+                    w = cached_pack(weight, "dw", lambda: pack_dw_weight(weight))
+                g = K.dwconv_dgrad(dy, w, s.stride, s.dil, (x.shape[1], x.shape[2]))
                 dx, dgamma, dbeta = bn_input_backward(g, x, s.bn_in, s.relu, inplace=True)
-        dW = dW9c.t().reshape(C, 1, 3, 3).contiguous()
         return dx, dgamma, dbeta, dW, None
 
 

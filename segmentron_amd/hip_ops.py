@@ -144,33 +144,57 @@ def conv_wgrad(x, dy, O, KH, KW, stride, pad, dil, pro=None):
 
 
 # ----------------------------------------------------------------------------- depthwise
+def dw_tiled(stride, dil):
+    """True where the LDS-tiled depthwise kernels run: they read the taps in torch's own
+    [C,1,3,3] layout (no repacking) and, for the data gradient, reversed in place."""
+    return stride == 1 and dil in (1, 2)
+
+
+def _dw_weight_arg(w, C, stride, dil, flip):
+    """-> (tensor, w_layout).  [C,1,3,3]/[C,9] parameter tensors go straight to the tiled
+    kernels; the strip kernels take the tap-major [9, C] packing."""
+    if w.dim() == 4 or (w.dim() == 2 and w.shape == (C, 9) and C != 9):
+        if not dw_tiled(stride, dil):
+            raise ValueError("depthwise strip kernels need tap-major [9, C] weights")
+        return w, 1 | (2 if flip else 0)
+    return w, (2 if flip else 0) if dw_tiled(stride, dil) else 0
+
+
 def dwconv(x, w9c, stride, dil, pro=None, out=None, want_stats=False):
+    """w9c: tap-major [9, C] fp32, or (stride 1, dil <= 2) the [C,1,3,3] parameter itself."""
     N, Hi, Wi, C, ldx = nhwc(x)
     Ho, Wo = conv_out_size(Hi, 3, stride, dil, dil), conv_out_size(Wi, 3, stride, dil, dil)
     mode, ps, pt = _pro(pro)
     if out is None:
         out = torch.empty((N, Ho, Wo, C), dtype=x.dtype, device=x.device)
     ldy = nhwc(out)[4]
+    w, layout = _dw_weight_arg(w9c, C, stride, dil, False)
     gy = LIB.query("seg_dwconv_grid_y", _DT[x.dtype], C, N, Ho, Wo, stride, dil)
     partial = torch.empty((gy, 2, C), dtype=torch.float32, device=x.device) if want_stats else None
-    LIB.call("seg_dwconv3x3", _DT[x.dtype], 0, _p(x), ldx, N, Hi, Wi, C, _p(w9c), stride, dil,
-             mode, _p(ps), _p(pt), _p(out), ldy, Ho, Wo, _p(partial), gy, _stream())
+    LIB.call("seg_dwconv3x3", _DT[x.dtype], 0, _p(x), ldx, N, Hi, Wi, C, _p(w), layout, stride,
+             dil, mode, _p(ps), _p(pt), _p(out), ldy, Ho, Wo, _p(partial), gy, _stream())
     return out, partial
 
 
-def dwconv_dgrad(dy, w9c, stride, dil, in_hw):
-    """stride 1: `w9c` must hold the taps REVERSED (pack_dw_weight(..., flipped=True))."""
+def dwconv_dgrad(dy, w9c, stride, dil, in_hw, flipped=True):
+    """stride 1: the forward correlation with the taps reversed.  `w9c` is either the
+    [C,1,3,3] parameter (reversed inside the kernel), or a tap-major [9, C] packing that is
+    ALREADY reversed (`flipped=True`, pack_dw_weight(..., flipped=True)) / not yet."""
     N, Ho, Wo, C, lddy = nhwc(dy)
     Hi, Wi = in_hw
     dx = torch.empty((N, Hi, Wi, C), dtype=dy.dtype, device=dy.device)
     gy = LIB.query("seg_dwconv_grid_y", _DT[dy.dtype], C, N, Hi, Wi, stride, dil)
     if stride == 1:
-        # stride-1 data gradient = the forward correlation with the taps flipped (same dilation,
-        # pad = dil) -> reuses the forward kernel including its sliding-window fast path
-        LIB.call("seg_dwconv3x3", _DT[dy.dtype], 0, _p(dy), lddy, N, Ho, Wo, C, _p(w9c), 1, dil,
-                 PRO_NONE, 0, 0, _p(dx), C, Hi, Wi, 0, gy, _stream())
+        if w9c.dim() == 4:
+            w, layout = w9c, 3
+        elif dw_tiled(stride, dil):
+            w, layout = w9c, 0 if flipped else 2
+        else:
+            w, layout = (w9c if flipped else w9c.flip(0).contiguous()), 0
+        LIB.call("seg_dwconv3x3", _DT[dy.dtype], 0, _p(dy), lddy, N, Ho, Wo, C, _p(w), layout, 1,
+                 dil, PRO_NONE, 0, 0, _p(dx), C, Hi, Wi, 0, gy, _stream())
     else:
-        LIB.call("seg_dwconv3x3", _DT[dy.dtype], 1, _p(dy), lddy, N, Ho, Wo, C, _p(w9c), stride,
+        LIB.call("seg_dwconv3x3", _DT[dy.dtype], 1, _p(dy), lddy, N, Ho, Wo, C, _p(w9c), 0, stride,
                  dil, PRO_NONE, 0, 0, _p(dx), C, Hi, Wi, 0, gy, _stream())
     return dx
 
@@ -191,8 +215,8 @@ def dwconv_bwd_fused(x, dy, w9c, dil, pro=None, want_bn=False):
     return g, colsum(pw, f64=False).view(9, C), pb
 
 
-def dwconv_wgrad(x, dy, stride, dil, pro=None):
-    """-> fp32 [9, C]."""
+def dwconv_wgrad(x, dy, stride, dil, pro=None, torch_layout=False):
+    """-> fp32 [9, C], or with torch_layout the parameter's own [C, 1, 3, 3]."""
     N, Hi, Wi, C, ldx = nhwc(x)
     _, Ho, Wo, _, lddy = nhwc(dy)
     mode, ps, pt = _pro(pro)
@@ -200,10 +224,13 @@ def dwconv_wgrad(x, dy, stride, dil, pro=None):
     partial = torch.empty((gy, 9 * C), dtype=torch.float32, device=x.device)
     LIB.call("seg_dwconv3x3_wgrad", _DT[x.dtype], _p(x), ldx, N, Hi, Wi, C, _p(dy), lddy, Ho, Wo,
              stride, dil, mode, _p(ps), _p(pt), _p(partial), gy, _stream())
+    if torch_layout:
+        out = torch.empty((C, 1, 3, 3), dtype=torch.float32, device=x.device)
+        LIB.call("seg_dwconv3x3_wgrad_finalize", _p(partial), gy, C, _p(out), _stream())
+        return out
     return colsum(partial, f64=False).view(9, C)
 
 
-# ----------------------------------------------------------------------------- batch norm
 def bn_finalize(sums, count, gamma, beta, eps, momentum, running_mean, running_var,
                 mean_offset=None):
     C = sums.numel() // 2

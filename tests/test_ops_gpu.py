@@ -182,6 +182,15 @@ def test_dwconv_fwd_dgrad_wgrad(case, dtype):
     # (bf16 tiled kernels see the activation rounded to bf16, the fp64 reference does not)
     assert_close(dW.t().reshape(C, 1, 3, 3).cpu(), wd.grad, torch.float32, "dw wgrad",
                  fac=20 if dtype == torch.float32 else 100)
+    if K().dw_tiled(stride, dil):
+        # the LDS-tiled kernels also take torch's [C,1,3,3] parameter as is (taps reversed in
+        # the kernel for the data gradient) and emit dW in that layout: bit-identical results
+        w4 = w.to(DEV)
+        y4, _ = K().dwconv(to_dev_nhwc(x, dtype), w4, stride, dil, pro)
+        assert torch.equal(y4, y)
+        assert torch.equal(K().dwconv_dgrad(dyd, w4, stride, dil, (H, W)), g)
+        dW4 = K().dwconv_wgrad(to_dev_nhwc(x, dtype), dyd, stride, dil, pro, torch_layout=True)
+        assert_close(dW4.cpu(), dW.t().reshape(C, 1, 3, 3).cpu().double(), torch.float32, "dw wgrad layout", fac=2)
     if stride == 1:  # fused one-pass backward: masked dgrad + wgrad + BN-backward sums
         gf, dWf, pb = K().dwconv_bwd_fused(to_dev_nhwc(x, dtype), dyd, w9c, dil, pro, want_bn=True)
         mask = (xa.detach() > 0).double() if (mode & 1) else torch.ones_like(xa.detach())
