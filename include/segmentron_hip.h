@@ -64,6 +64,11 @@ int seg_conv_gemm_wgrad(int dtype, const void* x, long ldx, int N, int Hi, int W
                         const void* dy, long lddy, int Ho, int Wo, int O, int KH, int KW,
                         int stride, int pad, int dil, int pro_mode, const float* pro_scale,
                         const float* pro_shift, float* partial, int splits, void* stream);
+/* rows of the [rows][2][O] statistics buffer seg_conv_gemm_fwd writes for this geometry */
+int seg_conv_gemm_stat_rows(int N, int Ho, int Wo, int O, int KH, int KW, int stride, int pad,
+                            int tconv);
+/* 1 (default): 1x1 stride-1 convs on the 256x128-tile kernel; returns the previous value */
+int seg_conv_gemm_px256(int enable);
 int seg_conv_gemm_wgrad_splits(int dtype, int N, int Ho, int Wo, int O, int K);
 int seg_conv_gemm_wgrad_config(int double_buffer);
 

@@ -10,7 +10,8 @@ import re
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
-LIB_PATH = os.path.join(_PKG, "libsegmentron_hip.so")
+# SEGMENTRON_HIP_LIB: load another build of the same C-ABI (kernel A/B experiments)
+LIB_PATH = os.environ.get("SEGMENTRON_HIP_LIB") or os.path.join(_PKG, "libsegmentron_hip.so")
 HEADER_PATH = os.path.join(_ROOT, "include", "segmentron_hip.h")
 
 _CTYPES = {"int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float,

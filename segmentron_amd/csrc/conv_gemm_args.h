@@ -1,0 +1,33 @@
+// Argument block shared by the implicit-GEMM forward/dgrad kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace seg {
+
+struct ConvGemmArgs {
+  const void* x;
+  const void* w;
+  void* y;
+  const float* pro_scale;
+  const float* pro_shift;
+  const float* bias;
+  float* stat_partial;  // [tiles_m][2][O] or null
+  // optional epilogue correction (data gradient through a folded BatchNorm, fold.hip):
+  //   y[p][o] = acc - ep_c0[o] - ep_c1[o] * ep_x[p][o]      (ep_x addressed like y)
+  const void* ep_x;
+  const float* ep_c0;
+  const float* ep_c1;
+  long ldx, ldy, ldep;
+  int N, Hi, Wi, C, Ho, Wo, O;
+  int KH, KW, stride, pad, dil;
+  int pro_mode;
+  int tconv;  // 1: transposed-stride gather (data gradient of a strided KxK convolution)
+  int M, K;
+  int out_H, out_W, out_s;  // output row scatter geometry (out_s == 1 -> dense rows)
+  int tiles_m, tiles_n;
+};
+
+int px256_tiles_m(long M);
+int launch_conv_gemm_px256(int dtype, ConvGemmArgs a, hipStream_t stream);
+
+}  // namespace seg

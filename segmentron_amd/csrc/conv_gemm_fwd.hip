@@ -15,31 +15,10 @@
 //              of a wider buffer (ldy) so torch.cat never copies; optional strided row scatter
 //              (dgrad of a stride-2 1x1 conv).
 #include "conv_gemm.h"
+#include "conv_gemm_args.h"
 
 namespace seg {
 
-struct ConvGemmArgs {
-  const void* x;
-  const void* w;
-  void* y;
-  const float* pro_scale;
-  const float* pro_shift;
-  const float* bias;
-  float* stat_partial;  // [tiles_m][2][O] or null
-  // optional epilogue correction (data gradient through a folded BatchNorm, fold.hip):
-  //   y[p][o] = acc - ep_c0[o] - ep_c1[o] * ep_x[p][o]      (ep_x addressed like y)
-  const void* ep_x;
-  const float* ep_c0;
-  const float* ep_c1;
-  long ldx, ldy, ldep;
-  int N, Hi, Wi, C, Ho, Wo, O;
-  int KH, KW, stride, pad, dil;
-  int pro_mode;
-  int tconv;  // 1: transposed-stride gather (data gradient of a strided KxK convolution)
-  int M, K;
-  int out_H, out_W, out_s;  // output row scatter geometry (out_s == 1 -> dense rows)
-  int tiles_m, tiles_n;
-};
 
 // FAST : 1x1, stride 1, no padding — the 96 %-of-FLOPs case: operand rows are addressed by
 //        pointers set up once and advanced by a constant per K-slab (no per-slab index math).
@@ -292,6 +271,7 @@ __global__ __launch_bounds__(GEMM_THREADS, (DBUF || !FAST) ? 2 : 3) void conv_ge
   }
 }
 
+static int g_gemm_px256 = 1;  // 1x1 stride-1 convs on the 256x128 kernel (conv_gemm_px256.hip)
 static int g_gemm_dbuf = 0;  // single LDS stage, 3 blocks/CU: measured faster on every C3 shape
                              // (gpurun_out/gemm_bench2: 709 vs 622 TF on 1536->2048 @65x129)
 
@@ -317,6 +297,30 @@ extern "C" int seg_conv_gemm_config(int double_buffer) {
   const int prev = seg::g_gemm_dbuf;
   if (double_buffer >= 0) seg::g_gemm_dbuf = double_buffer ? 1 : 0;
   return prev;
+}
+
+// 1 (default): 1x1 / stride-1 convolutions run on the 256x128-tile kernel; 0: first-generation
+// 128x128 kernel everywhere.  Returns the previous value; a negative argument only queries.
+extern "C" int seg_conv_gemm_px256(int enable) {
+  const int prev = seg::g_gemm_px256;
+  if (enable >= 0) seg::g_gemm_px256 = enable ? 1 : 0;
+  return prev;
+}
+
+// The 256x128 kernel pays off where an output row is wide enough to amortise its longer
+// per-block pipeline (tools/gemm_bench.py, bf16 TFLOP/s, 128x128 -> 256x128: 728->728 @65x129
+// 419 -> 487, 1536->2048 675 -> 675, 304->256 @257x513 434 -> 430, 128->128 @513x1025 326 -> 315)
+static bool gemm_use_px256(int KH, int KW, int stride, int pad, int tconv, int O, long M) {
+  return KH * KW == 1 && stride == 1 && pad == 0 && !tconv && O >= 384 && M >= 4096;
+}
+
+// rows of the statistics partial buffer [rows][2][O] the forward kernel will write
+extern "C" int seg_conv_gemm_stat_rows(int N, int Ho, int Wo, int O, int KH, int KW, int stride,
+                                       int pad, int tconv) {
+  const long M = (long)N * Ho * Wo;
+  if (seg::g_gemm_px256 && gemm_use_px256(KH, KW, stride, pad, tconv, O, M))
+    return seg::px256_tiles_m(M);
+  return (int)((M + seg::BM - 1) / seg::BM);
 }
 
 extern "C" int seg_conv_gemm_fwd(int dtype, const void* x, long ldx, int N, int Hi, int Wi, int C,
@@ -349,6 +353,9 @@ extern "C" int seg_conv_gemm_fwd(int dtype, const void* x, long ldx, int N, int 
   a.M = N * Ho * Wo; a.K = KH * KW * C;
   a.out_H = out_H; a.out_W = out_W; a.out_s = out_s;
   a.tiles_m = (a.M + BM - 1) / BM; a.tiles_n = (O + BN - 1) / BN;
+  SEG_REQUIRE(out_s == 1 || stat_partial == nullptr, "conv_gemm_fwd: no statistics with scatter");
+  if (g_gemm_px256 && gemm_use_px256(KH, KW, stride, pad, tconv, O, a.M) && out_s == 1)
+    return launch_conv_gemm_px256(dtype, a, (hipStream_t)stream);
   if (dtype == DT_BF16) return launch_conv_gemm_fwd<bf16_t>(a, (hipStream_t)stream);
   return launch_conv_gemm_fwd<float>(a, (hipStream_t)stream);
 }
