@@ -99,7 +99,8 @@ int seg_dwconv3x3_wgrad(int dtype, const void* x, long ldx, int N, int Hi, int W
  * x is the forward input (raw tensor + prologue), w9c the forward taps.  grid_y from
  * seg_dwconv_grid_y(dtype, C, N, H, W). */
 int seg_dwconv3x3_bwd_fused(int dtype, const void* dy, long lddy, const void* x, long ldx, int N,
-                            int H, int W, int C, const float* w9c, int dil, int pro_mode,
+                            int H, int W, int C, const float* w9c, int w_layout, int dil,
+                            int pro_mode,
                             const float* pro_scale, const float* pro_shift, void* g, long ldg,
                             float* partial_w, float* partial_bn, int grid_y, void* stream);
 

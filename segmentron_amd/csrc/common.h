@@ -47,6 +47,8 @@ template <> struct Vec<float> {
     return *reinterpret_cast<const uint4*>(p);
   }
   __device__ static __forceinline__ void unpack_raw(const raw_t& v, float* f) { unpack(v, f); }
+  __device__ static __forceinline__ raw_t pack_raw(const float* f) { return pack(f); }
+  __device__ static __forceinline__ raw_t zero_raw() { return make_uint4(0u, 0u, 0u, 0u); }
   __device__ static __forceinline__ void store(float* p, const float* f) {
     *reinterpret_cast<uint4*>(p) = pack(f);
   }
@@ -68,6 +70,8 @@ template <> struct Vec<bf16_t> {
     return *reinterpret_cast<const uint4*>(p);
   }
   __device__ static __forceinline__ void unpack_raw(const raw_t& v, float* f) { unpack(v, f); }
+  __device__ static __forceinline__ raw_t pack_raw(const float* f) { return pack(f); }
+  __device__ static __forceinline__ raw_t zero_raw() { return make_uint4(0u, 0u, 0u, 0u); }
   __device__ static __forceinline__ void store(bf16_t* p, const float* f) {
     *reinterpret_cast<uint4*>(p) = pack(f);
   }
@@ -96,6 +100,8 @@ template <> struct HVec<float> {
   __device__ static __forceinline__ void unpack_raw(const raw_t& v, float* f) {
     Vec<float>::unpack(v, f);
   }
+  __device__ static __forceinline__ raw_t pack_raw(const float* f) { return Vec<float>::pack(f); }
+  __device__ static __forceinline__ raw_t zero_raw() { return make_uint4(0u, 0u, 0u, 0u); }
   __device__ static __forceinline__ void load(const float* p, float* f) {
     const uint4 v = *reinterpret_cast<const uint4*>(p);
     Vec<float>::unpack(v, f);
@@ -114,6 +120,10 @@ template <> struct HVec<bf16_t> {
     f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xFFFF0000u);
     f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xFFFF0000u);
   }
+  __device__ static __forceinline__ raw_t pack_raw(const float* f) {
+    return make_uint2(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]));
+  }
+  __device__ static __forceinline__ raw_t zero_raw() { return make_uint2(0u, 0u); }
   __device__ static __forceinline__ void load(const bf16_t* p, float* f) {
     const uint2 v = *reinterpret_cast<const uint2*>(p);
     f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xFFFF0000u);

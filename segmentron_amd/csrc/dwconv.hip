@@ -691,7 +691,7 @@ extern "C" int seg_dwconv3x3_wgrad(int dtype, const void* x, long ldx, int N, in
 // + prologue), w9c the forward taps (not reversed).
 extern "C" int seg_dwconv3x3_bwd_fused(int dtype, const void* dy, long lddy, const void* x,
                                        long ldx, int N, int H, int W, int C, const float* w9c,
-                                       int dil, int pro_mode, const float* pro_scale,
+                                       int w_layout, int dil, int pro_mode, const float* pro_scale,
                                        const float* pro_shift, void* g, long ldg,
                                        float* partial_w, float* partial_bn, int grid_y,
                                        void* stream) {
@@ -703,6 +703,15 @@ extern "C" int seg_dwconv3x3_bwd_fused(int dtype, const void* dy, long lddy, con
   SEG_REQUIRE(((pro_mode & PRO_AFFINE) == 0) || (pro_scale && pro_shift),
               "dwconv3x3_bwd_fused: affine prologue without scale/shift");
   SEG_REQUIRE(grid_y >= 1 && partial_w != nullptr, "dwconv3x3_bwd_fused: bad grid/partials");
+  if (dw_tiled_supported(1, dil)) {
+    const int tvec = dtype == DT_BF16 ? 8 : 4;
+    SEG_REQUIRE(C % tvec == 0 && ldx % tvec == 0 && lddy % tvec == 0 && ldg % tvec == 0,
+                "dwconv3x3_bwd_fused: C/ld must be multiples of %d", tvec);
+    return launch_dw_bwd_tiled(dtype, dy, lddy, x, ldx, N, H, W, C, w9c, w_layout, dil, pro_mode,
+                               pro_scale, pro_shift, g, ldg, partial_w, partial_bn, grid_y,
+                               (hipStream_t)stream);
+  }
+  SEG_REQUIRE(w_layout == 0, "dwconv3x3_bwd_fused: the strip kernel takes tap-major weights");
   DwBwdArgs a;
   a.dy = dy; a.x = x; a.g = g; a.w = w9c; a.pro_scale = pro_scale; a.pro_shift = pro_shift;
   a.partial_w = partial_w; a.partial_bn = partial_bn;

@@ -31,6 +31,7 @@ struct DwTiledArgs {
   const void* dy;      // wgrad: gradient wrt the dw output
   const float* sc; const float* sh;
   float* partial;      // fwd: [gridDim.y][2][C] statistics or null; wgrad: [gridDim.y][9][C]
+  float* partial_bn;   // fused backward: [gridDim.y][2][C] or null
   long ldx, ldy, lddy;
   int N, H, W, C, CV, pro_mode, tiles_h, tiles_w, ntiles;
 };
@@ -44,12 +45,13 @@ template <int DIL> struct TileGeom {
 };
 
 // ---- global -> registers (all loads of the tile issued back to back)
-template <typename T, int DIL>
+template <typename T, typename V, int DIL>
 __device__ __forceinline__ void tile_issue(const DwTiledArgs& a, const T* __restrict__ X, int n,
-                                           int h0, int w0, int cv, uint4 (&raw)[TileGeom<DIL>::PER],
+                                           int h0, int w0, int cv,
+                                           typename V::raw_t (&raw)[TileGeom<DIL>::PER],
                                            unsigned& okmask) {
   using G = TileGeom<DIL>;
-  constexpr int VEC = Vec<T>::N;
+  constexpr int VEC = V::N;
   okmask = 0;
   const int cvc = min(cv, a.CV - 1);
 #pragma unroll
@@ -60,17 +62,18 @@ __device__ __forceinline__ void tile_issue(const DwTiledArgs& a, const T* __rest
     const bool ok = p < G::NPIX && cv < a.CV && hi >= 0 && hi < a.H && wi >= 0 && wi < a.W;
     okmask |= ok ? (1u << u) : 0u;
     const int hic = min(max(hi, 0), a.H - 1), wic = min(max(wi, 0), a.W - 1);
-    raw[u] = ldg16(X + (((long)n * a.H + hic) * a.W + wic) * a.ldx + cvc * VEC);
+    raw[u] = V::load_raw(X + (((long)n * a.H + hic) * a.W + wic) * a.ldx + cvc * VEC);
   }
 }
 
 // ---- registers -> LDS: activation once per element, zero padding outside the image
-template <typename T, int DIL>
-__device__ __forceinline__ void tile_commit(const DwTiledArgs& a, uint4* __restrict__ tile,
-                                            const uint4 (&raw)[TileGeom<DIL>::PER], unsigned okmask,
-                                            const float4* __restrict__ psm) {
+template <typename T, typename V, int DIL>
+__device__ __forceinline__ void tile_commit(const DwTiledArgs& a,
+                                            typename V::raw_t* __restrict__ tile,
+                                            const typename V::raw_t (&raw)[TileGeom<DIL>::PER],
+                                            unsigned okmask, const float4* __restrict__ psm) {
   using G = TileGeom<DIL>;
-  constexpr int VEC = Vec<T>::N, WQ = VEC / 4;
+  constexpr int VEC = V::N, WQ = VEC / 4;
   const int cx = threadIdx.x & (LT_CVB - 1);
   float sc[VEC], sh[VEC];
   if (a.pro_mode & PRO_AFFINE) {
@@ -87,7 +90,7 @@ __device__ __forceinline__ void tile_commit(const DwTiledArgs& a, uint4* __restr
     if (p < G::NPIX) {
       const int r = p / G::IW, c = p - r * G::IW;
       float f[VEC];
-      Vec<T>::unpack(raw[u], f);
+      V::unpack_raw(raw[u], f);
       if (a.pro_mode & PRO_AFFINE) {
 #pragma unroll
         for (int i = 0; i < VEC; ++i) f[i] = fmaf(f[i], sc[i], sh[i]);
@@ -100,8 +103,8 @@ __device__ __forceinline__ void tile_commit(const DwTiledArgs& a, uint4* __restr
 #pragma unroll
         for (int i = 0; i < VEC; ++i) f[i] = fminf(f[i], 6.f);
       }
-      uint4 v = Vec<T>::pack(f);
-      if (!((okmask >> u) & 1u)) v = make_uint4(0u, 0u, 0u, 0u);
+      typename V::raw_t v = V::pack_raw(f);
+      if (!((okmask >> u) & 1u)) v = V::zero_raw();
       tile[(r * G::IWP + c) * LT_CVB + cx] = v;
     }
   }
@@ -109,10 +112,10 @@ __device__ __forceinline__ void tile_commit(const DwTiledArgs& a, uint4* __restr
 
 // per-block constants -> LDS: rows 0..8 = the nine taps, rows 9/10 = prologue scale / shift
 // (kept out of registers: the persistent loop already carries accumulators and the next tile)
-template <typename T>
+template <typename V>
 __device__ __forceinline__ void stage_params(const DwTiledArgs& a, float4* __restrict__ psm,
                                              int cvb0, bool taps) {
-  constexpr int VEC = Vec<T>::N, WQ = VEC / 4;
+  constexpr int VEC = V::N, WQ = VEC / 4;
   const int tid = threadIdx.x;
   if (tid < 11 * LT_CVB * WQ) {
     const int r = tid / (LT_CVB * WQ), q = tid - r * (LT_CVB * WQ);
@@ -160,7 +163,7 @@ __global__ __launch_bounds__(LT_THREADS, sizeof(T) == 2 ? 3 : 4) void dwconv_til
   const T* __restrict__ X = reinterpret_cast<const T*>(a.x);
   T* __restrict__ Y = reinterpret_cast<T*>(a.y);
 
-  stage_params<T>(a, wsm, cvb0, true);
+  stage_params<Vec<T>>(a, wsm, cvb0, true);
   __syncthreads();
   float ssum[VEC], ssq[VEC];
 #pragma unroll
@@ -171,9 +174,9 @@ __global__ __launch_bounds__(LT_THREADS, sizeof(T) == 2 ? 3 : 4) void dwconv_til
     tile_coords(a, t, n, h0, w0);
     uint4 raw[G::PER];
     unsigned okmask;
-    tile_issue<T, DIL>(a, X, n, h0, w0, cv, raw, okmask);
+    tile_issue<T, Vec<T>, DIL>(a, X, n, h0, w0, cv, raw, okmask);
     __syncthreads();  // every thread is done reading the previous tile
-    tile_commit<T, DIL>(a, tile, raw, okmask, wsm);
+    tile_commit<T, Vec<T>, DIL>(a, tile, raw, okmask, wsm);
     __syncthreads();
 
     float acc[4][VEC];
@@ -264,7 +267,7 @@ __global__ __launch_bounds__(LT_THREADS, 2) void dwconv_wgrad_tiled_kernel(const
   const T* __restrict__ DY = reinterpret_cast<const T*>(a.dy);
 
   float4* psm = reinterpret_cast<float4*>(lt_smem + G::TILE_VECS);
-  stage_params<T>(a, psm, cvb0, false);
+  stage_params<Vec<T>>(a, psm, cvb0, false);
   __syncthreads();
   float acc[9][VEC];
 #pragma unroll
@@ -277,7 +280,7 @@ __global__ __launch_bounds__(LT_THREADS, 2) void dwconv_wgrad_tiled_kernel(const
     tile_coords(a, t, n, h0, w0);
     uint4 raw[G::PER];
     unsigned okmask;
-    tile_issue<T, DIL>(a, X, n, h0, w0, cv, raw, okmask);
+    tile_issue<T, Vec<T>, DIL>(a, X, n, h0, w0, cv, raw, okmask);
     // this thread's four dy vectors (zero outside the image / channel range)
     const int ho = h0 + row;
     uint4 graw[4];
@@ -290,7 +293,7 @@ __global__ __launch_bounds__(LT_THREADS, 2) void dwconv_wgrad_tiled_kernel(const
       if (!(rok && wo < a.W)) graw[j] = make_uint4(0u, 0u, 0u, 0u);
     }
     __syncthreads();
-    tile_commit<T, DIL>(a, tile, raw, okmask, psm);
+    tile_commit<T, Vec<T>, DIL>(a, tile, raw, okmask, psm);
     __syncthreads();
     float g[4][VEC];
 #pragma unroll
@@ -346,6 +349,209 @@ __global__ __launch_bounds__(LT_THREADS, 2) void dwconv_wgrad_tiled_kernel(const
     const int tap = k / VEC, ci = k - tap * VEC;
     const int c = (cvb0 + lcx) * VEC + ci;
     if (c < a.C) a.partial[((long)blockIdx.y * 9 + tap) * a.C + c] = tot;
+  }
+}
+
+
+// ------------------------------------------------------------------ fused backward
+// One pass over (dy, x) for the whole depthwise backward (stride 1):
+//   g'[q]   = relu_mask(x[q]) * sum_k dy[q - d_k] * w[k]      data gradient wrt act(x), masked
+//   dW[k]  += act(x[q]) * dy[q - d_k]                          the SAME shifted dy values
+//   (sum g', sum g' * x)                                       BatchNorm-backward sums of the
+//                                                              producer's BN (if any)
+// The dy tile (+halo) is staged in LDS exactly like the forward input tile; LDS row r = kh*3+kw
+// of the staged taps holds w[8 - r] (flipped), and the value read at tile offset (kh, kw) pairs
+// with tap 8 - r of the weight gradient.  Replaces dgrad + wgrad + bn_bwd_reduce (three passes
+// over two tensors each).
+template <typename T, int DIL>
+__global__ __launch_bounds__(LT_THREADS, 2) void dwconv_bwd_tiled_kernel(const DwTiledArgs a) {
+  // 4 channels per thread in both element types (8-byte bf16 vectors): this kernel carries nine
+  // tap accumulators per channel on top of the data-gradient accumulators
+  using G = TileGeom<DIL>;
+  using V = HVec<T>;
+  using raw_t = typename V::raw_t;
+  constexpr int VEC = V::N, WQ = VEC / 4;
+  extern __shared__ uint4 lt_smem[];
+  raw_t* tile = reinterpret_cast<raw_t*>(lt_smem);
+  float4* psm = reinterpret_cast<float4*>(lt_smem + G::TILE_VECS);
+  const int tid = threadIdx.x;
+  const int cvb0 = blockIdx.x * LT_CVB;
+  const int cx = tid & (LT_CVB - 1), row = (tid >> 3) & (LT_TH - 1), strip = tid >> 6;
+  const int cv = cvb0 + cx;
+  const T* __restrict__ DY = reinterpret_cast<const T*>(a.dy);
+  const T* __restrict__ X = reinterpret_cast<const T*>(a.x);
+  T* __restrict__ GO = reinterpret_cast<T*>(a.y);
+
+  // taps (flipped) + the prologue of x; the dy tile itself is staged without activation
+  stage_params<V>(a, psm, cvb0, true);
+  __syncthreads();
+  float sc[VEC], sh[VEC];
+#pragma unroll
+  for (int q = 0; q < WQ; ++q) {
+    const float4 s4 = psm[(9 * LT_CVB + cx) * WQ + q], t4 = psm[(10 * LT_CVB + cx) * WQ + q];
+    sc[q * 4] = s4.x; sc[q * 4 + 1] = s4.y; sc[q * 4 + 2] = s4.z; sc[q * 4 + 3] = s4.w;
+    sh[q * 4] = t4.x; sh[q * 4 + 1] = t4.y; sh[q * 4 + 2] = t4.z; sh[q * 4 + 3] = t4.w;
+  }
+  DwTiledArgs plain = a;  // dy is staged raw
+  plain.pro_mode = PRO_NONE;
+
+  float accw[9][VEC], s1[VEC], s2[VEC];
+#pragma unroll
+  for (int k = 0; k < 9; ++k)
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) accw[k][i] = 0.f;
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) s1[i] = s2[i] = 0.f;
+
+  for (int t = blockIdx.y; t < a.ntiles; t += gridDim.y) {
+    int n, h0, w0;
+    tile_coords(a, t, n, h0, w0);
+    raw_t raw[G::PER];
+    unsigned okmask;
+    {
+      DwTiledArgs d = plain;
+      d.ldx = a.lddy;
+      tile_issue<T, V, DIL>(d, DY, n, h0, w0, cv, raw, okmask);
+    }
+    // this thread's four x vectors (zero outside the image / channel range)
+    const int ho = h0 + row;
+    raw_t xraw[4];
+    const bool rok = cv < a.CV && ho < a.H;
+    const int hoc = min(ho, a.H - 1), cvc = min(cv, a.CV - 1);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int wo = w0 + strip * 4 + j;
+      xraw[j] = V::load_raw(X + (((long)n * a.H + hoc) * a.W + min(wo, a.W - 1)) * a.ldx + cvc * VEC);
+    }
+    __syncthreads();
+    tile_commit<T, V, DIL>(plain, tile, raw, okmask, psm);
+    __syncthreads();
+
+    float xa[4][VEC];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      V::unpack_raw(xraw[j], xa[j]);
+      if (a.pro_mode & PRO_AFFINE) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) xa[j][i] = fmaf(xa[j][i], sc[i], sh[i]);
+      }
+      if (a.pro_mode & PRO_RELU) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) xa[j][i] = fmaxf(xa[j][i], 0.f);
+      }
+      if (a.pro_mode & PRO_CLAMP6) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) xa[j][i] = fminf(xa[j][i], 6.f);
+      }
+      const bool ok = rok && (w0 + strip * 4 + j) < a.W;
+      if (!ok) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) xa[j][i] = 0.f;
+      }
+    }
+    float accg[4][VEC];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) accg[j][i] = 0.f;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      float wv[3][VEC];
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+        for (int q = 0; q < WQ; ++q) {
+          const float4 w4 = psm[((kh * 3 + kw) * LT_CVB + cx) * WQ + q];
+          wv[kw][q * 4] = w4.x; wv[kw][q * 4 + 1] = w4.y;
+          wv[kw][q * 4 + 2] = w4.z; wv[kw][q * 4 + 3] = w4.w;
+        }
+      const raw_t* trow = tile + ((row + kh * DIL) * G::IWP + strip * 4) * LT_CVB + cx;
+#pragma unroll
+      for (int q = 0; q < G::COLS; ++q) {
+        float v[VEC];
+        V::unpack_raw(trow[q * LT_CVB], v);
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int j = q - kw * DIL;
+          if (j >= 0 && j < 4) {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+              accg[j][i] = fmaf(v[i], wv[kw][i], accg[j][i]);
+              accw[kh * 3 + kw][i] = fmaf(v[i], xa[j][i], accw[kh * 3 + kw][i]);
+            }
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // mask, store, BatchNorm-backward sums
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int wo = w0 + strip * 4 + j;
+      if (rok && wo < a.W) {
+        float xr[VEC];
+        V::unpack_raw(xraw[j], xr);
+        if (a.pro_mode & PRO_RELU) {
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) {
+            const bool on = xa[j][i] > 0.f && (!(a.pro_mode & PRO_CLAMP6) || xa[j][i] < 6.f);
+            accg[j][i] = on ? accg[j][i] : 0.f;
+          }
+        }
+        V::store(GO + (((long)n * a.H + ho) * a.W + wo) * a.ldy + cv * VEC, accg[j]);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+          s1[i] += accg[j][i];
+          s2[i] = fmaf(accg[j][i], xr[i], s2[i]);
+        }
+      }
+    }
+  }
+
+  // ---- block reductions (rows of a wave by lane exchange, strips through LDS)
+#pragma unroll
+  for (int k = 0; k < 9; ++k)
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      float v = accw[k][i];
+      v += __shfl_xor(v, 8, 64);
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      accw[k][i] = v;
+    }
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    s1[i] += __shfl_xor(s1[i], 8, 64);  s1[i] += __shfl_xor(s1[i], 16, 64);
+    s1[i] += __shfl_xor(s1[i], 32, 64);
+    s2[i] += __shfl_xor(s2[i], 8, 64);  s2[i] += __shfl_xor(s2[i], 16, 64);
+    s2[i] += __shfl_xor(s2[i], 32, 64);
+  }
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(lt_smem);  // [4 strips][CVB][11 * VEC]
+  if (row == 0) {
+    float* mine = red + (strip * LT_CVB + cx) * 11 * VEC;
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) mine[k * VEC + i] = accw[k][i];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      mine[9 * VEC + i] = s1[i];
+      mine[10 * VEC + i] = s2[i];
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < LT_CVB * 11 * VEC; e += LT_THREADS) {
+    float tot = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) tot += red[s * LT_CVB * 11 * VEC + e];
+    const int lcx = e / (11 * VEC), k = e - lcx * 11 * VEC;
+    const int r = k / VEC, ci = k - r * VEC;
+    const int c = (cvb0 + lcx) * VEC + ci;
+    if (c < a.C) {
+      if (r < 9) a.partial[((long)blockIdx.y * 9 + (8 - r)) * a.C + c] = tot;  // LDS row r = tap 8-r
+      else if (a.partial_bn != nullptr) a.partial_bn[((long)blockIdx.y * 2 + (r - 9)) * a.C + c] = tot;
+    }
   }
 }
 
@@ -405,7 +611,7 @@ template <int DIL> static size_t tiled_lds(int dtype, bool with_weights) {
   const int vec = dtype == DT_BF16 ? 8 : 4;
   size_t b = (size_t)TileGeom<DIL>::TILE_VECS * 16;
   const size_t red_fwd = (size_t)LT_THREADS * 2 * vec * sizeof(float);
-  const size_t red_wg = (size_t)4 * LT_CVB * 9 * vec * sizeof(float);
+  const size_t red_wg = (size_t)4 * LT_CVB * 11 * vec * sizeof(float);
   if (b < red_fwd) b = red_fwd;
   if (b < red_wg) b = red_wg;
   (void)with_weights;
@@ -421,6 +627,7 @@ int launch_dw_tiled(int dtype, const void* x, long ldx, int N, int H, int W, int
   tiled_geom(a, dtype, N, H, W, C);
   a.w_layout = w_layout;
   a.x = x; a.w = w; a.y = y; a.dy = nullptr; a.sc = sc; a.sh = sh; a.partial = stat_partial;
+  a.partial_bn = nullptr;
   a.ldx = ldx; a.ldy = ldy; a.lddy = 0; a.pro_mode = pro_mode;
   const dim3 grid((a.CV + LT_CVB - 1) / LT_CVB, grid_y);
 #define SEG_LT(TT, DD) \
@@ -439,6 +646,7 @@ int launch_dw_wgrad_tiled(int dtype, const void* x, long ldx, int N, int H, int 
   tiled_geom(a, dtype, N, H, W, C);
   a.w_layout = 0;
   a.x = x; a.w = nullptr; a.y = nullptr; a.dy = dy; a.sc = sc; a.sh = sh; a.partial = partial;
+  a.partial_bn = nullptr;
   a.ldx = ldx; a.ldy = 0; a.lddy = lddy; a.pro_mode = pro_mode;
   const dim3 grid((a.CV + LT_CVB - 1) / LT_CVB, grid_y);
 #define SEG_LT(TT, DD) \
@@ -448,6 +656,28 @@ int launch_dw_wgrad_tiled(int dtype, const void* x, long ldx, int N, int H, int 
   else { if (dil == 1) SEG_LT(float, 1); else SEG_LT(float, 2); }
 #undef SEG_LT
   return check_launch("dwconv3x3_wgrad (tiled)");
+}
+
+
+int launch_dw_bwd_tiled(int dtype, const void* dy, long lddy, const void* x, long ldx, int N, int H,
+                        int W, int C, const float* w, int w_layout, int dil, int pro_mode,
+                        const float* sc, const float* sh, void* g, long ldg, float* partial_w,
+                        float* partial_bn, int grid_y, hipStream_t st) {
+  DwTiledArgs a;
+  tiled_geom(a, dtype, N, H, W, C);
+  a.CV = C / 4;               // HVec: 4 channels per thread in both element types
+  a.w_layout = w_layout ^ 2;  // taps staged flipped (bit 1 toggles the caller's orientation)
+  a.x = x; a.w = w; a.y = g; a.dy = dy; a.sc = sc; a.sh = sh;
+  a.partial = partial_w; a.partial_bn = partial_bn;
+  a.ldx = ldx; a.ldy = ldg; a.lddy = lddy; a.pro_mode = pro_mode;
+  const dim3 grid((a.CV + LT_CVB - 1) / LT_CVB, grid_y);
+#define SEG_LT(TT, DD) \
+  hipLaunchKernelGGL((dwconv_bwd_tiled_kernel<TT, DD>), grid, dim3(LT_THREADS), \
+                     tiled_lds<DD>(dtype, true), st, a)
+  if (dtype == DT_BF16) { if (dil == 1) SEG_LT(bf16_t, 1); else SEG_LT(bf16_t, 2); }
+  else { if (dil == 1) SEG_LT(float, 1); else SEG_LT(float, 2); }
+#undef SEG_LT
+  return check_launch("dwconv3x3_bwd_fused (tiled)");
 }
 
 }  // namespace seg

@@ -373,15 +373,19 @@ class _DwFn(torch.autograd.Function):
         if K.nhwc(dy)[4] % K.vec_of(dy.dtype) != 0:
             dy = dy.contiguous()
         dx = dgamma = dbeta = None
+        tiled = K.dw_tiled(s.stride, s.dil)
         big = x.numel() * x.element_size() >= (40 << 20)
-        if s.stride == 1 and ctx.needs_input_grad[0] and big:
+        if s.stride == 1 and ctx.needs_input_grad[0] and (tiled or big):
             # one pass over (dy, x): masked data gradient + weight-gradient partials + BN sums
-            # (tools/dw_bench.py, 269 MB entry-flow tensor: 400 us vs 149 + 176 + 91 us for the
-            # tiled dgrad + wgrad + BN-reduce kernels; on small tensors the separate kernels win)
+            # (LDS-tiled for dil <= 2; the strip version only pays on large tensors)
             bn = s.bn_in
-            w9c = cached_pack(weight, "dw", lambda: pack_dw_weight(weight))
-            g, dW9c, pb = K.dwconv_bwd_fused(x, dy, w9c, s.dil, s.pro, want_bn=bn is not None)
-            dW = dW9c.t().reshape(C, 1, 3, 3).contiguous()
+            if tiled:
+                g, dW, pb = K.dwconv_bwd_fused(x, dy, weight.detach(), s.dil, s.pro,
+                                               want_bn=bn is not None, torch_layout=True)
+            else:
+                w9c = cached_pack(weight, "dw", lambda: pack_dw_weight(weight))
+                g, dW9c, pb = K.dwconv_bwd_fused(x, dy, w9c, s.dil, s.pro, want_bn=bn is not None)
+                dW = dW9c.t().reshape(C, 1, 3, 3).contiguous()
             if bn is None:
                 dx = g  # plain / ReLU input: the masked gradient is final
             else:

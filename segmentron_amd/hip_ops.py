@@ -200,19 +200,28 @@ def dwconv_dgrad(dy, w9c, stride, dil, in_hw, flipped=True):
     return dx
 
 
-def dwconv_bwd_fused(x, dy, w9c, dil, pro=None, want_bn=False):
+def dwconv_bwd_fused(x, dy, w, dil, pro=None, want_bn=False, torch_layout=False):
     """stride-1 depthwise backward in one pass: returns (g masked by the prologue's ReLU,
-    dW fp32 [9, C], bn_partial fp32 [gy, 2C] | None)."""
+    dW fp32 [9, C] (or [C,1,3,3] with torch_layout), bn_partial fp32 [gy, 2C] | None).
+    w: tap-major [9, C] or (dil <= 2) the [C,1,3,3] parameter itself."""
     N, H, W, C, ldx = nhwc(x)
     lddy = nhwc(dy)[4]
     mode, ps, pt = _pro(pro)
     g = torch.empty((N, H, W, C), dtype=x.dtype, device=x.device)
-    # stride 0 = geometry of the strip kernels (the fused backward is one of them)
-    gy = LIB.query("seg_dwconv_grid_y", _DT[x.dtype], C, N, H, W, 0, dil)
+    tiled = dw_tiled(1, dil)
+    layout = 1 if w.dim() == 4 else 0
+    if layout and not tiled:
+        raise ValueError("depthwise strip kernels need tap-major [9, C] weights")
+    # stride 0 = geometry of the strip kernels
+    gy = LIB.query("seg_dwconv_grid_y", _DT[x.dtype], C, N, H, W, 1 if tiled else 0, dil)
     pw = torch.empty((gy, 9 * C), dtype=torch.float32, device=x.device)
     pb = torch.empty((gy, 2 * C), dtype=torch.float32, device=x.device) if want_bn else None
     LIB.call("seg_dwconv3x3_bwd_fused", _DT[x.dtype], _p(dy), lddy, _p(x), ldx, N, H, W, C,
-             _p(w9c), dil, mode, _p(ps), _p(pt), _p(g), C, _p(pw), _p(pb), gy, _stream())
+             _p(w), layout, dil, mode, _p(ps), _p(pt), _p(g), C, _p(pw), _p(pb), gy, _stream())
+    if torch_layout:
+        dW = torch.empty((C, 1, 3, 3), dtype=torch.float32, device=x.device)
+        LIB.call("seg_dwconv3x3_wgrad_finalize", _p(pw), gy, C, _p(dW), _stream())
+        return g, dW, pb
     return g, colsum(pw, f64=False).view(9, C), pb
 
 

@@ -202,6 +202,12 @@ def test_dwconv_fwd_dgrad_wgrad(case, dtype):
         assert_close(dW4.cpu(), dW.t().reshape(C, 1, 3, 3).cpu().double(), torch.float32, "dw wgrad layout", fac=2)
     if stride == 1:  # fused one-pass backward: masked dgrad + wgrad + BN-backward sums
         gf, dWf, pb = K().dwconv_bwd_fused(to_dev_nhwc(x, dtype), dyd, w9c, dil, pro, want_bn=True)
+        if K().dw_tiled(stride, dil):  # same kernel fed with the [C,1,3,3] parameter
+            g4, dW4, pb4 = K().dwconv_bwd_fused(to_dev_nhwc(x, dtype), dyd, w.to(DEV), dil, pro,
+                                                want_bn=True, torch_layout=True)
+            assert torch.equal(g4, gf) and torch.equal(pb4, pb)
+            assert_close(dW4.cpu(), dWf.t().reshape(C, 1, 3, 3).cpu().double(), torch.float32,
+                         "fused dw wgrad layout", fac=2)
         mask = (xa.detach() > 0).double() if (mode & 1) else torch.ones_like(xa.detach())
         gref = xa.grad * mask
         assert_close(to_cpu_nchw(gf), gref, dtype, "fused dw dgrad")
