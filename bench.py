@@ -12,11 +12,13 @@ all-reduces when N > 1) -> SGD step, on BASELINE.json configs[2]: batch 2 per GP
 init weights, bf16 compute path (fp32 accumulation / statistics / master weights / logits).
 Inputs are resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
 
-roofline: the dominant kernel is the MFMA implicit-GEMM `conv_gemm_fwd_kernel` (all 1x1 / dense
-convolutions forward + all their data gradients).  `achieved` = algorithmic FLOPs
+roofline: the dominant kernel is the MFMA implicit-GEMM `conv_gemm_px256_kernel` (every 1x1
+stride-1 convolution with O >= 384, forward + data gradient: the Xception middle / exit flow and
+ASPP — 120 of the ~157 GEMM launches per step).  `achieved` = algorithmic FLOPs
 (2 * output pixels * K * O per launch — SURVEY.md §8d counts conv MACs only) summed over its
 launches inside the timed region / summed launch durations measured with HIP events on the
-launch stream.  `traffic` is filled from profiles/ (rocprofv3 PMC pass) when available.
+launch stream; the figure over ALL forward/dgrad GEMM launches is reported beside it
+(`all_gemm_*`).  `traffic` is filled from profiles/ (rocprofv3 PMC pass) when available.
 
 cpu_baseline: the CPU oracle (oracle/torch_ref.py — bit-identical to the reference's module graph
 on CPU, see oracle/gen_golden.py; the reference tree itself is not on the GPU box) timed on the
@@ -53,6 +55,7 @@ class GemmTimer:
         self.K = hip_ops
         self.orig = hip_ops.conv_gemm
         self.events, self.flops, self.active = [], 0.0, False
+        self.events_all, self.flops_all = [], 0.0
         hip_ops.conv_gemm = self._wrapped
 
     def _wrapped(self, x, w_packed, O, KH, KW, stride, pad, dil, *a, **kw):
@@ -65,13 +68,23 @@ class GemmTimer:
         n, hi, wi, c = x.shape
         ho = self.K.conv_out_size(hi, KH, stride, pad, dil)
         wo = self.K.conv_out_size(wi, KW, stride, pad, dil)
-        self.flops += 2.0 * n * ho * wo * KH * KW * c * O
-        self.events.append((e0, e1))
+        fl = 2.0 * n * ho * wo * KH * KW * c * O
+        self.flops_all += fl
+        self.events_all.append((e0, e1))
+        # the dispatch rule of seg_conv_gemm_fwd (csrc/conv_gemm_fwd.hip: gemm_use_px256)
+        if (KH * KW == 1 and stride == 1 and pad == 0 and O >= 384 and n * ho * wo >= 4096
+                and kw.get("scatter") is None and kw.get("tconv_out_hw") is None):
+            self.flops += fl
+            self.events.append((e0, e1))
         return y, p
 
     def result(self):
         ms = sum(a.elapsed_time(b) for a, b in self.events)
         return self.flops, ms * 1e-3, len(self.events)
+
+    def result_all(self):
+        ms = sum(a.elapsed_time(b) for a, b in self.events_all)
+        return self.flops_all, ms * 1e-3, len(self.events_all)
 
 
 def cpu_baseline():
@@ -185,7 +198,8 @@ def main():
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get("conv_gemm_fwd_bytes_per_launch")
+            traffic = json.load(open(tpath)).get("conv_gemm_px256_bytes_per_launch")
+        fa, sa, la = timer.result_all()
         full = (args.height, args.width) == (H, W)
         line = {
             "metric": "images/sec fwd+bwd DeepLabv3+_xception65 @1025x2049",
@@ -200,13 +214,16 @@ def main():
                        "loss": float(loss.item())},
             "model_flop_fraction_of_bf16_mfma_peak":
                 value / world * FLOP_FWD_BWD_PER_IMAGE / MFMA_BF16_PEAK if full else None,
-            "roofline": {"bound": "mfma", "kernel": "conv_gemm_fwd_kernel<%s>" % args.dtype,
+            "roofline": {"bound": "mfma", "kernel": "conv_gemm_px256_kernel<%s>" % args.dtype,
                          "achieved": achieved, "peak": MFMA_BF16_PEAK / 1e12 if
                          args.dtype == "bf16" else 157.3, "unit": "TFLOP/s",
                          "frac": achieved / (MFMA_BF16_PEAK / 1e12 if args.dtype == "bf16"
                                              else 157.3),
                          "traffic": traffic, "launches_per_step": launches / max(args.steps, 1),
-                         "kernel_ms_per_step": secs * 1e3 / max(args.steps, 1)},
+                         "kernel_ms_per_step": secs * 1e3 / max(args.steps, 1),
+                         "all_gemm_achieved": fa / sa / 1e12 if sa > 0 else 0.0,
+                         "all_gemm_launches_per_step": la / max(args.steps, 1),
+                         "all_gemm_ms_per_step": sa * 1e3 / max(args.steps, 1)},
         }
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline()

@@ -169,9 +169,13 @@ int seg_bn_bwd_apply(int dtype, const void* g, long ldg, const void* x, long ldx
  *                caller between the two calls under SyncBN. */
 int seg_fold_weights(int dtype, const float* W, const float* scale, const float* shift, void* Wp,
                      void* WpT, float* bprime, int O, int C, void* stream);
-int seg_fold_bwd_reduce(const float* W, const float* dWp, const float* scale, const float* shift,
-                        const float* db, float* dW, float* dsdt, int O, int C, void* stream);
-int seg_fold_bwd_finalize(const float* dsdt, double count, const float* mean, const float* invstd,
+/* dWp: the weight-gradient split partials [splits][O*C] as written by seg_conv_gemm_wgrad (summed
+ * here); dsdt: [seg_fold_bwd_rows(O)][2][C] partial (ds, dt) rows, summed by the finalize. */
+int seg_fold_bwd_rows(int O);
+int seg_fold_bwd_reduce(const float* W, const float* dWp, int splits, const float* scale,
+                        const float* shift, const float* db, float* dW, float* dsdt, int O, int C,
+                        void* stream);
+int seg_fold_bwd_finalize(const float* dsdt, int rows, double count, const float* mean, const float* invstd,
                           const float* gamma, const float* scale, float* dgamma, float* dbeta,
                           float* c0, float* c1, int C, void* stream);
 

@@ -14,6 +14,7 @@
 // The BatchNorm(+ReLU) prologue of the forward pass is re-applied to X on the fly (the
 // activated tensor is never materialised in HBM, forward or backward).
 #include "conv_gemm.h"
+#include <cstdlib>
 
 namespace seg {
 
@@ -261,7 +262,11 @@ extern "C" int seg_conv_gemm_wgrad_splits(int dtype, int N, int Ho, int Wo, int 
   const int bkp = dtype == DT_BF16 ? 64 : 32;
   const long M = (long)N * Ho * Wo;
   const int tiles = ((O + BM - 1) / BM) * ((K + BN - 1) / BN);
-  long want = (g_wgrad_dbuf ? 512 : 768) / tiles;  // resident blocks: 2 (two stages) or 3 per CU
+  static const int target = [] {
+    const char* e = getenv("SEG_WGRAD_BLOCKS");  // experiment knob: total blocks aimed for
+    return e ? atoi(e) : 0;
+  }();
+  long want = (target > 0 ? target : (g_wgrad_dbuf ? 512 : 768)) / tiles;  // 2 or 3 blocks per CU
   long maxs = (M + 8 * bkp - 1) / (8 * bkp);       // at least 8 slabs per split
   if (maxs < 1) maxs = 1;
   if (want > maxs) want = maxs;

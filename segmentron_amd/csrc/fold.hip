@@ -36,41 +36,55 @@ __global__ __launch_bounds__(256) void fold_weights_kernel(const float* __restri
   if (lane == 0 && bprime) bprime[o] = acc;
 }
 
-// block: 8 columns (c) x 32 row groups (o) -> C/8 blocks, O/32 serial iterations
+// dWp arrives as the weight-gradient GEMM's split partials [S][O*C] (summed here in a fixed
+// order: the separate column-sum pass and its 2x2 MB round trip are gone).  Lanes run along c
+// (256 contiguous bytes per row and wave), a block owns 64 columns x one of RS row ranges and
+// emits one row of (ds, dt) partials: dsdt[rs][2][C], summed by fold_bwd_finalize.
+constexpr int FOLD_RS = 32;
 __global__ __launch_bounds__(256) void fold_bwd_reduce_kernel(
-    const float* __restrict__ W, const float* __restrict__ dWp, const float* __restrict__ s,
+    const float* __restrict__ W, const float* __restrict__ dWp, int S, const float* __restrict__ s,
     const float* __restrict__ t, const float* __restrict__ db, float* __restrict__ dW,
     float* __restrict__ dsdt, int O, int C) {
-  __shared__ float red[2][32][9];
-  const int cx = threadIdx.x & 7, ry = threadIdx.x >> 3;
-  const int c = blockIdx.x * 8 + cx;
+  __shared__ float red[2][4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  const int rows_per = (O + gridDim.y - 1) / gridDim.y;
+  const int o0 = blockIdx.y * rows_per, o1 = min(O, o0 + rows_per);
+  const long OC = (long)O * C;
   float a0 = 0.f, a1 = 0.f;
   if (c < C) {
     const float sc = s[c], tc = t[c];
-    for (int o = ry; o < O; o += 32) {
-      const float w = W[(long)o * C + c], g = dWp[(long)o * C + c];
+    for (int o = o0 + wave; o < o1; o += 4) {
+      const long idx = (long)o * C + c;
+      // the splits are summed in a fixed order, eight independent loads in flight at a time
+      float g = 0.f;
+      int k = 0;
+      for (; k + 8 <= S; k += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = dWp[(long)(k + u) * OC + idx];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) g += v[u];
+      }
+      for (; k < S; ++k) g += dWp[(long)k * OC + idx];
+      const float w = W[idx];
       const float dbo = db ? db[o] : 0.f;
-      dW[(long)o * C + c] = fmaf(g, sc, dbo * tc);
+      dW[idx] = fmaf(g, sc, dbo * tc);
       a0 = fmaf(w, g, a0);
       a1 = fmaf(w, dbo, a1);
     }
   }
-  red[0][ry][cx] = a0;
-  red[1][ry][cx] = a1;
+  red[0][wave][lane] = a0;
+  red[1][wave][lane] = a1;
   __syncthreads();
-  if (ry == 0 && c < C) {
-    float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-    for (int k = 0; k < 32; ++k) {
-      s0 += red[0][k][cx];
-      s1 += red[1][k][cx];
-    }
-    dsdt[c] = s0;
-    dsdt[C + c] = s1;
+  if (wave == 0 && c < C) {
+    float* dst = dsdt + (long)blockIdx.y * 2 * C;
+    dst[c] = red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane];
+    dst[C + c] = red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane];
   }
 }
 
-__global__ void fold_bwd_finalize_kernel(const float* __restrict__ dsdt, double count,
+__global__ void fold_bwd_finalize_kernel(const float* __restrict__ dsdt, int R, double count,
                                          const float* __restrict__ mean,
                                          const float* __restrict__ invstd,
                                          const float* __restrict__ gamma,
@@ -78,7 +92,22 @@ __global__ void fold_bwd_finalize_kernel(const float* __restrict__ dsdt, double 
                                          float* dbeta, float* c0, float* c1, int C) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  const double ds = dsdt[c], dt = dsdt[C + c];
+  double ds = 0.0, dt = 0.0;
+  int r = 0;
+  for (; r + 8 <= R; r += 8) {  // eight independent row loads in flight
+    float a[8], b[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      a[u] = dsdt[(long)(r + u) * 2 * C + c];
+      b[u] = dsdt[(long)(r + u) * 2 * C + C + c];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { ds += (double)a[u]; dt += (double)b[u]; }
+  }
+  for (; r < R; ++r) {
+    ds += (double)dsdt[(long)r * 2 * C + c];
+    dt += (double)dsdt[(long)r * 2 * C + C + c];
+  }
   const double mu = mean[c], is = invstd[c];
   const double g = gamma ? (double)gamma[c] : 1.0;
   const double u = ds - mu * dt;
@@ -106,24 +135,28 @@ extern "C" int seg_fold_weights(int dtype, const float* W, const float* scale, c
   return check_launch("fold_weights");
 }
 
-extern "C" int seg_fold_bwd_reduce(const float* W, const float* dWp, const float* scale,
+extern "C" int seg_fold_bwd_rows(int O) {
+  return O < 4 * seg::FOLD_RS ? 1 : seg::FOLD_RS;
+}
+
+extern "C" int seg_fold_bwd_reduce(const float* W, const float* dWp, int splits, const float* scale,
                                    const float* shift, const float* db, float* dW, float* dsdt,
                                    int O, int C, void* stream) {
   using namespace seg;
-  SEG_REQUIRE(O >= 1 && C >= 1, "fold_bwd_reduce: empty");
-  hipLaunchKernelGGL(fold_bwd_reduce_kernel, dim3((C + 7) / 8), dim3(256), 0,
-                     (hipStream_t)stream, W, dWp, scale, shift, db, dW, dsdt, O, C);
+  SEG_REQUIRE(O >= 1 && C >= 1 && splits >= 1, "fold_bwd_reduce: empty");
+  hipLaunchKernelGGL(fold_bwd_reduce_kernel, dim3((C + 63) / 64, seg_fold_bwd_rows(O)), dim3(256),
+                     0, (hipStream_t)stream, W, dWp, splits, scale, shift, db, dW, dsdt, O, C);
   return check_launch("fold_bwd_reduce");
 }
 
-extern "C" int seg_fold_bwd_finalize(const float* dsdt, double count, const float* mean,
+extern "C" int seg_fold_bwd_finalize(const float* dsdt, int rows, double count, const float* mean,
                                      const float* invstd, const float* gamma, const float* scale,
                                      float* dgamma, float* dbeta, float* c0, float* c1, int C,
                                      void* stream) {
   using namespace seg;
-  SEG_REQUIRE(count >= 1.0 && C >= 1, "fold_bwd_finalize: bad count/C");
-  hipLaunchKernelGGL(fold_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0,
-                     (hipStream_t)stream, dsdt, count, mean, invstd, gamma, scale, dgamma, dbeta,
+  SEG_REQUIRE(count >= 1.0 && C >= 1 && rows >= 1, "fold_bwd_finalize: bad count/C/rows");
+  hipLaunchKernelGGL(fold_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0,
+                     (hipStream_t)stream, dsdt, rows, count, mean, invstd, gamma, scale, dgamma, dbeta,
                      c0, c1, C);
   return check_launch("fold_bwd_finalize");
 }

@@ -321,12 +321,13 @@ class _FoldConvFn(torch.autograd.Function):
         O, C = weight.shape[0], weight.shape[1]
         if K.nhwc(dy)[4] % K.vec_of(dy.dtype) != 0:
             dy = dy.contiguous()
-        dwp = K.conv_wgrad(x, dy, O, 1, 1, s.stride, 0, 1, None)
+        dwp = K.conv_wgrad(x, dy, O, 1, 1, s.stride, 0, 1, None, raw_partial=True)
         db = None
         if not s.drop_const:  # eval-mode consumer: the constant term carries gradient
             db = K.bn_bwd_reduce(dy, dy, (PRO_NONE, None, None))[:O].float()
         dW, dsdt = K.fold_bwd_reduce(weight.detach().view(O, C), dwp, bn.scale, bn.shift, db)
         if bn.group is not None:
+            dsdt = K.colsum(dsdt, f64=False)
             parallel.allreduce_backward_sums(dsdt, bn.group)
         dgamma, dbeta, c0, c1 = K.fold_bwd_finalize(dsdt, bn.count, bn.mean, bn.invstd, bn.gamma,
                                                     bn.scale)

@@ -128,7 +128,7 @@ def colsum(partial2d, f64=True):
     return out
 
 
-def conv_wgrad(x, dy, O, KH, KW, stride, pad, dil, pro=None):
+def conv_wgrad(x, dy, O, KH, KW, stride, pad, dil, pro=None, raw_partial=False):
     """-> dW fp32 [O, KH*KW*C]."""
     N, Hi, Wi, C, ldx = nhwc(x)
     Nd, Ho, Wo, Od, lddy = nhwc(dy)
@@ -139,6 +139,8 @@ def conv_wgrad(x, dy, O, KH, KW, stride, pad, dil, pro=None):
     partial = torch.empty((splits, O * K), dtype=torch.float32, device=x.device)
     LIB.call("seg_conv_gemm_wgrad", _DT[x.dtype], _p(x), ldx, N, Hi, Wi, C, _p(dy), lddy, Ho, Wo,
              O, KH, KW, stride, pad, dil, mode, _p(ps), _p(pt), _p(partial), splits, _stream())
+    if raw_partial:  # [splits, O*K]: the consumer sums the splits itself (fold_bwd_reduce)
+        return partial
     if splits == 1:
         return partial.view(O, K)
     return colsum(partial, f64=False).view(O, K)
@@ -383,11 +385,15 @@ def fold_weights(w2d, scale, shift, dtype, want_transpose=False, want_bias=True)
 
 
 def fold_bwd_reduce(w2d, dwp, scale, shift, db=None):
-    """-> (dW fp32 [O,C], dsdt fp32 [2C])."""
+    """dwp: dW' [O, C] or the weight-gradient split partials [S, O*C].
+    -> (dW fp32 [O,C], dsdt fp32 [R, 2C] partial rows for fold_bwd_finalize)."""
     O, C = w2d.shape
+    S = 1 if tuple(dwp.shape) == (O, C) else dwp.shape[0]
+    assert dwp.numel() == S * O * C and dwp.is_contiguous()
     dW = torch.empty((O, C), dtype=torch.float32, device=w2d.device)
-    dsdt = torch.empty(2 * C, dtype=torch.float32, device=w2d.device)
-    LIB.call("seg_fold_bwd_reduce", _p(w2d), _p(dwp), _p(scale), _p(shift), _p(db), _p(dW),
+    R = LIB.query("seg_fold_bwd_rows", O)
+    dsdt = torch.empty((R, 2 * C), dtype=torch.float32, device=w2d.device)
+    LIB.call("seg_fold_bwd_reduce", _p(w2d), _p(dwp), S, _p(scale), _p(shift), _p(db), _p(dW),
              _p(dsdt), O, C, _stream())
     return dW, dsdt
 
@@ -395,7 +401,8 @@ def fold_bwd_reduce(w2d, dwp, scale, shift, db=None):
 def fold_bwd_finalize(dsdt, count, mean, invstd, gamma, scale):
     C = mean.numel()
     out = torch.empty((4, C), dtype=torch.float32, device=mean.device)
-    LIB.call("seg_fold_bwd_finalize", _p(dsdt), float(count), _p(mean), _p(invstd), _p(gamma),
+    dsdt = dsdt.view(-1, 2 * C)
+    LIB.call("seg_fold_bwd_finalize", _p(dsdt), dsdt.shape[0], float(count), _p(mean), _p(invstd), _p(gamma),
              _p(scale), _p(out[0]), _p(out[1]), _p(out[2]), _p(out[3]), C, _stream())
     return out[0], out[1], out[2], out[3]  # dgamma, dbeta, c0, c1
 

@@ -390,6 +390,14 @@ def test_fold_linear_bn_into_pointwise_matches_autograd(dtype):
     db = dy.sum((0, 2, 3)).to(DEV)  # general case: the constant term W@shift carries gradient
     dW, dsdt = Km.fold_bwd_reduce(w2d, dwp, scale, shift, db)
     dgamma, dbeta, c0, c1 = Km.fold_bwd_finalize(dsdt, N * H * W, mean, invstd, gd, scale)
+    # the same from the weight-gradient GEMM's split partials [S, O*C] (summed inside)
+    parts = Km.conv_wgrad(xd, dyd, O, 1, 1, 1, 0, 1, None, raw_partial=True)
+    fake = torch.stack([parts.sum(0) * 0.25, parts.sum(0) * 0.5, parts.sum(0) * 0.25])
+    for pp in (parts, fake):
+        dW2, dsdt2 = Km.fold_bwd_reduce(w2d, pp.contiguous(), scale, shift, db)
+        assert_close(dW2.cpu(), dW.cpu().double(), torch.float32, "fold dW from splits", fac=5)
+        assert_close(dsdt2.sum(0).cpu(), dsdt.sum(0).cpu().double(), torch.float32,
+                     "fold dsdt from splits", fac=20)
     dx, _ = Km.conv_gemm(dyd, wpt, C, 1, 1, 1, 0, 1, ep=(xd, c0, c1))
     assert_close(dW.view(O, C, 1, 1).cpu(), wr.grad, torch.float32, "folded dW", fac=50)
     assert_close(dgamma.cpu(), gr.grad, torch.float32, "folded dgamma", fac=50)
