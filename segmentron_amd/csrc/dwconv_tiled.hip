@@ -21,6 +21,9 @@
 namespace seg {
 
 constexpr int LT_TH = 8, LT_TW = 16, LT_CVB = 8, LT_THREADS = 256;
+#ifndef DW_BWD_OCC
+#define DW_BWD_OCC 2
+#endif
 
 struct DwTiledArgs {
   const void* x;       // tensor the taps read (fwd: input, dgrad: dy)
@@ -364,7 +367,7 @@ __global__ __launch_bounds__(LT_THREADS, 2) void dwconv_wgrad_tiled_kernel(const
 // with tap 8 - r of the weight gradient.  Replaces dgrad + wgrad + bn_bwd_reduce (three passes
 // over two tensors each).
 template <typename T, int DIL>
-__global__ __launch_bounds__(LT_THREADS, 2) void dwconv_bwd_tiled_kernel(const DwTiledArgs a) {
+__global__ __launch_bounds__(LT_THREADS, DW_BWD_OCC) void dwconv_bwd_tiled_kernel(const DwTiledArgs a) {
   // 4 channels per thread in both element types (8-byte bf16 vectors): this kernel carries nine
   // tap accumulators per channel on top of the data-gradient accumulators
   using G = TileGeom<DIL>;

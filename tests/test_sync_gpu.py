@@ -1,0 +1,116 @@
+"""GPU, world_size 2 on ONE device (gloo transport — RCCL refuses two ranks per GPU): the full
+data-parallel path of tools/train.py:73-79,108-111 — nn.SyncBatchNorm.convert_sync_batchnorm +
+DistributedDataParallel around the HIP model — must reproduce the single-process full-batch
+step: each rank's logits equal its slice of the full-batch logits, and the DDP-averaged
+gradients equal the full-batch gradients (HRNet-W18-small, fp32: the least chaotic of the five
+configs, see tests/test_more_models.py)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+H, W, PER = 64, 128, 2
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _build():
+    import segmentron_amd
+    import test_more_models as T
+    model, _ = T._build_hip("c5", torch.float32, True)
+    return model
+
+
+def _data(world):
+    from oracle import synth
+    x = synth.synth_images(PER * world, H, W, seed=3)
+    y = synth.synth_targets(PER * world, H, W, seed=3).clamp_min(0)  # no ignore: equal counts
+    return x, y
+
+
+def _worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        model = _build()
+        model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
+        ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0], output_device=0)
+        x, y = _data(world)
+        xs, ys = x[rank * PER:(rank + 1) * PER].cuda(), y[rank * PER:(rank + 1) * PER].cuda()
+        out = ddp(xs)
+        loss = torch.nn.functional.cross_entropy(out[0], ys)
+        loss.backward()
+        torch.cuda.synchronize()
+        ret[rank] = {"logits": out[0].detach().cpu(), "loss": loss.item(),
+                     "grads": {k: p.grad.detach().cpu() for k, p in model.named_parameters()},
+                     "rm": {k: v.detach().cpu() for k, v in model.state_dict().items()
+                            if k.endswith("running_mean") or k.endswith("running_var")}}
+    finally:
+        dist.destroy_process_group()
+
+
+def test_syncbn_ddp_two_ranks_match_full_batch():
+    world = 2
+    # single-process full batch, plain BatchNorm
+    model = _build()
+    x, y = _data(world)
+    out = model(x.cuda())
+    loss = torch.nn.functional.cross_entropy(out[0], y.cuda())
+    loss.backward()
+    ref_logits = out[0].detach().cpu()
+    ref_grads = {k: p.grad.detach().cpu() for k, p in model.named_parameters()}
+    ref_stats = {k: v.detach().cpu() for k, v in model.state_dict().items()
+                 if k.endswith("running_mean") or k.endswith("running_var")}
+    ref_loss = loss.item()
+    del model, out, loss
+    torch.cuda.empty_cache()
+
+    ctx = mp.get_context("spawn")
+    mgr = ctx.Manager()
+    ret = mgr.dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    # forward: each rank's logits = its slice; mean of the rank losses = full-batch loss
+    for r in range(world):
+        sl = ref_logits[r * PER:(r + 1) * PER]
+        rel = ((ret[r]["logits"] - sl).abs().max() / sl.abs().max()).item()
+        print("rank %d logits max-rel vs full batch %.3e" % (r, rel))
+        assert rel < 1e-3
+    assert abs(sum(ret[r]["loss"] for r in range(world)) / world - ref_loss) < 1e-4 * ref_loss
+    # running statistics: global mean / unbiased variance over the full batch on every rank
+    for k, v in ref_stats.items():
+        for r in range(world):
+            assert (ret[r]["rm"][k] - v).abs().max().item() <= 1e-3 * v.abs().max().item() + 1e-6, k
+    # backward: DDP-averaged gradients identical on both ranks and equal to the full-batch ones
+    num = den = 0.0
+    rels = []
+    for k, g in ref_grads.items():
+        g0, g1 = ret[0]["grads"][k], ret[1]["grads"][k]
+        assert torch.equal(g0, g1), k
+        e, n = (g0.double() - g.double()).norm().item(), g.double().norm().item()
+        num, den = num + e * e, den + n * n
+        rels.append(e / max(n, 1e-30))
+    rels.sort()
+    print("gradients vs full batch: global rel err %.3e, median per-tensor %.3e, worst %.3e"
+          % ((num / den) ** 0.5, rels[len(rels) // 2], rels[-1]))
+    # (ReLU near-ties can move single tensors by percents — see test_more_models.py)
+    assert (num / den) ** 0.5 < 6e-2 and rels[len(rels) // 2] < 2e-3
