@@ -56,7 +56,12 @@ class SegBaseModel(nn.Module):
             if crop is not None:
                 assert crop[0] >= h and crop[1] >= w
                 ch, cw = int(math.ceil(crop[0] * scale)), int(math.ceil(crop[1] * scale))
-                cur = TF.pad(cur, (0, max(cw - width, 0), 0, max(ch - height, 0)))
+                padh, padw = max(ch - height, 0), max(cw - width, 0)
+                # as the reference's _pad_image (segbase.py:88-95): F.pad(img, (0, padh, 0, padw))
+                # — i.e. the WIDTH grows by padh and the HEIGHT by padw (kept for parity; equal
+                # for the configs' square-ish crops, e.g. 1025x2049 around 1024x2048)
+                if padh or padw:
+                    cur = TF.pad(cur, (0, padh, 0, padw))
             out = self.forward(cur)[0][..., :height, :width]
             if flip:
                 out = out + self.forward(cur.flip(3))[0].flip(3)[..., :height, :width]
