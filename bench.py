@@ -152,8 +152,12 @@ def main():
         model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local],
                                                           output_device=local)
     params = [{"params": model.parameters(), "lr": cfg.SOLVER.LR}]
-    opt = torch.optim.SGD(params, lr=cfg.SOLVER.LR, momentum=cfg.SOLVER.MOMENTUM,
-                          weight_decay=cfg.SOLVER.WEIGHT_DECAY)
+    sgd = dict(lr=cfg.SOLVER.LR, momentum=cfg.SOLVER.MOMENTUM,
+               weight_decay=cfg.SOLVER.WEIGHT_DECAY)  # solver/optimizer.py:45-66
+    try:  # torch's single-kernel multi-tensor SGD (same update rule; 27 launches -> a few)
+        opt = torch.optim.SGD(params, fused=True, **sgd)
+    except (TypeError, RuntimeError, ValueError):
+        opt = torch.optim.SGD(params, **sgd)
 
     g = torch.Generator().manual_seed(rank)
     images = torch.randn(BATCH, 3, args.height, args.width, generator=g).to(dev)
