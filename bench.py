@@ -22,7 +22,7 @@ launch stream; the figure over ALL forward/dgrad GEMM launches is reported besid
 
 cpu_baseline: the CPU oracle (oracle/torch_ref.py — bit-identical to the reference's module graph
 on CPU, see oracle/gen_golden.py; the reference tree itself is not on the GPU box) timed on the
-host cores of rank 0 on a bounded sample (same network, same train step, batch 2 at 257x513,
+host cores of rank 0 on a bounded sample (same network, same train step, batch 2 at 513x1025,
 1 warm-up + 1 timed, <= 32 threads) and scaled by the pixel ratio to 1025x2049-equivalent images/sec.
 """
 import argparse
@@ -90,7 +90,7 @@ class GemmTimer:
 def cpu_baseline():
     from oracle import synth, torch_ref
     import segmentron_amd
-    h, w = 257, 513
+    h, w = 513, 1025  # a quarter of the pixels of the full-size step: ~10-20 s of CPU work
     threads = min(32, os.cpu_count() or 1)  # oneDNN collapses when oversubscribed (256-core host)
     torch.set_num_threads(threads)
     model = segmentron_amd.get_segmentation_model()
@@ -109,8 +109,8 @@ def cpu_baseline():
     return {"value": BATCH * ratio / times[-1], "unit": "images/sec (1025x2049-equivalent)",
             "cores": threads, "host_cores": os.cpu_count(), "kind": "port",
             "sample": "oracle (torch CPU fp32 restatement of the reference graph) train fwd+bwd, "
-                      "batch 2 @257x513, 1 warm-up + 1 timed (%.1f s), scaled by pixel ratio %.4f"
-                      % (times[-1], ratio)}
+                      "batch 2 @%dx%d, 1 warm-up + 1 timed (%.1f s), scaled by pixel ratio %.4f"
+                      % (h, w, times[-1], ratio)}
 
 
 def main():
