@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Inference throughput of the other BASELINE configs on one MI355X (evidence, not the bench
+line): C2 DeepLabv3+ mobilenet_v2 @1024x2048 B=1, C5 HRNet-W18-small-v1 @1024x2048 B=16,
+C4 PSPNet-resnet101 / C1 FCN-resnet101 eval at 1025x2049 / 480x480.  bf16, random init."""
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import segmentron_amd  # noqa: E402
+from segmentron_amd.config import cfg, reset_cfg  # noqa: E402
+
+CASES = {
+    "c2": (["MODEL.MODEL_NAME", "DeepLabV3_Plus", "MODEL.BACKBONE", "mobilenet_v2",
+            "MODEL.DEEPLABV3_PLUS.USE_ASPP", "False", "MODEL.DEEPLABV3_PLUS.ENABLE_DECODER", "False"],
+           None, 1, 1024, 2048),
+    "c5": ([], "configs/cityscapes_hrnet_w18_small_v1.yaml", 16, 1024, 2048),
+    "c1": (["MODEL.MODEL_NAME", "FCN", "MODEL.BACKBONE", "resnet101"], None, 1, 480, 480),
+    "c4": (["MODEL.MODEL_NAME", "PSPNet", "MODEL.BACKBONE", "resnet101", "MODEL.OUTPUT_STRIDE", "8"],
+           None, 1, 1025, 2049),
+}
+
+
+def main():
+    which = sys.argv[1:] or list(CASES)
+    for tag in which:
+        over, yaml_, B, H, W = CASES[tag]
+        reset_cfg()
+        if yaml_:
+            cfg.update_from_file(os.path.join(ROOT, yaml_))
+        cfg.update_from_list(["DATASET.NAME", "cityscape", "TRAIN.BACKBONE_PRETRAINED", "False"] + over)
+        cfg.PHASE = "test"
+        cfg.check_and_freeze()
+        segmentron_amd.set_compute_dtype("bf16")
+        torch.manual_seed(0)
+        model = segmentron_amd.get_segmentation_model().cuda().eval()
+        x = torch.randn(B, 3, H, W, device="cuda")
+        with torch.no_grad():
+            for _ in range(2):
+                out = model(x)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            n = 5
+            for _ in range(n):
+                out = model(x)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / n
+        print(json.dumps({"config": tag, "model": cfg.MODEL.MODEL_NAME, "backbone": cfg.MODEL.BACKBONE,
+                          "batch": B, "size": [H, W], "ms_per_batch": dt * 1e3,
+                          "images_per_sec": B / dt, "finite": bool(torch.isfinite(out[0]).all()),
+                          "out_shape": list(out[0].shape)}), flush=True)
+        del model, out, x
+        torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    main()
