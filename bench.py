@@ -128,11 +128,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
+    # SEG_BENCH_ONE_DEVICE=1 (test plumbing): every rank on device 0 over gloo, to exercise the
+    # N > 1 code path on a single-GPU box (RCCL refuses two ranks per device)
+    one_dev = os.environ.get("SEG_BENCH_ONE_DEVICE") == "1"
+    if one_dev:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", init_method="env://", device_id=dev)
+        if one_dev:
+            dist.init_process_group("gloo", init_method="env://")
+        else:
+            dist.init_process_group("nccl", init_method="env://", device_id=dev)
 
     import segmentron_amd
     from segmentron_amd.config import cfg, reset_cfg

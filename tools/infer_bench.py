@@ -25,8 +25,47 @@ CASES = {
 }
 
 
+def train_c4():
+    """BASELINE C4: PSPNet-resnet101 (OS8, aux loss) train step fwd+bwd, B=2 @1025x2049."""
+    reset_cfg()
+    cfg.update_from_list(["DATASET.NAME", "cityscape", "TRAIN.BACKBONE_PRETRAINED", "False",
+                          "MODEL.MODEL_NAME", "PSPNet", "MODEL.BACKBONE", "resnet101",
+                          "MODEL.OUTPUT_STRIDE", "8", "SOLVER.AUX", "True"])
+    cfg.PHASE = "train"
+    cfg.check_and_freeze()
+    segmentron_amd.set_compute_dtype("bf16")
+    torch.manual_seed(0)
+    model = segmentron_amd.get_segmentation_model().cuda().train()
+    B, H, W = 2, 1025, 2049
+    x = torch.randn(B, 3, H, W, device="cuda")
+    y = torch.randint(0, 19, (B, H, W), device="cuda")
+
+    def step():
+        out = model(x)
+        loss = torch.nn.functional.cross_entropy(out[0], y) + \
+            0.4 * torch.nn.functional.cross_entropy(out[1], y)
+        model.zero_grad(set_to_none=True)
+        loss.backward()
+        return loss
+    for _ in range(2):
+        loss = step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 3
+    for _ in range(n):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    print(json.dumps({"config": "c4-train", "model": "PSPNet", "backbone": "resnet101", "batch": B,
+                      "size": [H, W], "ms_per_step": dt * 1e3, "images_per_sec": B / dt,
+                      "loss": float(loss), "peak_mem_GB": torch.cuda.max_memory_allocated() / 2 ** 30}),
+          flush=True)
+
+
 def main():
     which = sys.argv[1:] or list(CASES)
+    if which == ["c4-train"]:
+        return train_c4()
     for tag in which:
         over, yaml_, B, H, W = CASES[tag]
         reset_cfg()
