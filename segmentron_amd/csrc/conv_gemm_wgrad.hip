@@ -266,7 +266,9 @@ extern "C" int seg_conv_gemm_wgrad_splits(int dtype, int N, int Ho, int Wo, int 
     const char* e = getenv("SEG_WGRAD_BLOCKS");  // experiment knob: total blocks aimed for
     return e ? atoi(e) : 0;
   }();
-  long want = (target > 0 ? target : (g_wgrad_dbuf ? 512 : 768)) / tiles;  // 2 or 3 blocks per CU
+  // 512 blocks in total: 2 per CU.  (768 = all 3 resident blocks per CU measured 0.3-0.4 ms/step
+  // slower on C3: a third more split partials to write and to reduce for the same GEMM.)
+  long want = (target > 0 ? target : 512) / tiles;
   long maxs = (M + 8 * bkp - 1) / (8 * bkp);       // at least 8 slabs per split
   if (maxs < 1) maxs = 1;
   if (want > maxs) want = maxs;
