@@ -584,7 +584,11 @@ static int pick_cvb_log2(int CV) {
 
 extern "C" int seg_dwconv_grid_y(int dtype, int C, int N, int Ho, int Wo, int stride, int dil) {
   using namespace seg;
-  if (dw_tiled_supported(stride, dil)) return dw_tiled_grid_y(dtype, C, N, Ho, Wo);
+  // stride -1 / -2: geometry of the LDS-tiled FUSED BACKWARD / WEIGHT GRADIENT (stride 1),
+  // stride 0: strip kernels
+  if (stride == -1 && dw_tiled_supported(1, dil)) return dw_tiled_grid_y(dtype, C, N, Ho, Wo, 1);
+  if (stride == -2 && dw_tiled_supported(1, dil)) return dw_tiled_grid_y(dtype, C, N, Ho, Wo, 2);
+  if (dw_tiled_supported(stride, dil)) return dw_tiled_grid_y(dtype, C, N, Ho, Wo, 0);
   const int vec = dtype == DT_BF16 ? 8 : 4;
   const int CV = C / vec;
   const int l = pick_cvb_log2(CV);

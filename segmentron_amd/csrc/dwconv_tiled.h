@@ -4,7 +4,7 @@
 
 namespace seg {
 bool dw_tiled_supported(int stride, int dil);
-int dw_tiled_grid_y(int dtype, int C, int N, int H, int W);
+int dw_tiled_grid_y(int dtype, int C, int N, int H, int W, int kind);
 int launch_dw_tiled(int dtype, const void* x, long ldx, int N, int H, int W, int C,
                     const float* w, int w_layout, int dil, int pro_mode, const float* sc,
                     const float* sh, void* y, long ldy, float* stat_partial, int grid_y,

@@ -172,14 +172,32 @@ __global__ __launch_bounds__(LT_THREADS, sizeof(T) == 2 ? 3 : 4) void dwconv_til
 #pragma unroll
   for (int i = 0; i < VEC; ++i) ssum[i] = ssq[i] = 0.f;
 
-  for (int t = blockIdx.y; t < a.ntiles; t += gridDim.y) {
-    int n, h0, w0;
-    tile_coords(a, t, n, h0, w0);
-    uint4 raw[G::PER];
-    unsigned okmask;
-    tile_issue<T, Vec<T>, DIL>(a, X, n, h0, w0, cv, raw, okmask);
+  // Tile loop with an optional software pipeline (PIPE): the NEXT tile's global loads are issued
+  // right after the current tile has been committed to LDS and stay in flight (across the
+  // barrier) while the current tile is computed.  Measured for THIS kernel (3 blocks/CU already
+  // overlap each other): no gain on the 24 MB tensors, -10 % on the large ones -> off; the fused
+  // backward (2 blocks/CU, long compute phase) gains 35 % from it.
+  constexpr bool PIPE = false;
+  int t = blockIdx.y, nn = 0, nh0 = 0, nw0 = 0;
+  uint4 raw[G::PER];
+  unsigned okmask = 0;
+  if (PIPE && t < a.ntiles) {
+    tile_coords(a, t, nn, nh0, nw0);
+    tile_issue<T, Vec<T>, DIL>(a, X, nn, nh0, nw0, cv, raw, okmask);
+  }
+  while (t < a.ntiles) {
+    if (!PIPE) {
+      tile_coords(a, t, nn, nh0, nw0);
+      tile_issue<T, Vec<T>, DIL>(a, X, nn, nh0, nw0, cv, raw, okmask);
+    }
     __syncthreads();  // every thread is done reading the previous tile
     tile_commit<T, Vec<T>, DIL>(a, tile, raw, okmask, wsm);
+    const int n = nn, h0 = nh0, w0 = nw0;
+    t += gridDim.y;
+    if (PIPE && t < a.ntiles) {
+      tile_coords(a, t, nn, nh0, nw0);
+      tile_issue<T, Vec<T>, DIL>(a, X, nn, nh0, nw0, cv, raw, okmask);
+    }
     __syncthreads();
 
     float acc[4][VEC];
@@ -406,29 +424,48 @@ __global__ __launch_bounds__(LT_THREADS, DW_BWD_OCC) void dwconv_bwd_tiled_kerne
 #pragma unroll
   for (int i = 0; i < VEC; ++i) s1[i] = s2[i] = 0.f;
 
-  for (int t = blockIdx.y; t < a.ntiles; t += gridDim.y) {
-    int n, h0, w0;
-    tile_coords(a, t, n, h0, w0);
-    raw_t raw[G::PER];
-    unsigned okmask;
-    {
-      DwTiledArgs d = plain;
-      d.ldx = a.lddy;
-      tile_issue<T, V, DIL>(d, DY, n, h0, w0, cv, raw, okmask);
-    }
-    // this thread's four x vectors (zero outside the image / channel range)
-    const int ho = h0 + row;
-    raw_t xraw[4];
-    const bool rok = cv < a.CV && ho < a.H;
-    const int hoc = min(ho, a.H - 1), cvc = min(cv, a.CV - 1);
+  // software pipeline over the block's tiles (see dwconv_tiled_kernel): the next tile's dy halo
+  // tile and x vectors are in flight while the current tile is computed
+  auto issue_x = [&](int n, int h0, int w0, raw_t (&xr)[4]) {
+    const int hoc = min(h0 + row, a.H - 1), cvc = min(cv, a.CV - 1);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int wo = w0 + strip * 4 + j;
-      xraw[j] = V::load_raw(X + (((long)n * a.H + hoc) * a.W + min(wo, a.W - 1)) * a.ldx + cvc * VEC);
+      xr[j] = V::load_raw(X + (((long)n * a.H + hoc) * a.W + min(wo, a.W - 1)) * a.ldx + cvc * VEC);
+    }
+  };
+  DwTiledArgs dyargs = plain;
+  dyargs.ldx = a.lddy;
+  constexpr bool PIPE = DIL == 1;  // dilation 2 (wider halo tile) would spill with the prefetch
+  int t = blockIdx.y, nn = 0, nh0 = 0, nw0 = 0;
+  raw_t raw[G::PER], xnext[4];
+  unsigned okmask = 0;
+  if (PIPE && t < a.ntiles) {
+    tile_coords(a, t, nn, nh0, nw0);
+    tile_issue<T, V, DIL>(dyargs, DY, nn, nh0, nw0, cv, raw, okmask);
+    issue_x(nn, nh0, nw0, xnext);
+  }
+  while (t < a.ntiles) {
+    if (!PIPE) {
+      tile_coords(a, t, nn, nh0, nw0);
+      tile_issue<T, V, DIL>(dyargs, DY, nn, nh0, nw0, cv, raw, okmask);
+      issue_x(nn, nh0, nw0, xnext);
     }
     __syncthreads();
     tile_commit<T, V, DIL>(plain, tile, raw, okmask, psm);
+    const int n = nn, h0 = nh0, w0 = nw0;
+    raw_t xraw[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) xraw[j] = xnext[j];
+    t += gridDim.y;
+    if (PIPE && t < a.ntiles) {
+      tile_coords(a, t, nn, nh0, nw0);
+      tile_issue<T, V, DIL>(dyargs, DY, nn, nh0, nw0, cv, raw, okmask);
+      issue_x(nn, nh0, nw0, xnext);
+    }
     __syncthreads();
+    const int ho = h0 + row;
+    const bool rok = cv < a.CV && ho < a.H;
 
     float xa[4][VEC];
 #pragma unroll
@@ -599,11 +636,18 @@ static void tiled_geom(DwTiledArgs& a, int dtype, int N, int H, int W, int C) {
   a.ntiles = N * a.tiles_h * a.tiles_w;
 }
 
-int dw_tiled_grid_y(int dtype, int C, int N, int H, int W) {
+// Persistent blocks: about one resident set of blocks for the whole launch (3 per CU forward, 2 per
+// CU fused backward), each walking several tiles so that the tile pipeline has something to
+// overlap; the count also bounds the number of partial rows.
+int dw_tiled_grid_y(int dtype, int C, int N, int H, int W, int kind) {
+  // kind 0: forward / dgrad (one tile per block where possible: 3 blocks/CU overlap each other),
+  // 1: fused backward (two resident blocks per CU, several tiles each for the tile pipeline),
+  // 2: weight gradient (few partial rows: its block reduction is the expensive part)
   DwTiledArgs a;
   tiled_geom(a, dtype, N, H, W, C);
-  const int gx = (a.CV + LT_CVB - 1) / LT_CVB;
-  long cap = 2048 / gx;  // ~8 blocks per CU in total; bounds the number of partial rows
+  const int cv = kind == 1 ? C / 4 : a.CV;  // the fused backward works on 4-channel vectors
+  const int gx = (cv + LT_CVB - 1) / LT_CVB;
+  long cap = (kind == 0 ? 2048 : kind == 1 ? 512 : 768) / gx;
   if (cap < 1) cap = 1;
   long gy = a.ntiles;
   if (gy > cap) gy = cap;

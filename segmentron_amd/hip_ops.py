@@ -214,8 +214,8 @@ def dwconv_bwd_fused(x, dy, w, dil, pro=None, want_bn=False, torch_layout=False)
     layout = 1 if w.dim() == 4 else 0
     if layout and not tiled:
         raise ValueError("depthwise strip kernels need tap-major [9, C] weights")
-    # stride 0 = geometry of the strip kernels
-    gy = LIB.query("seg_dwconv_grid_y", _DT[x.dtype], C, N, H, W, 1 if tiled else 0, dil)
+    # stride -1 = geometry of the tiled fused backward, stride 0 = of the strip kernels
+    gy = LIB.query("seg_dwconv_grid_y", _DT[x.dtype], C, N, H, W, -1 if tiled else 0, dil)
     pw = torch.empty((gy, 9 * C), dtype=torch.float32, device=x.device)
     pb = torch.empty((gy, 2 * C), dtype=torch.float32, device=x.device) if want_bn else None
     LIB.call("seg_dwconv3x3_bwd_fused", _DT[x.dtype], _p(dy), lddy, _p(x), ldx, N, H, W, C,
@@ -232,7 +232,8 @@ def dwconv_wgrad(x, dy, stride, dil, pro=None, torch_layout=False):
     N, Hi, Wi, C, ldx = nhwc(x)
     _, Ho, Wo, _, lddy = nhwc(dy)
     mode, ps, pt = _pro(pro)
-    gy = LIB.query("seg_dwconv_grid_y", _DT[x.dtype], C, N, Ho, Wo, stride, dil)
+    gy = LIB.query("seg_dwconv_grid_y", _DT[x.dtype], C, N, Ho, Wo,
+                   -2 if dw_tiled(stride, dil) else stride, dil)  # -2: tiled wgrad geometry
     partial = torch.empty((gy, 9 * C), dtype=torch.float32, device=x.device)
     LIB.call("seg_dwconv3x3_wgrad", _DT[x.dtype], _p(x), ldx, N, Hi, Wi, C, _p(dy), lddy, Ho, Wo,
              stride, dil, mode, _p(ps), _p(pt), _p(partial), gy, _stream())
