@@ -17,6 +17,7 @@
 // tiles and are reduced once per block (deterministic, no atomics).
 #include "common.h"
 #include "dwconv_tiled.h"
+#include <cstdlib>
 
 namespace seg {
 
@@ -647,7 +648,11 @@ int dw_tiled_grid_y(int dtype, int C, int N, int H, int W, int kind) {
   tiled_geom(a, dtype, N, H, W, C);
   const int cv = kind == 1 ? C / 4 : a.CV;  // the fused backward works on 4-channel vectors
   const int gx = (cv + LT_CVB - 1) / LT_CVB;
-  long cap = (kind == 0 ? 2048 : kind == 1 ? 512 : 768) / gx;
+  static const int fwd_cap = [] {
+    const char* e = getenv("SEG_DW_FWD_BLOCKS");  // experiment knob
+    return e ? atoi(e) : 2048;
+  }();
+  long cap = (kind == 0 ? fwd_cap : kind == 1 ? 512 : 768) / gx;
   if (cap < 1) cap = 1;
   long gy = a.ntiles;
   if (gy > cap) gy = cap;

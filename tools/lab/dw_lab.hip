@@ -1,4 +1,6 @@
-// Lab: LDS-tiled depthwise 3x3 (stride 1, dil 1) vs the production kernel.
+// Lab: the first LDS-tiled depthwise 3x3 prototype (stride 1, dil 1) vs the production entry point
+// (which has since become the tiled kernel itself: kept as the record of the experiment).
+// hipcc -O3 --offload-arch=gfx950 -DOCC=4 -o dw_lab dw_lab.hip -L../../segmentron_amd -lsegmentron_hip -Wl,-rpath,'$ORIGIN/../../segmentron_amd'
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
@@ -6,10 +8,10 @@
 #include <cmath>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("err %s line %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 extern "C" int seg_dwconv3x3(int dtype, int mode, const void* x, long ldx, int N, int Hi, int Wi, int C,
-                             const float* w9c, int stride, int dil, int pro_mode, const float* ps,
+                             const float* w9c, int w_layout, int stride, int dil, int pro_mode, const float* ps,
                              const float* pt, void* y, long ldy, int Ho, int Wo, float* stat_partial,
                              int grid_y, void* stream);
-extern "C" int seg_dwconv_grid_y(int dtype, int C, int N, int Ho, int Wo);
+extern "C" int seg_dwconv_grid_y(int dtype, int C, int N, int Ho, int Wo, int stride, int dil);
 extern "C" const char* seg_last_error();
 
 __device__ __forceinline__ void unpack(const uint4& v, float* f) {
@@ -181,7 +183,7 @@ int main() {
     const int tiles_h = (H + TH - 1) / TH, tiles_w = (W + TW - 1) / TW;
     const int ntiles = N * tiles_h * tiles_w;
     CK(hipMalloc(&stat, (size_t)ntiles * 2 * C * 4));
-    const int gy = seg_dwconv_grid_y(1, C, N, H, W);
+    const int gy = seg_dwconv_grid_y(1, C, N, H, W, 1, 1);
     CK(hipMalloc(&stat2, (size_t)gy * 2 * C * 4));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     auto timeit = [&](const char* name, auto fn) {
@@ -198,7 +200,7 @@ int main() {
       Args a{(const uint16_t*)x, w, (uint16_t*)y, sc, sh, stat, N, H, W, C, CV, mode, tiles_h, tiles_w};
       char nm[64];
       snprintf(nm, 64, "production mode %d + stats", mode);
-      timeit(nm, [&] { if (seg_dwconv3x3(1, 0, x, C, N, H, W, C, w, 1, 1, mode, sc, sh, y2, C, H, W, stat2, gy, nullptr)) printf("ERR %s\n", seg_last_error()); });
+      timeit(nm, [&] { if (seg_dwconv3x3(1, 0, x, C, N, H, W, C, w, 0, 1, 1, mode, sc, sh, y2, C, H, W, stat2, gy, nullptr)) printf("ERR %s\n", seg_last_error()); });
       snprintf(nm, 64, "lds-tiled  mode %d + stats", mode);
       timeit(nm, [&] { hipLaunchKernelGGL(dw_lds, dim3((CV + CVB - 1) / CVB, ntiles), dim3(256), 0, 0, a); });
       a.stat = nullptr;
@@ -209,7 +211,7 @@ int main() {
     {
       Args a{(const uint16_t*)x, w, (uint16_t*)y, sc, sh, nullptr, N, H, W, C, CV, 3, tiles_h, tiles_w};
       hipLaunchKernelGGL(dw_lds, dim3((CV + CVB - 1) / CVB, ntiles), dim3(256), 0, 0, a);
-      seg_dwconv3x3(1, 0, x, C, N, H, W, C, w, 1, 1, 3, sc, sh, y2, C, H, W, nullptr, gy, nullptr);
+      seg_dwconv3x3(1, 0, x, C, N, H, W, C, w, 0, 1, 1, 3, sc, sh, y2, C, H, W, nullptr, gy, nullptr);
       std::vector<uint16_t> ha(n * 8), hb(n * 8);
       CK(hipMemcpy(ha.data(), y, n * 16, hipMemcpyDeviceToHost));
       CK(hipMemcpy(hb.data(), y2, n * 16, hipMemcpyDeviceToHost));
