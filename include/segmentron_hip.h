@@ -83,7 +83,9 @@ int seg_dwconv3x3(int dtype, int mode, const void* x, long ldx, int N, int Hi, i
                   const float* w9c, int w_layout, int stride, int dil, int pro_mode,
                   const float* pro_scale, const float* pro_shift, void* y, long ldy, int Ho, int Wo, float* stat_partial,
                   int grid_y, void* stream);
-int seg_dwconv_grid_y(int dtype, int C, int N, int Ho, int Wo, int stride, int dil);
+/* partial rows (= persistent blocks per channel block) of one depthwise launch.
+ * kind: 0 forward / data gradient, 1 fused backward, 2 weight gradient */
+int seg_dwconv_grid_y(int dtype, int C, int N, int Ho, int Wo, int stride, int dil, int kind);
 /* partial: fp32 [grid_y][9][C]; column-sum gives dW[9][C];
  * seg_dwconv3x3_wgrad_finalize reduces it straight into torch's [C,1,3,3] layout. */
 int seg_dwconv3x3_wgrad_finalize(const float* partial, int R, int C, float* dw_c9, void* stream);

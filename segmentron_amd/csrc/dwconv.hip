@@ -67,14 +67,12 @@ __device__ __forceinline__ void dw_act(float* f, int mode, const float* sc, cons
   }
 }
 
-// FAST: stride 1, dilation 1 (59 of the 68 xception dw layers, and every stride-1 data
-// gradient through flipped taps): per input row the TW+2 needed vectors are loaded and
-// activated ONCE and reused by the three horizontal taps (18 loads / strip instead of 36).
-template <typename T, int MODE, bool FAST>
-__global__ __launch_bounds__(DW_THREADS, FAST ? 3 : 2) void dwconv_kernel(const DwArgs a) {
-  // FAST: 4 channels per thread (8-byte bf16 vectors) so that 18 packed loads + accumulators fit
-  // ~120 VGPRs (3-4 waves/SIMD, all loads of a strip in flight); generic: 16-byte vectors
-  using V = typename std::conditional<FAST, HVec<T>, Vec<T>>::type;
+// Strip kernels: stride 2 and wide dilations (6/12/18) only — every stride-1, dil <= 2 layer runs
+// on the LDS-tiled kernels of dwconv_tiled.hip (the sliding-window fast path these kernels once
+// had for that case is gone with it).
+template <typename T, int MODE>
+__global__ __launch_bounds__(DW_THREADS, 2) void dwconv_kernel(const DwArgs a) {
+  using V = Vec<T>;
   constexpr int VEC = V::N;
   extern __shared__ __attribute__((aligned(16))) float dw_smem[];
   const int tid = threadIdx.x;
@@ -115,89 +113,41 @@ __global__ __launch_bounds__(DW_THREADS, FAST ? 3 : 2) void dwconv_kernel(const 
 #pragma unroll
       for (int i = 0; i < VEC; ++i) acc[j][i] = 0.f;
 
-    if (FAST) {
-      // all 18 loads of the strip are issued before the first use (kept packed: 72 VGPRs) from
-      // clamped row / column indices — no branch sits between loads, one wait covers them all;
-      // out-of-image taps are zeroed by a select after the activation (= zero padding).
-      typename V::raw_t raw[3][DW_TW + 2];
-      float ckeep[DW_TW + 2], rkeep[3];
 #pragma unroll
-      for (int q = 0; q < DW_TW + 2; ++q) {
-        const int wi = w0 - 1 + q;
-        ckeep[q] = (wi >= 0 && wi < a.Wi) ? 1.f : 0.f;
+    for (int kh = 0; kh < 3; ++kh) {
+      int hi;
+      if (MODE == MODE_FWD) {
+        hi = ho * a.stride - a.pad + kh * a.dil;
+      } else {
+        const int hn = ho + a.pad - kh * a.dil;
+        if (hn < 0 || (hn % a.stride) != 0) continue;
+        hi = hn / a.stride;
       }
+      if (hi < 0 || hi >= a.Hi) continue;
+      const long rowbase = ((long)n * a.Hi + hi) * a.Wi;
 #pragma unroll
-      for (int kh = 0; kh < 3; ++kh) {
-        const int hi = ho - 1 + kh;
-        const int hic = min(max(hi, 0), a.Hi - 1);
-        rkeep[kh] = (hi == hic) ? 1.f : 0.f;
-        // 32-bit element offsets from the (uniform) tensor base: one VGPR per address and the
-        // compiler can use the scalar-base + vector-offset form of global_load
-        const unsigned rowbase = (unsigned)((n * a.Hi + hic) * a.Wi);
+      for (int kw = 0; kw < 3; ++kw) {
+        float wv[VEC];
+        load_params<VEC>(a.w + (kh * 3 + kw) * a.C, c0, wv);
 #pragma unroll
-        for (int q = 0; q < DW_TW + 2; ++q) {
-          const unsigned wic = (unsigned)min(max(w0 - 1 + q, 0), a.Wi - 1);
-          raw[kh][q] = V::load_raw(X + ((rowbase + wic) * (unsigned)a.ldx + (unsigned)c0));
-        }
-      }
+        for (int j = 0; j < DW_TW; ++j) {
+          const int wo = w0 + j;
+          int wi;
+          bool ok = wo < a.Wo;
+          if (MODE == MODE_FWD) {
+            wi = wo * a.stride - a.pad + kw * a.dil;
+          } else {
+            const int wn = wo + a.pad - kw * a.dil;
+            ok = ok && wn >= 0 && (wn % a.stride) == 0;
+            wi = wn / a.stride;
+          }
+          ok = ok && wi >= 0 && wi < a.Wi;
+          if (ok) {
+            float f[VEC];
+            V::unpack_raw(V::load_raw(X + (rowbase + wi) * a.ldx + c0), f);
+            dw_act<VEC>(f, a.pro_mode, sc, sh);
 #pragma unroll
-      for (int kh = 0; kh < 3; ++kh) {
-        float v[DW_TW + 2][VEC];
-#pragma unroll
-        for (int q = 0; q < DW_TW + 2; ++q) {
-          V::unpack_raw(raw[kh][q], v[q]);
-          dw_act<VEC>(v[q], a.pro_mode, sc, sh);
-          const float keep = ckeep[q] * rkeep[kh];
-#pragma unroll
-          for (int i = 0; i < VEC; ++i) v[q][i] *= keep;
-        }
-#pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
-          float wv[VEC];
-          load_params<VEC>(a.w + (kh * 3 + kw) * a.C, c0, wv);
-#pragma unroll
-          for (int j = 0; j < DW_TW; ++j)
-#pragma unroll
-            for (int i = 0; i < VEC; ++i) acc[j][i] = fmaf(v[j + kw][i], wv[i], acc[j][i]);
-        }
-      }
-    } else {
-#pragma unroll
-      for (int kh = 0; kh < 3; ++kh) {
-        int hi;
-        if (MODE == MODE_FWD) {
-          hi = ho * a.stride - a.pad + kh * a.dil;
-        } else {
-          const int hn = ho + a.pad - kh * a.dil;
-          if (hn < 0 || (hn % a.stride) != 0) continue;
-          hi = hn / a.stride;
-        }
-        if (hi < 0 || hi >= a.Hi) continue;
-        const long rowbase = ((long)n * a.Hi + hi) * a.Wi;
-#pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
-          float wv[VEC];
-          load_params<VEC>(a.w + (kh * 3 + kw) * a.C, c0, wv);
-#pragma unroll
-          for (int j = 0; j < DW_TW; ++j) {
-            const int wo = w0 + j;
-            int wi;
-            bool ok = wo < a.Wo;
-            if (MODE == MODE_FWD) {
-              wi = wo * a.stride - a.pad + kw * a.dil;
-            } else {
-              const int wn = wo + a.pad - kw * a.dil;
-              ok = ok && wn >= 0 && (wn % a.stride) == 0;
-              wi = wn / a.stride;
-            }
-            ok = ok && wi >= 0 && wi < a.Wi;
-            if (ok) {
-              float f[VEC];
-              V::unpack_raw(V::load_raw(X + (rowbase + wi) * a.ldx + c0), f);
-              dw_act<VEC>(f, a.pro_mode, sc, sh);
-#pragma unroll
-              for (int i = 0; i < VEC; ++i) acc[j][i] = fmaf(f[i], wv[i], acc[j][i]);
-            }
+            for (int i = 0; i < VEC; ++i) acc[j][i] = fmaf(f[i], wv[i], acc[j][i]);
           }
         }
       }
@@ -251,7 +201,7 @@ struct DwWgradArgs {
   long strips;
 };
 
-template <typename T, bool FAST>
+template <typename T>
 __global__ __launch_bounds__(DW_THREADS) void dwconv_wgrad_kernel(const DwWgradArgs a) {
   constexpr int VEC = Vec<T>::N;
   extern __shared__ __attribute__((aligned(16))) float dw_smem[];
@@ -299,52 +249,23 @@ __global__ __launch_bounds__(DW_THREADS) void dwconv_wgrad_kernel(const DwWgradA
 #pragma unroll
       for (int i = 0; i < VEC; ++i) g[j][i] *= keep;
     }
-    if (FAST) {
 #pragma unroll
-      for (int kh = 0; kh < 3; ++kh) {
-        const int hi = ho - 1 + kh;
-        if (hi < 0 || hi >= a.Hi) continue;
-        const long rowbase = ((long)n * a.Hi + hi) * a.Wi;
-        float v[DW_TW + 2][VEC];
+    for (int kh = 0; kh < 3; ++kh) {
+      const int hi = ho * a.stride - a.pad + kh * a.dil;
+      if (hi < 0 || hi >= a.Hi) continue;
+      const long rowbase = ((long)n * a.Hi + hi) * a.Wi;
 #pragma unroll
-        for (int q = 0; q < DW_TW + 2; ++q) {
-          // unconditional load from a clamped column + select-to-zero: no divergent branch
-          // around the load, so the six loads of a row issue back to back
-          const int wi = w0 - 1 + q;
-          const int wic = min(max(wi, 0), a.Wi - 1);
-          Vec<T>::unpack(ldg16(X + (rowbase + wic) * a.ldx + c0), v[q]);
-          dw_act<VEC>(v[q], a.pro_mode, sc, sh);
-          const float keep = (wi == wic) ? 1.f : 0.f;
+      for (int kw = 0; kw < 3; ++kw) {
 #pragma unroll
-          for (int i = 0; i < VEC; ++i) v[q][i] *= keep;
-        }
-#pragma unroll
-        for (int kw = 0; kw < 3; ++kw)
-#pragma unroll
-          for (int j = 0; j < DW_TW; ++j)
+        for (int j = 0; j < DW_TW; ++j) {
+          const int wi = (w0 + j) * a.stride - a.pad + kw * a.dil;
+          if (w0 + j < a.Wo && wi >= 0 && wi < a.Wi) {
+            float f[VEC];
+            Vec<T>::unpack(ldg16(X + (rowbase + wi) * a.ldx + c0), f);
+            dw_act<VEC>(f, a.pro_mode, sc, sh);
 #pragma unroll
             for (int i = 0; i < VEC; ++i)
-              acc[kh * 3 + kw][i] = fmaf(v[j + kw][i], g[j][i], acc[kh * 3 + kw][i]);
-      }
-    } else {
-#pragma unroll
-      for (int kh = 0; kh < 3; ++kh) {
-        const int hi = ho * a.stride - a.pad + kh * a.dil;
-        if (hi < 0 || hi >= a.Hi) continue;
-        const long rowbase = ((long)n * a.Hi + hi) * a.Wi;
-#pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
-#pragma unroll
-          for (int j = 0; j < DW_TW; ++j) {
-            const int wi = (w0 + j) * a.stride - a.pad + kw * a.dil;
-            if (w0 + j < a.Wo && wi >= 0 && wi < a.Wi) {
-              float f[VEC];
-              Vec<T>::unpack(ldg16(X + (rowbase + wi) * a.ldx + c0), f);
-              dw_act<VEC>(f, a.pro_mode, sc, sh);
-#pragma unroll
-              for (int i = 0; i < VEC; ++i)
-                acc[kh * 3 + kw][i] = fmaf(f[i], g[j][i], acc[kh * 3 + kw][i]);
-            }
+              acc[kh * 3 + kw][i] = fmaf(f[i], g[j][i], acc[kh * 3 + kw][i]);
           }
         }
       }
@@ -387,7 +308,7 @@ struct DwBwdArgs {
   long strips;
 };
 
-template <typename T, bool FAST>
+template <typename T>
 __global__ __launch_bounds__(DW_THREADS) void dwconv_bwd_fused_kernel(const DwBwdArgs a) {
   constexpr int VEC = HVec<T>::N;  // 4 channels per thread (8-byte bf16 vectors): this kernel
                                    // carries 9 tap accumulators per channel
@@ -450,71 +371,25 @@ __global__ __launch_bounds__(DW_THREADS) void dwconv_bwd_fused_kernel(const DwBw
         xr[j][i] *= keep;
       }
     }
-    if (FAST) {
-      typename HVec<T>::raw_t raw[3][DW_TW + 2];
-      float ckeep[DW_TW + 2], rkeep[3];
 #pragma unroll
-      for (int q = 0; q < DW_TW + 2; ++q) {
-        const int c = w0 - 1 + q;
-        ckeep[q] = (c >= 0 && c < a.W) ? 1.f : 0.f;
-      }
+    for (int kh = 0; kh < 3; ++kh) {
+      const int r = h + (1 - kh) * d;
+      if (r < 0 || r >= a.H) continue;
+      const long rowbase = ((long)n * a.H + r) * a.W;
 #pragma unroll
-      for (int kh = 0; kh < 3; ++kh) {
-        const int r = h + 1 - kh;  // dy row feeding tap row kh
-        const int rc = min(max(r, 0), a.H - 1);
-        rkeep[kh] = (r == rc) ? 1.f : 0.f;
-        const unsigned rowbase = (unsigned)((n * a.H + rc) * a.W);
+      for (int kw = 0; kw < 3; ++kw) {
+        float wv[VEC];
+        load_params<VEC>(a.w + (kh * 3 + kw) * a.C, c0, wv);
 #pragma unroll
-        for (int q = 0; q < DW_TW + 2; ++q) {
-          const unsigned cc = (unsigned)min(max(w0 - 1 + q, 0), a.W - 1);
-          raw[kh][q] = HVec<T>::load_raw(DY + ((rowbase + cc) * (unsigned)a.lddy + (unsigned)c0));
-        }
-      }
-#pragma unroll
-      for (int kh = 0; kh < 3; ++kh) {
-        float v[DW_TW + 2][VEC];
-#pragma unroll
-        for (int q = 0; q < DW_TW + 2; ++q) {
-          HVec<T>::unpack_raw(raw[kh][q], v[q]);
-          const float keep = ckeep[q] * rkeep[kh];
-#pragma unroll
-          for (int i = 0; i < VEC; ++i) v[q][i] *= keep;
-        }
-#pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
-          float wv[VEC];
-          load_params<VEC>(a.w + (kh * 3 + kw) * a.C, c0, wv);
-#pragma unroll
-          for (int j = 0; j < DW_TW; ++j)
+        for (int j = 0; j < DW_TW; ++j) {
+          const int c = w0 + j + (1 - kw) * d;
+          if (w0 + j < a.W && c >= 0 && c < a.W) {
+            float dyv[VEC];
+            HVec<T>::load(DY + (rowbase + c) * a.lddy + c0, dyv);
 #pragma unroll
             for (int i = 0; i < VEC; ++i) {
-              const float dyv = v[j + 2 - kw][i];
-              g[j][i] = fmaf(dyv, wv[i], g[j][i]);
-              accw[kh * 3 + kw][i] = fmaf(dyv, xa[j][i], accw[kh * 3 + kw][i]);
-            }
-        }
-      }
-    } else {
-#pragma unroll
-      for (int kh = 0; kh < 3; ++kh) {
-        const int r = h + (1 - kh) * d;
-        if (r < 0 || r >= a.H) continue;
-        const long rowbase = ((long)n * a.H + r) * a.W;
-#pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
-          float wv[VEC];
-          load_params<VEC>(a.w + (kh * 3 + kw) * a.C, c0, wv);
-#pragma unroll
-          for (int j = 0; j < DW_TW; ++j) {
-            const int c = w0 + j + (1 - kw) * d;
-            if (w0 + j < a.W && c >= 0 && c < a.W) {
-              float dyv[VEC];
-              HVec<T>::load(DY + (rowbase + c) * a.lddy + c0, dyv);
-#pragma unroll
-              for (int i = 0; i < VEC; ++i) {
-                g[j][i] = fmaf(dyv[i], wv[i], g[j][i]);
-                accw[kh * 3 + kw][i] = fmaf(dyv[i], xa[j][i], accw[kh * 3 + kw][i]);
-              }
+              g[j][i] = fmaf(dyv[i], wv[i], g[j][i]);
+              accw[kh * 3 + kw][i] = fmaf(dyv[i], xa[j][i], accw[kh * 3 + kw][i]);
             }
           }
         }
@@ -582,13 +457,15 @@ static int pick_cvb_log2(int CV) {
 
 }  // namespace seg
 
-extern "C" int seg_dwconv_grid_y(int dtype, int C, int N, int Ho, int Wo, int stride, int dil) {
+// Number of partial rows / persistent blocks per channel block for one depthwise launch.
+// kind: 0 forward / data gradient, 1 fused backward, 2 weight gradient (the LDS-tiled kernels size
+// them differently; the strip kernels — stride 2, dilation > 2 — share one geometry).
+extern "C" int seg_dwconv_grid_y(int dtype, int C, int N, int Ho, int Wo, int stride, int dil,
+                                 int kind) {
   using namespace seg;
-  // stride -1 / -2: geometry of the LDS-tiled FUSED BACKWARD / WEIGHT GRADIENT (stride 1),
-  // stride 0: strip kernels
-  if (stride == -1 && dw_tiled_supported(1, dil)) return dw_tiled_grid_y(dtype, C, N, Ho, Wo, 1);
-  if (stride == -2 && dw_tiled_supported(1, dil)) return dw_tiled_grid_y(dtype, C, N, Ho, Wo, 2);
-  if (dw_tiled_supported(stride, dil)) return dw_tiled_grid_y(dtype, C, N, Ho, Wo, 0);
+  const int tiled_stride = kind == 0 ? stride : 1;  // kinds 1/2 describe a stride-1 layer's backward
+  if ((kind == 0 || stride == 1) && dw_tiled_supported(tiled_stride, dil))
+    return dw_tiled_grid_y(dtype, C, N, Ho, Wo, kind);
   const int vec = dtype == DT_BF16 ? 8 : 4;
   const int CV = C / vec;
   const int l = pick_cvb_log2(CV);
@@ -601,8 +478,6 @@ extern "C" int seg_dwconv_grid_y(int dtype, int C, int N, int Ho, int Wo, int st
   if (gy > cap) gy = cap;
   return (int)gy;
 }
-
-// mode: 0 forward, 1 dgrad (x = dy, y = dx; (N,Hi,Wi) is dy's geometry, (Ho,Wo) dx's)
 extern "C" int seg_dwconv3x3(int dtype, int mode, const void* x, long ldx, int N, int Hi, int Wi,
                              int C, const float* w9c, int w_layout, int stride, int dil, int pro_mode,
                              const float* pro_scale, const float* pro_shift, void* y, long ldy,
@@ -627,8 +502,7 @@ extern "C" int seg_dwconv3x3(int dtype, int mode, const void* x, long ldx, int N
   a.stat_partial = stat_partial; a.ldx = ldx; a.ldy = ldy;
   a.N = N; a.Hi = Hi; a.Wi = Wi; a.C = C; a.Ho = Ho; a.Wo = Wo;
   a.stride = stride; a.pad = dil; a.dil = dil; a.pro_mode = pro_mode;
-  const bool fast = mode == MODE_FWD && stride == 1 && dil == 1;  // dgrad: flipped taps, mode 0
-  const int kvec = fast ? 4 : vec;  // channels per thread
+  const int kvec = vec;  // channels per thread
   a.CV = C / kvec; a.cvb_log2 = pick_cvb_log2(a.CV);
   a.strips = (long)N * Ho * ((Wo + DW_TW - 1) / DW_TW);
   const int gx = (a.CV + (1 << a.cvb_log2) - 1) >> a.cvb_log2;
@@ -638,14 +512,12 @@ extern "C" int seg_dwconv3x3(int dtype, int mode, const void* x, long ldx, int N
   hipStream_t st = (hipStream_t)stream;
   SEG_REQUIRE(a.strips < (1L << 31), "dwconv3x3: too many strips");
   SEG_REQUIRE((long)N * Hi * Wi * ldx < (1L << 31), "dwconv3x3: tensor exceeds 32-bit offsets");
-#define SEG_DW_LAUNCH(TT, MM, FF) \
-  hipLaunchKernelGGL((dwconv_kernel<TT, MM, FF>), grid, dim3(DW_THREADS), lds, st, a)
+#define SEG_DW_LAUNCH(TT, MM) \
+  hipLaunchKernelGGL((dwconv_kernel<TT, MM>), grid, dim3(DW_THREADS), lds, st, a)
   if (dtype == DT_BF16) {
-    if (mode == MODE_FWD) { if (fast) SEG_DW_LAUNCH(bf16_t, MODE_FWD, true); else SEG_DW_LAUNCH(bf16_t, MODE_FWD, false); }
-    else SEG_DW_LAUNCH(bf16_t, MODE_DGRAD, false);
+    if (mode == MODE_FWD) SEG_DW_LAUNCH(bf16_t, MODE_FWD); else SEG_DW_LAUNCH(bf16_t, MODE_DGRAD);
   } else {
-    if (mode == MODE_FWD) { if (fast) SEG_DW_LAUNCH(float, MODE_FWD, true); else SEG_DW_LAUNCH(float, MODE_FWD, false); }
-    else SEG_DW_LAUNCH(float, MODE_DGRAD, false);
+    if (mode == MODE_FWD) SEG_DW_LAUNCH(float, MODE_FWD); else SEG_DW_LAUNCH(float, MODE_DGRAD);
   }
 #undef SEG_DW_LAUNCH
   return check_launch("dwconv3x3");
@@ -679,14 +551,10 @@ extern "C" int seg_dwconv3x3_wgrad(int dtype, const void* x, long ldx, int N, in
   const size_t lds = (size_t)DW_THREADS * 3 * vec * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
   SEG_REQUIRE(a.strips < (1L << 31), "dwconv3x3_wgrad: too many strips");
-  const bool fast = stride == 1 && dil == 1;
-  if (dtype == DT_BF16) {
-    if (fast) hipLaunchKernelGGL((dwconv_wgrad_kernel<bf16_t, true>), grid, dim3(DW_THREADS), lds, st, a);
-    else hipLaunchKernelGGL((dwconv_wgrad_kernel<bf16_t, false>), grid, dim3(DW_THREADS), lds, st, a);
-  } else {
-    if (fast) hipLaunchKernelGGL((dwconv_wgrad_kernel<float, true>), grid, dim3(DW_THREADS), lds, st, a);
-    else hipLaunchKernelGGL((dwconv_wgrad_kernel<float, false>), grid, dim3(DW_THREADS), lds, st, a);
-  }
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL((dwconv_wgrad_kernel<bf16_t>), grid, dim3(DW_THREADS), lds, st, a);
+  else
+    hipLaunchKernelGGL((dwconv_wgrad_kernel<float>), grid, dim3(DW_THREADS), lds, st, a);
   return check_launch("dwconv3x3_wgrad");
 }
 
@@ -728,13 +596,10 @@ extern "C" int seg_dwconv3x3_bwd_fused(int dtype, const void* dy, long lddy, con
   const dim3 grid(gx, grid_y);
   const size_t lds = (size_t)DW_THREADS * 3 * vec * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == DT_BF16) {
-    if (dil == 1) hipLaunchKernelGGL((dwconv_bwd_fused_kernel<bf16_t, true>), grid, dim3(DW_THREADS), lds, st, a);
-    else hipLaunchKernelGGL((dwconv_bwd_fused_kernel<bf16_t, false>), grid, dim3(DW_THREADS), lds, st, a);
-  } else {
-    if (dil == 1) hipLaunchKernelGGL((dwconv_bwd_fused_kernel<float, true>), grid, dim3(DW_THREADS), lds, st, a);
-    else hipLaunchKernelGGL((dwconv_bwd_fused_kernel<float, false>), grid, dim3(DW_THREADS), lds, st, a);
-  }
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL((dwconv_bwd_fused_kernel<bf16_t>), grid, dim3(DW_THREADS), lds, st, a);
+  else
+    hipLaunchKernelGGL((dwconv_bwd_fused_kernel<float>), grid, dim3(DW_THREADS), lds, st, a);
   return check_launch("dwconv3x3_bwd_fused");
 }
 

@@ -172,7 +172,7 @@ def dwconv(x, w9c, stride, dil, pro=None, out=None, want_stats=False):
         out = torch.empty((N, Ho, Wo, C), dtype=x.dtype, device=x.device)
     ldy = nhwc(out)[4]
     w, layout = _dw_weight_arg(w9c, C, stride, dil, False)
-    gy = LIB.query("seg_dwconv_grid_y", _DT[x.dtype], C, N, Ho, Wo, stride, dil)
+    gy = LIB.query("seg_dwconv_grid_y", _DT[x.dtype], C, N, Ho, Wo, stride, dil, 0)
     partial = torch.empty((gy, 2, C), dtype=torch.float32, device=x.device) if want_stats else None
     LIB.call("seg_dwconv3x3", _DT[x.dtype], 0, _p(x), ldx, N, Hi, Wi, C, _p(w), layout, stride,
              dil, mode, _p(ps), _p(pt), _p(out), ldy, Ho, Wo, _p(partial), gy, _stream())
@@ -186,7 +186,7 @@ def dwconv_dgrad(dy, w9c, stride, dil, in_hw, flipped=True):
     N, Ho, Wo, C, lddy = nhwc(dy)
     Hi, Wi = in_hw
     dx = torch.empty((N, Hi, Wi, C), dtype=dy.dtype, device=dy.device)
-    gy = LIB.query("seg_dwconv_grid_y", _DT[dy.dtype], C, N, Hi, Wi, stride, dil)
+    gy = LIB.query("seg_dwconv_grid_y", _DT[dy.dtype], C, N, Hi, Wi, stride, dil, 0)
     if stride == 1:
         if w9c.dim() == 4:
             w, layout = w9c, 3
@@ -214,8 +214,7 @@ def dwconv_bwd_fused(x, dy, w, dil, pro=None, want_bn=False, torch_layout=False)
     layout = 1 if w.dim() == 4 else 0
     if layout and not tiled:
         raise ValueError("depthwise strip kernels need tap-major [9, C] weights")
-    # stride -1 = geometry of the tiled fused backward, stride 0 = of the strip kernels
-    gy = LIB.query("seg_dwconv_grid_y", _DT[x.dtype], C, N, H, W, -1 if tiled else 0, dil)
+    gy = LIB.query("seg_dwconv_grid_y", _DT[x.dtype], C, N, H, W, 1, dil, 1)
     pw = torch.empty((gy, 9 * C), dtype=torch.float32, device=x.device)
     pb = torch.empty((gy, 2 * C), dtype=torch.float32, device=x.device) if want_bn else None
     LIB.call("seg_dwconv3x3_bwd_fused", _DT[x.dtype], _p(dy), lddy, _p(x), ldx, N, H, W, C,
@@ -232,8 +231,7 @@ def dwconv_wgrad(x, dy, stride, dil, pro=None, torch_layout=False):
     N, Hi, Wi, C, ldx = nhwc(x)
     _, Ho, Wo, _, lddy = nhwc(dy)
     mode, ps, pt = _pro(pro)
-    gy = LIB.query("seg_dwconv_grid_y", _DT[x.dtype], C, N, Ho, Wo,
-                   -2 if dw_tiled(stride, dil) else stride, dil)  # -2: tiled wgrad geometry
+    gy = LIB.query("seg_dwconv_grid_y", _DT[x.dtype], C, N, Ho, Wo, stride, dil, 2)
     partial = torch.empty((gy, 9 * C), dtype=torch.float32, device=x.device)
     LIB.call("seg_dwconv3x3_wgrad", _DT[x.dtype], _p(x), ldx, N, Hi, Wi, C, _p(dy), lddy, Ho, Wo,
              stride, dil, mode, _p(ps), _p(pt), _p(partial), gy, _stream())

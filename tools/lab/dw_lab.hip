@@ -11,7 +11,7 @@ extern "C" int seg_dwconv3x3(int dtype, int mode, const void* x, long ldx, int N
                              const float* w9c, int w_layout, int stride, int dil, int pro_mode, const float* ps,
                              const float* pt, void* y, long ldy, int Ho, int Wo, float* stat_partial,
                              int grid_y, void* stream);
-extern "C" int seg_dwconv_grid_y(int dtype, int C, int N, int Ho, int Wo, int stride, int dil);
+extern "C" int seg_dwconv_grid_y(int dtype, int C, int N, int Ho, int Wo, int stride, int dil, int kind);
 extern "C" const char* seg_last_error();
 
 __device__ __forceinline__ void unpack(const uint4& v, float* f) {
@@ -183,7 +183,7 @@ int main() {
     const int tiles_h = (H + TH - 1) / TH, tiles_w = (W + TW - 1) / TW;
     const int ntiles = N * tiles_h * tiles_w;
     CK(hipMalloc(&stat, (size_t)ntiles * 2 * C * 4));
-    const int gy = seg_dwconv_grid_y(1, C, N, H, W, 1, 1);
+    const int gy = seg_dwconv_grid_y(1, C, N, H, W, 1, 1, 0);
     CK(hipMalloc(&stat2, (size_t)gy * 2 * C * 4));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     auto timeit = [&](const char* name, auto fn) {
