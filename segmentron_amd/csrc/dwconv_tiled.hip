@@ -652,7 +652,11 @@ int dw_tiled_grid_y(int dtype, int C, int N, int H, int W, int kind) {
     const char* e = getenv("SEG_DW_FWD_BLOCKS");  // experiment knob
     return e ? atoi(e) : 2048;
   }();
-  long cap = (kind == 0 ? fwd_cap : kind == 1 ? 512 : 768) / gx;
+  static const int bwd_cap = [] {
+    const char* e = getenv("SEG_DW_BWD_BLOCKS");  // experiment knob
+    return e ? atoi(e) : 512;
+  }();
+  long cap = (kind == 0 ? fwd_cap : kind == 1 ? bwd_cap : 768) / gx;
   if (cap < 1) cap = 1;
   long gy = a.ntiles;
   if (gy > cap) gy = cap;
