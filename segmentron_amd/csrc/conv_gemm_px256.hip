@@ -27,6 +27,9 @@ constexpr int PX_BM = 256, PX_BN = 128;
 constexpr int PX_SA = PX_BM * ROW_STRIDE;  // pixel operand tile (36864 B)
 constexpr int PX_SB = PX_BN * ROW_STRIDE;  // weight operand tile (18432 B)
 
+// (Tried and removed, r01: a two-LDS-stage / two-register-stage variant with one barrier per slab
+// and one block per CU — hipcc spread the 128 accumulators over VGPRs AND AGPRs with ~800
+// v_accvgpr moves per K loop; 36.7 -> 64.7 us on 728->728.  See profiles/r01_pmc_px256.md.)
 template <typename T>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_gemm_px256_kernel(const ConvGemmArgs a) {
   constexpr int VEC = Vec<T>::N;
@@ -80,42 +83,41 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_gemm_px256_kernel(const 
     }
   }
 
-  uint4 ra[8], rbv[4];
-  bool kok = false;
-  auto load_slab = [&](int kt) {
-    kok = kt * BK + vc * VEC < a.K;
+  struct Regs { uint4 a[8]; uint4 b[4]; bool kok; };
+  auto load_slab = [&](int kt, Regs& r) {
+    r.kok = kt * BK + vc * VEC < a.K;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      ra[j] = make_uint4(0, 0, 0, 0);
-      if (kok && ((row_ok >> j) & 1u)) ra[j] = X[aoff[j] + kt * (BK / VEC)];
+      r.a[j] = make_uint4(0, 0, 0, 0);
+      if (r.kok && ((row_ok >> j) & 1u)) r.a[j] = X[aoff[j] + kt * (BK / VEC)];
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      rbv[j] = make_uint4(0, 0, 0, 0);
-      if (kok && ((col_ok >> j) & 1u)) rbv[j] = W[boff[j] + kt * (BK / VEC)];
+      r.b[j] = make_uint4(0, 0, 0, 0);
+      if (r.kok && ((col_ok >> j) & 1u)) r.b[j] = W[boff[j] + kt * (BK / VEC)];
     }
   };
-  auto stage = [&](int kt) {
+  auto stage = [&](int kt, Regs& r, unsigned char* dA, unsigned char* dB) {
     // registers -> LDS; the producer's BatchNorm(+ReLU) rides on the pixel operand (rows beyond
     // M and columns beyond K stay exactly zero)
-    if (a.pro_mode != PRO_NONE && kok) {
+    if (a.pro_mode != PRO_NONE && r.kok) {
       const int c = kt * BK + vc * VEC;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         if ((row_ok >> j) & 1u) {
           float f[VEC];
-          Vec<T>::unpack(ra[j], f);
+          Vec<T>::unpack(r.a[j], f);
           apply_prologue<VEC>(f, a.pro_mode, a.pro_scale, a.pro_shift, c);
-          ra[j] = Vec<T>::pack(f);
+          r.a[j] = Vec<T>::pack(f);
         }
       }
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j)
-      *reinterpret_cast<uint4*>(sA + (rb + 32 * j) * ROW_STRIDE + vc * 16) = ra[j];
+      *reinterpret_cast<uint4*>(dA + (rb + 32 * j) * ROW_STRIDE + vc * 16) = r.a[j];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-      *reinterpret_cast<uint4*>(sB + (rb + 32 * j) * ROW_STRIDE + vc * 16) = rbv[j];
+      *reinterpret_cast<uint4*>(dB + (rb + 32 * j) * ROW_STRIDE + vc * 16) = r.b[j];
   };
 
   f32x16 acc[2][4];
@@ -127,26 +129,46 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_gemm_px256_kernel(const 
       for (int e = 0; e < 16; ++e) acc[jc][ip][e] = 0.f;
 
   const int r32 = lane & 31, hh = lane >> 5;
-  const unsigned char* fragP = sA + (wp * 128 + r32) * ROW_STRIDE + hh * 16;
-  const unsigned char* fragC = sB + (wc * 64 + r32) * ROW_STRIDE + hh * 16;
-  const int nk = (a.K + BK - 1) / BK;
-  load_slab(0);
-  for (int kt = 0; kt < nk; ++kt) {
-    stage(kt);
-    __syncthreads();
-    if (kt + 1 < nk) load_slab(kt + 1);  // global loads in flight under the MFMAs
+  const int fragP = (wp * 128 + r32) * ROW_STRIDE + hh * 16;  // byte offsets inside a stage
+  const int fragC = (wc * 64 + r32) * ROW_STRIDE + hh * 16;
+  // Fragment reads software-pipelined by hand: the six fragments of k-step s+1 are requested
+  // before the eight MFMAs of step s are issued, into their own registers.  (Left to itself the
+  // compiler re-used ONE register quad for consecutive pixel fragments: ds_read -> wait -> 2 MFMAs
+  // -> ds_read ..., i.e. a full LDS round trip in front of every MFMA pair.)
+  auto mma = [&](const unsigned char* bA, const unsigned char* bB) {
+    uint4 cf[2][2], pf[2][4];
+    auto frags = [&](int s, int set) {
+      cf[set][0] = *reinterpret_cast<const uint4*>(bB + fragC + s * 32);
+      cf[set][1] = *reinterpret_cast<const uint4*>(bB + fragC + 32 * ROW_STRIDE + s * 32);
+#pragma unroll
+      for (int ip = 0; ip < 4; ++ip)
+        pf[set][ip] = *reinterpret_cast<const uint4*>(bA + fragP + ip * 32 * ROW_STRIDE + s * 32);
+    };
+    frags(0, 0);
 #pragma unroll
     for (int s = 0; s < ROW_BYTES / 32; ++s) {
-      const uint4 c0 = *reinterpret_cast<const uint4*>(fragC + s * 32);
-      const uint4 c1 = *reinterpret_cast<const uint4*>(fragC + 32 * ROW_STRIDE + s * 32);
+      if (s + 1 < ROW_BYTES / 32) frags(s + 1, (s + 1) & 1);
+      // keep those reads ABOVE this step's MFMAs (bf16; the fp32 instantiation has no spare
+      // registers for the second fragment set and is left to the compiler)
+      if (sizeof(T) == 2) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int ip = 0; ip < 4; ++ip) {
-        const uint4 p = *reinterpret_cast<const uint4*>(fragP + ip * 32 * ROW_STRIDE + s * 32);
-        Mma<T>::step(c0, p, acc[0][ip]);
-        Mma<T>::step(c1, p, acc[1][ip]);
+        Mma<T>::step(cf[s & 1][0], pf[s & 1][ip], acc[0][ip]);
+        Mma<T>::step(cf[s & 1][1], pf[s & 1][ip], acc[1][ip]);
       }
     }
-    __syncthreads();
+  };
+  const int nk = (a.K + BK - 1) / BK;
+  {
+    Regs r;
+    load_slab(0, r);
+    for (int kt = 0; kt < nk; ++kt) {
+      stage(kt, r, sA, sB);
+      __syncthreads();
+      if (kt + 1 < nk) load_slab(kt + 1, r);  // global loads in flight under the MFMAs
+      mma(sA, sB);
+      __syncthreads();
+    }
   }
 
   // ---- epilogue, per wave and 32-pixel tile: channel groups -> LDS patch [32 px][64 ch] ->
