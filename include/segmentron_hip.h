@@ -81,8 +81,8 @@ int seg_conv_gemm_wgrad_config(int double_buffer);
  * stat_partial (forward only, nullable): [grid_y][2][C].  grid_y from seg_dwconv_grid_y. */
 int seg_dwconv3x3(int dtype, int mode, const void* x, long ldx, int N, int Hi, int Wi, int C,
                   const float* w9c, int w_layout, int stride, int dil, int pro_mode,
-                  const float* pro_scale, const float* pro_shift, void* y, long ldy, int Ho, int Wo, float* stat_partial,
-                  int grid_y, void* stream);
+                  const float* pro_scale, const float* pro_shift, void* y, long ldy, int Ho, int Wo,
+                  float* stat_partial, int grid_y, void* stream);
 /* partial rows (= persistent blocks per channel block) of one depthwise launch.
  * kind: 0 forward / data gradient, 1 fused backward, 2 weight gradient */
 int seg_dwconv_grid_y(int dtype, int C, int N, int Ho, int Wo, int stride, int dil, int kind);
@@ -98,13 +98,14 @@ int seg_dwconv3x3_wgrad(int dtype, const void* x, long ldx, int N, int Hi, int W
  *   g[p]  = relu_mask(x[p]) * sum_k dy[p - d_k] * w9c[k]        (gradient wrt act(x), masked)
  *   partial_w  [grid_y][9][C] : weight-gradient partials (sum rows -> dW[9][C])
  *   partial_bn [grid_y][2][C] : (sum g, sum g*x_raw) for seg_bn_bwd_finalize_p (nullable)
- * x is the forward input (raw tensor + prologue), w9c the forward taps.  grid_y from
- * seg_dwconv_grid_y(dtype, C, N, H, W). */
+ * x is the forward input (raw tensor + prologue), w9c the FORWARD taps (w_layout as above, bit 1
+ * unused).  grid_y from seg_dwconv_grid_y(dtype, C, N, H, W, 1, dil, 1).  dil <= 2: LDS-tiled
+ * kernel with a tile software pipeline (csrc/dwconv_tiled.hip); wider dilations: strip kernel. */
 int seg_dwconv3x3_bwd_fused(int dtype, const void* dy, long lddy, const void* x, long ldx, int N,
                             int H, int W, int C, const float* w9c, int w_layout, int dil,
-                            int pro_mode,
-                            const float* pro_scale, const float* pro_shift, void* g, long ldg,
-                            float* partial_w, float* partial_bn, int grid_y, void* stream);
+                            int pro_mode, const float* pro_scale, const float* pro_shift, void* g,
+                            long ldg, float* partial_w, float* partial_bn, int grid_y,
+                            void* stream);
 
 /* ---- nn.BatchNorm2d / nn.SyncBatchNorm (train + eval, forward + backward) -------------------
  * Replaces F.batch_norm behind every `bn*` module (segmentron/modules/basic.py:41,43,70;
