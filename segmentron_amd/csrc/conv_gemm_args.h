@@ -25,7 +25,6 @@ struct ConvGemmArgs {
   int M, K;
   int out_H, out_W, out_s;  // output row scatter geometry (out_s == 1 -> dense rows)
   int tiles_m, tiles_n;
-  int l2_warm;  // px256: touch the block's pixel panel before the K loop
 };
 
 int px256_tiles_m(long M);

@@ -353,7 +353,6 @@ extern "C" int seg_conv_gemm_fwd(int dtype, const void* x, long ldx, int N, int 
   a.M = N * Ho * Wo; a.K = KH * KW * C;
   a.out_H = out_H; a.out_W = out_W; a.out_s = out_s;
   a.tiles_m = (a.M + BM - 1) / BM; a.tiles_n = (O + BN - 1) / BN;
-  a.l2_warm = 0;
   SEG_REQUIRE(out_s == 1 || stat_partial == nullptr, "conv_gemm_fwd: no statistics with scatter");
   if (g_gemm_px256 && gemm_use_px256(KH, KW, stride, pad, tconv, O, a.M) && out_s == 1)
     return launch_conv_gemm_px256(dtype, a, (hipStream_t)stream);

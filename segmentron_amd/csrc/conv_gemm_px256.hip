@@ -66,23 +66,6 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_gemm_px256_kernel(const 
     if (o < a.O) col_ok |= 1u << j;
   }
 
-  // ---- experiment knob (SEG_GEMM_L2_WARM=1, default off): touch this block's whole pixel panel
-  // (256 rows x K, one dword per 128-byte line) before the K loop.  Hypothesis was that the
-  // pixel operand pays a fabric round trip per K slab; measured (tools/gemm_probe.py,
-  // 728->728 @2x65x129): 36.9 -> 43.1 us, and a lone block per CU 23.3 -> 25.0 us, i.e. the
-  // per-slab time is NOT an L2-miss latency (PMC: FETCH_SIZE = 1.4x the operand bytes).
-  unsigned touch = 0;
-  if (a.l2_warm) {
-    const int p = m0 + tid;  // one panel row per thread
-    if (p < a.M) {
-      const unsigned* __restrict__ row =
-          reinterpret_cast<const unsigned*>(a.x) + (long)p * (a.ldx * (long)sizeof(T) / 4);
-      const int lines = (a.K * (int)sizeof(T) + 127) / 128;
-#pragma unroll 4
-      for (int l = 0; l < lines; ++l) touch ^= row[l * 32];
-    }
-  }
-
   struct Regs { uint4 a[8]; uint4 b[4]; bool kok; };
   auto load_slab = [&](int kt, Regs& r) {
     r.kok = kt * BK + vc * VEC < a.K;
@@ -244,7 +227,6 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_gemm_px256_kernel(const 
     }
     __syncthreads();
   }
-  if (touch == 0x9e3779b9u && a.M < 0) a.stat_partial[0] = 0.f;  // keeps the warm-up loads alive
   if (a.stat_partial != nullptr) {
     // lanes sharing a vector column differ in lane bits >= log2(VPR): fold them, then the two
     // pixel halves through LDS: red[wp][2][128]
@@ -279,11 +261,6 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_gemm_px256_kernel(const 
 int px256_tiles_m(long M) { return (int)((M + PX_BM - 1) / PX_BM); }
 
 int launch_conv_gemm_px256(int dtype, ConvGemmArgs a, hipStream_t stream) {
-  static const int warm = [] {
-    const char* e = getenv("SEG_GEMM_L2_WARM");
-    return e ? atoi(e) : 0;
-  }();
-  a.l2_warm = warm && a.K * (dtype == DT_BF16 ? 2 : 4) >= 512;  // >= 4 lines per row
   a.tiles_m = px256_tiles_m(a.M);
   a.tiles_n = (a.O + PX_BN - 1) / PX_BN;
   const dim3 grid(a.tiles_m * a.tiles_n), block(GEMM_THREADS);
