@@ -112,3 +112,28 @@ def test_product_fails_loudly_without_a_device(c3_cfg):
     model = segmentron_amd.get_segmentation_model().eval()
     with pytest.raises(RuntimeError):
         model(torch.zeros(1, 3, 33, 33))
+
+
+def test_evaluate_glue_matches_the_reference_fixture():
+    """SegBaseModel.evaluate (segbase.py:44-79): multi-scale / flip / pad / crop glue, called
+    unbound on a stub forward, vs fixtures generated by the REFERENCE's own method
+    (oracle/gen_golden_eval.py) — including the reference's F.pad argument order."""
+    import os
+
+    import numpy as np
+    import torch
+
+    from conftest import GOLDEN
+    from oracle.gen_golden_eval import CASES, Stub, image
+    from segmentron_amd.config import cfg, reset_cfg
+    from segmentron_amd.models.segbase import SegBaseModel
+    gold = np.load(os.path.join(GOLDEN, "evaluate_cases.npz"))
+    for name, (h, w), scales, flip, crop in CASES:
+        reset_cfg()
+        cfg.TEST.SCALES, cfg.TEST.FLIP, cfg.TEST.CROP_SIZE = scales, flip, crop
+        with torch.no_grad():
+            got = SegBaseModel.evaluate(Stub(), image(h, w))
+        ref = torch.from_numpy(gold[name])
+        assert got.shape == ref.shape, name
+        assert (got - ref).abs().max().item() <= 1e-5 * ref.abs().max().item(), name
+    reset_cfg()
