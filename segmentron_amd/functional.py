@@ -95,8 +95,15 @@ def finish_bn(bn, partial, count, mean_offset=None):
         C = partial.shape[-1]
         sums = K.colsum(partial.view(partial.shape[0], 2 * C))
         sums, cnt = parallel.allreduce_forward_sums(sums, cnt, group)
+        naive = parallel.is_naive_sync(bn)
+        if naive:  # the reference's own SyncBN: biased running_var, no counter (batch_norm.py:174)
+            rm = rv = None
         mean, invstd, scale, shift = K.bn_finalize(sums, cnt, bn.weight, bn.bias, bn.eps,
                                                    momentum, rm, rv, mean_offset)
+        if naive and track:
+            mo = mean if mean_offset is None else mean + mean_offset
+            parallel.naive_running_update(bn, mo, invstd)
+            track = False
     if track and bn.num_batches_tracked is not None:
         _PENDING_COUNTERS.append(bn.num_batches_tracked)
     return BNState(bn.weight, bn.bias, mean, invstd, scale, shift, cnt, True, group)

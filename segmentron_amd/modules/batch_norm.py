@@ -9,9 +9,14 @@ is a SyncBatchNorm."""
 import torch.nn as nn
 
 
-class NaiveSyncBatchNorm(nn.SyncBatchNorm):
-    """'SyncBN' of the reference (segmentron/modules/batch_norm.py:150-183): cross-rank batch
-    statistics.  Here it is served by the same fused statistics all-reduce as nn.SyncBatchNorm."""
+class NaiveSyncBatchNorm(nn.BatchNorm2d):
+    """'SyncBN' of the reference (segmentron/modules/batch_norm.py:150-183).  Like there it IS an
+    nn.BatchNorm2d (so `_set_batch_norm_attr`, `convert_sync_batchnorm` and state_dicts treat it
+    as one) and behaves as plain BatchNorm in eval mode / with one process.  Training with
+    world_size > 1: cross-rank batch statistics (equal weight per rank), `running_var` updated
+    with the BIASED variance and `num_batches_tracked` left alone (`:172-176` never calls
+    `super().forward`).  Served by the same fused statistics all-reduce as nn.SyncBatchNorm
+    (segmentron_amd.functional.finish_bn / parallel.naive_running_update)."""
 
 
 def get_norm(norm):

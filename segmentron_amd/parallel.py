@@ -12,12 +12,33 @@ import torch.distributed as dist
 import torch.nn as nn
 
 
+def is_naive_sync(bn):
+    """The reference's own NaiveSyncBatchNorm (an nn.BatchNorm2d subclass)."""
+    return type(bn).__name__ == "NaiveSyncBatchNorm" and isinstance(bn, nn.BatchNorm2d)
+
+
 def sync_group(bn):
     """Process group to synchronise over, or None (plain BN / eval / single process)."""
-    if isinstance(bn, nn.SyncBatchNorm) and bn.training and dist.is_available() \
-            and dist.is_initialized() and dist.get_world_size() > 1:
+    if not (bn.training and dist.is_available() and dist.is_initialized()
+            and dist.get_world_size() > 1):
+        return None
+    if isinstance(bn, nn.SyncBatchNorm):
         return bn.process_group if bn.process_group is not None else dist.group.WORLD
+    if is_naive_sync(bn):
+        return dist.group.WORLD
     return None
+
+
+def naive_running_update(bn, mean, invstd):
+    """Running statistics of the reference's NaiveSyncBatchNorm (batch_norm.py:174-176):
+    `running += momentum * (batch - running)` with the BIASED batch variance; the counter
+    `num_batches_tracked` is not touched."""
+    import torch
+    with torch.no_grad():
+        m = bn.momentum
+        var = invstd.double().pow(-2) - bn.eps  # invstd = rsqrt(var_biased + eps)
+        bn.running_mean += m * (mean.to(bn.running_mean.dtype) - bn.running_mean)
+        bn.running_var += m * (var.to(bn.running_var.dtype) - bn.running_var)
 
 
 def allreduce_forward_sums(sums, local_count, group):

@@ -76,6 +76,17 @@ def _worker(rank, world, port, ret):
         avg /= world  # DDP averages
         assert torch.allclose(avg[0], gamma.grad / world, rtol=1e-9, atol=1e-11)
         assert torch.allclose(avg[1], beta.grad / world, rtol=1e-9, atol=1e-11)
+        # ---- the reference's own NaiveSyncBatchNorm (modules/batch_norm.py:150-183): an
+        # nn.BatchNorm2d that syncs when training on > 1 rank, biased running_var, no counter
+        from segmentron_amd.modules.batch_norm import NaiveSyncBatchNorm
+        nb = NaiveSyncBatchNorm(C, eps=eps, momentum=0.1).double().train()
+        assert isinstance(nb, torch.nn.BatchNorm2d) and not isinstance(nb, torch.nn.SyncBatchNorm)
+        assert parallel.sync_group(nb) is dist.group.WORLD
+        assert parallel.sync_group(NaiveSyncBatchNorm(C).eval()) is None
+        parallel.naive_running_update(nb, mean, invstd)
+        assert torch.allclose(nb.running_mean, 0.1 * mean, rtol=1e-12, atol=1e-14)
+        assert torch.allclose(nb.running_var, 1 + 0.1 * (var - 1), rtol=1e-9, atol=1e-12)
+        assert int(nb.num_batches_tracked) == 0
         ret[rank] = 1
     finally:
         dist.destroy_process_group()
