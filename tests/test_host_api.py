@@ -137,3 +137,18 @@ def test_evaluate_glue_matches_the_reference_fixture():
         assert got.shape == ref.shape, name
         assert (got - ref).abs().max().item() <= 1e-5 * ref.abs().max().item(), name
     reset_cfg()
+
+
+def test_cfg_default_tree_equals_the_reference():
+    """Every key and default of segmentron/config/settings.py (dumped from the reference by
+    oracle/gen_golden_cfg.py) — the contract with the reference's yaml files / command lines."""
+    import json
+    import os
+
+    from conftest import GOLDEN
+    from oracle.gen_golden_cfg import plain
+    from segmentron_amd.config import cfg, reset_cfg
+    reset_cfg()
+    ref = json.load(open(os.path.join(GOLDEN, "cfg_defaults.json")))
+    mine = json.loads(json.dumps(plain(dict(cfg)), sort_keys=True))
+    assert mine == ref
