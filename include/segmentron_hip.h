@@ -119,9 +119,12 @@ int seg_colsum(const float* in, long R, int L, double* out_d, float* out_f, doub
  * scale = gamma*invstd, shift = beta - mean*scale; updates running stats (nullable) with the
  * unbiased variance and `momentum`.  mean_offset (nullable, [C]) is added to the batch mean for the
  * running_mean update only: the per-channel constant a folded convolution (seg_fold_weights) leaves
- * out of its stored output because the following BatchNorm cancels it. */
-int seg_bn_finalize(const double* sums, double count, const float* gamma, const float* beta,
-                    float eps, float momentum, float* running_mean, float* running_var,
+ * out of its stored output because the following BatchNorm cancels it.
+ * count_dev (nullable, here and in the backward finalizes): a DEVICE double that overrides
+ * `count` — the SyncBatchNorm caller all-reduces [sums | local count] as one message and passes
+ * &buf[2C], so unequal per-rank shards are exact without a host read-back. */
+int seg_bn_finalize(const double* sums, double count, const double* count_dev,
+                    const float* gamma, const float* beta, float eps, float momentum, float* running_mean, float* running_var,
                     float* mean, float* invstd, float* scale, float* shift, int C,
                     const float* mean_offset, void* stream);
 /* Single-process BatchNorm: the same directly from the [R][2][C] fp32 partial rows the conv /
@@ -150,8 +153,8 @@ int seg_bn_bwd_reduce(int dtype, const void* g, long ldg, const void* x, long ld
                       const float* scale, const float* shift, const float* chan_mul,
                       long rows_per_n, const void* elem_mul, long ldm, long M, int C,
                       float* partial, int grid_y, void* stream);
-int seg_bn_bwd_finalize(const double* sums, double count, const float* mean, const float* invstd,
-                        const float* gamma, float* dgamma, float* dbeta, float* c0, float* c1,
+int seg_bn_bwd_finalize(const double* sums, double count, const double* count_dev,
+                        const float* mean, const float* invstd, const float* gamma, float* dgamma, float* dbeta, float* c0, float* c1,
                         int C, void* stream);
 int seg_bn_bwd_finalize_p(const float* partial, long R, double count, const float* mean,
                           const float* invstd, const float* gamma, float* dgamma, float* dbeta,
@@ -178,8 +181,8 @@ int seg_fold_bwd_rows(int O);
 int seg_fold_bwd_reduce(const float* W, const float* dWp, int splits, const float* scale,
                         const float* shift, const float* db, float* dW, float* dsdt, int O, int C,
                         void* stream);
-int seg_fold_bwd_finalize(const float* dsdt, int rows, double count, const float* mean, const float* invstd,
-                          const float* gamma, const float* scale, float* dgamma, float* dbeta,
+int seg_fold_bwd_finalize(const float* dsdt, int rows, double count, const double* count_dev,
+                          const float* mean, const float* invstd, const float* gamma, const float* scale, float* dgamma, float* dbeta,
                           float* c0, float* c1, int C, void* stream);
 
 /* ---- pooling --------------------------------------------------------------------------------

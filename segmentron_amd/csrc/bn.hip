@@ -58,6 +58,7 @@ __global__ __launch_bounds__(EW_THREADS) void colsum_f64_kernel(const double* __
 
 // ------------------------------------------------------------------ finalize (forward)
 __global__ void bn_finalize_kernel(const double* __restrict__ sums, double count,
+                                   const double* __restrict__ count_dev,
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float eps, float momentum, float* running_mean,
                                    float* running_var, float* mean_o, float* invstd_o,
@@ -65,6 +66,7 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sums, double count
                                    const float* __restrict__ mean_offset) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
+  if (count_dev) count = *count_dev;  // SyncBN: the all-reduced element count
   const double mean = sums[c] / count;
   double var = sums[C + c] / count - mean * mean;  // biased
   if (var < 0.0) var = 0.0;
@@ -312,12 +314,14 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_reduce_kernel(const BwdArgs
 }
 
 __global__ void bn_bwd_finalize_kernel(const double* __restrict__ sums, double count,
+                                       const double* __restrict__ count_dev,
                                        const float* __restrict__ mean,
                                        const float* __restrict__ invstd,
                                        const float* __restrict__ gamma, float* dgamma,
                                        float* dbeta, float* c0_o, float* c1_o, int C) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
+  if (count_dev) count = *count_dev;
   const double sg = sums[c], sgx = sums[C + c];
   const double mu = mean[c], is = invstd[c];
   const double dg = (sgx - mu * sg) * is;  // sum g' * xhat
@@ -504,14 +508,15 @@ extern "C" int seg_colsum(const float* in, long R, int L, double* out_d, float* 
   return check_launch("colsum");
 }
 
-extern "C" int seg_bn_finalize(const double* sums, double count, const float* gamma,
+extern "C" int seg_bn_finalize(const double* sums, double count, const double* count_dev,
+                               const float* gamma,
                                const float* beta, float eps, float momentum, float* running_mean,
                                float* running_var, float* mean, float* invstd, float* scale,
                                float* shift, int C, const float* mean_offset, void* stream) {
   using namespace seg;
-  SEG_REQUIRE(count >= 1.0 && C >= 1, "bn_finalize: bad count/C");
+  SEG_REQUIRE((count_dev || count >= 1.0) && C >= 1, "bn_finalize: bad count/C");
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream,
-                     sums, count, gamma, beta, eps, momentum, running_mean, running_var, mean,
+                     sums, count, count_dev, gamma, beta, eps, momentum, running_mean, running_var, mean,
                      invstd, scale, shift, C, mean_offset);
   return check_launch("bn_finalize");
 }
@@ -600,13 +605,14 @@ extern "C" int seg_bn_bwd_reduce(int dtype, const void* g, long ldg, const void*
   return check_launch("bn_bwd_reduce");
 }
 
-extern "C" int seg_bn_bwd_finalize(const double* sums, double count, const float* mean,
+extern "C" int seg_bn_bwd_finalize(const double* sums, double count, const double* count_dev,
+                                   const float* mean,
                                    const float* invstd, const float* gamma, float* dgamma,
                                    float* dbeta, float* c0, float* c1, int C, void* stream) {
   using namespace seg;
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0,
-                     (hipStream_t)stream, sums, count, mean, invstd, gamma, dgamma, dbeta, c0, c1,
-                     C);
+                     (hipStream_t)stream, sums, count, count_dev, mean, invstd, gamma, dgamma,
+                     dbeta, c0, c1, C);
   return check_launch("bn_bwd_finalize");
 }
 

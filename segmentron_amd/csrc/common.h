@@ -4,6 +4,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "../../include/segmentron_hip.h"  // the public C-ABI: definitions are checked against it
 
 namespace seg {
 

@@ -85,6 +85,7 @@ __global__ __launch_bounds__(256) void fold_bwd_reduce_kernel(
 }
 
 __global__ void fold_bwd_finalize_kernel(const float* __restrict__ dsdt, int R, double count,
+                                         const double* __restrict__ count_dev,
                                          const float* __restrict__ mean,
                                          const float* __restrict__ invstd,
                                          const float* __restrict__ gamma,
@@ -92,6 +93,7 @@ __global__ void fold_bwd_finalize_kernel(const float* __restrict__ dsdt, int R, 
                                          float* dbeta, float* c0, float* c1, int C) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
+  if (count_dev) count = *count_dev;
   double ds = 0.0, dt = 0.0;
   int r = 0;
   for (; r + 8 <= R; r += 8) {  // eight independent row loads in flight
@@ -149,14 +151,17 @@ extern "C" int seg_fold_bwd_reduce(const float* W, const float* dWp, int splits,
   return check_launch("fold_bwd_reduce");
 }
 
-extern "C" int seg_fold_bwd_finalize(const float* dsdt, int rows, double count, const float* mean,
+extern "C" int seg_fold_bwd_finalize(const float* dsdt, int rows, double count,
+                                     const double* count_dev, const float* mean,
                                      const float* invstd, const float* gamma, const float* scale,
                                      float* dgamma, float* dbeta, float* c0, float* c1, int C,
                                      void* stream) {
   using namespace seg;
-  SEG_REQUIRE(count >= 1.0 && C >= 1 && rows >= 1, "fold_bwd_finalize: bad count/C/rows");
+  SEG_REQUIRE((count_dev || count >= 1.0) && C >= 1 && rows >= 1,
+              "fold_bwd_finalize: bad count/C/rows");
   hipLaunchKernelGGL(fold_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0,
-                     (hipStream_t)stream, dsdt, rows, count, mean, invstd, gamma, scale, dgamma, dbeta,
+                     (hipStream_t)stream, dsdt, rows, count, count_dev, mean, invstd, gamma, scale,
+                     dgamma, dbeta,
                      c0, c1, C);
   return check_launch("fold_bwd_finalize");
 }

@@ -33,6 +33,14 @@ def _p(t):
     return 0 if t is None else t.data_ptr()
 
 
+def _count(count):
+    """BatchNorm element count: a host number, or (SyncBN) a device float64 scalar tensor that
+    came out of the statistics all-reduce -> (host double, device pointer)."""
+    if isinstance(count, torch.Tensor):
+        return 0.0, count.data_ptr()
+    return float(count), 0
+
+
 def nhwc(t):
     """-> (N, H, W, C, ld) of an NHWC view; checks it is addressable as rows with pitch ld."""
     if not t.is_cuda:
@@ -247,7 +255,7 @@ def bn_finalize(sums, count, gamma, beta, eps, momentum, running_mean, running_v
     C = sums.numel() // 2
     dev = sums.device
     out = torch.empty((4, C), dtype=torch.float32, device=dev)
-    LIB.call("seg_bn_finalize", _p(sums), float(count), _p(gamma), _p(beta), float(eps),
+    LIB.call("seg_bn_finalize", _p(sums), *_count(count), _p(gamma), _p(beta), float(eps),
              float(momentum), _p(running_mean), _p(running_var), _p(out[0]), _p(out[1]),
              _p(out[2]), _p(out[3]), C, _p(mean_offset), _stream())
     return out[0], out[1], out[2], out[3]  # mean, invstd, scale, shift
@@ -351,7 +359,7 @@ def bn_bwd_finalize_p(partial, count, mean, invstd, gamma):
 def bn_bwd_finalize(sums, count, mean, invstd, gamma):
     C = mean.numel()
     out = torch.empty((4, C), dtype=torch.float32, device=mean.device)
-    LIB.call("seg_bn_bwd_finalize", _p(sums), float(count), _p(mean), _p(invstd), _p(gamma),
+    LIB.call("seg_bn_bwd_finalize", _p(sums), *_count(count), _p(mean), _p(invstd), _p(gamma),
              _p(out[0]), _p(out[1]), _p(out[2]), _p(out[3]), C, _stream())
     return out[0], out[1], out[2], out[3]  # dgamma, dbeta, c0, c1
 
@@ -401,8 +409,8 @@ def fold_bwd_finalize(dsdt, count, mean, invstd, gamma, scale):
     C = mean.numel()
     out = torch.empty((4, C), dtype=torch.float32, device=mean.device)
     dsdt = dsdt.view(-1, 2 * C)
-    LIB.call("seg_fold_bwd_finalize", _p(dsdt), dsdt.shape[0], float(count), _p(mean), _p(invstd), _p(gamma),
-             _p(scale), _p(out[0]), _p(out[1]), _p(out[2]), _p(out[3]), C, _stream())
+    LIB.call("seg_fold_bwd_finalize", _p(dsdt), dsdt.shape[0], *_count(count), _p(mean),
+             _p(invstd), _p(gamma), _p(scale), _p(out[0]), _p(out[1]), _p(out[2]), _p(out[3]), C, _stream())
     return out[0], out[1], out[2], out[3]  # dgamma, dbeta, c0, c1
 
 
@@ -490,6 +498,8 @@ def upsample_to_nchw(x, C, out_hw, align_corners=True):
 
 def upsample_to_nchw_bwd(gy, in_hw, dtype, pitch, align_corners=True):
     """gy float32 NCHW -> NHWC [N,Hi,Wi,pitch] of `dtype` (channels >= C are zero)."""
+    if not gy.is_cuda or gy.dtype != torch.float32:
+        raise RuntimeError("upsample_to_nchw_bwd needs a float32 HIP device tensor")
     N, C, Ho, Wo = gy.shape
     Hi, Wi = in_hw
     gy = gy.contiguous()
@@ -501,6 +511,8 @@ def upsample_to_nchw_bwd(gy, in_hw, dtype, pitch, align_corners=True):
 
 def nchw_to_nhwc_pad(x, dtype):
     """float32 NCHW image (C <= 16B/elem) -> NHWC [N,H,W,VEC] zero-padded."""
+    if not x.is_cuda:
+        raise RuntimeError("segmentron_amd ops need HIP device tensors (no CPU fallback)")
     N, Cin, H, W = x.shape
     x = x.contiguous().float()
     y = torch.empty((N, H, W, vec_of(dtype)), dtype=dtype, device=x.device)

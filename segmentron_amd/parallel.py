@@ -43,9 +43,17 @@ def naive_running_update(bn, mean, invstd):
 
 def allreduce_forward_sums(sums, local_count, group):
     """sums: float64 [2C] local (sum x, sum x^2) -> (global sums, global count).
-    Shards are equal-sized (drop_last batches), so the count is local_count * world."""
-    dist.all_reduce(sums, group=group)
-    return sums, float(local_count) * dist.get_world_size(group)
+    The local element count rides in the same message ([2C+1]), so ranks with different
+    N*H*W (uneven last batch, variable-size inputs) still get the exact global statistics —
+    torch's SyncBatchNorm all-gathers per-rank counts for the same reason
+    (torch/nn/modules/_functions.py:49-74)."""
+    import torch
+    n = sums.numel()
+    buf = torch.empty(n + 1, dtype=sums.dtype, device=sums.device)
+    buf[:n] = sums
+    buf[n] = float(local_count)
+    dist.all_reduce(buf, group=group)
+    return buf[:n], buf[n:]
 
 
 def allreduce_backward_sums(sums, group):

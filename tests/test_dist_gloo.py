@@ -42,9 +42,10 @@ def _worker(rank, world, port, ret):
         assert parallel.sync_group(torch.nn.BatchNorm2d(C).train()) is None
         assert parallel.sync_group(torch.nn.SyncBatchNorm(C).eval()) is None
 
-        per = N // world
-        xs = x.detach()[rank * per:(rank + 1) * per]
-        gs = g[rank * per:(rank + 1) * per]
+        # UNEQUAL shards (1 and 3 images): the element count travels with the sums
+        lo, hi = (0, 1) if rank == 0 else (1, N)
+        xs = x.detach()[lo:hi]
+        gs = g[lo:hi]
         # ---- forward exchange
         sums = torch.cat([xs.sum((0, 2, 3)), (xs * xs).sum((0, 2, 3))])
         sums, cnt = parallel.allreduce_forward_sums(sums, xs.numel() // C, group)
@@ -68,7 +69,7 @@ def _worker(rank, world, port, ret):
         c1 = scale * (dgamma / cnt) * invstd
         c0 = scale * (sg / cnt) - c1 * mean
         dx = scale.view(1, -1, 1, 1) * gp - c0.view(1, -1, 1, 1) - c1.view(1, -1, 1, 1) * xs
-        assert torch.allclose(dx, x.grad[rank * per:(rank + 1) * per], rtol=1e-9, atol=1e-11)
+        assert torch.allclose(dx, x.grad[lo:hi], rtol=1e-9, atol=1e-11)
         # ---- parameter gradients as DistributedDataParallel will see them
         dgl, dbl = parallel.local_param_grads(dgamma, dbeta, group)
         avg = torch.stack([dgl, dbl])
