@@ -1,17 +1,11 @@
-"""Drop-in name: `import segmentron` resolves to the MI355X implementation, so the reference's
-entry points (`from segmentron.config import cfg`, `from segmentron.models.model_zoo import
-get_segmentation_model`, ...) bind to the HIP path unchanged.  Pure aliasing, no logic."""
-import importlib
+"""Drop-in name.  With this repository ahead of the reference checkout on sys.path,
+`import segmentron` serves the hot path (`segmentron.config`, `segmentron.models[.model_zoo,
+.backbones, ...]`, `segmentron.modules`, `segmentron.utils.registry`) from segmentron_amd — the
+HIP kernels — and every other `segmentron.*` module (solver, data pipeline, utils, options) from
+the reference checkout's own files, so tools/train.py, tools/eval.py and tools/demo.py run
+unchanged.  All logic lives in segmentron_amd/dropin.py."""
 import sys
 
-import segmentron_amd as _impl
+from segmentron_amd import dropin as _dropin
 
-_ALIASES = ["config", "config.config", "config.settings", "utils", "utils.registry", "modules",
-            "modules.basic", "modules.module", "modules.batch_norm", "models", "models.model_zoo",
-            "models.segbase", "models.deeplabv3_plus", "models.fcn", "models.pspnet", "models.backbones",
-            "models.backbones.build", "models.backbones.xception", "models.backbones.resnet", "models.backbones.mobilenet", "models.backbones.hrnet", "models.hrnet_seg", "data", "data.dataloader"]
-for _name in _ALIASES:
-    sys.modules["segmentron." + _name] = importlib.import_module("segmentron_amd." + _name)
-config, utils, modules, models, data = (sys.modules["segmentron." + n] for n in
-                                        ("config", "utils", "modules", "models", "data"))
-__all__ = ["config", "utils", "modules", "models", "data"]
+_dropin.install(sys.modules[__name__])
