@@ -11,19 +11,32 @@ all-reduces when N > 1) -> SGD step, on BASELINE.json configs[2]: batch 2 per GP
 `randn(2,3,1025,2049)` images and `randint(0,19)` labels with 5 % ignore, random
 init weights, bf16 compute path (fp32 accumulation / statistics / master weights / logits).
 Inputs are resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
+`python bench.py --gpus N` without a torchrun environment re-launches itself under
+`python -m torch.distributed.run` with N ranks (one per GPU, RCCL).
+
+Launch path: the step issues ~1400 kernels, and issued one by one from Python the host is the
+bottleneck (BENCH_r01: 39 ms/step against 33 ms of kernels).  With one GPU the whole step
+(forward, loss, backward, SGD) is therefore captured ONCE into a HIP graph (torch.cuda.CUDAGraph
+over the C-ABI launches — every entry point is capture-safe: no allocation, no host sync) and
+the timed region replays it; `"launch": "hip_graph"` in the line says so, `--no-graph` /
+a failed capture falls back to eager launches.  N > 1 runs eager under DDP.
 
 roofline: the dominant kernel is the MFMA implicit-GEMM `conv_gemm_px256_kernel` (every 1x1
 stride-1 convolution with O >= 384, forward + data gradient: the Xception middle / exit flow and
 ASPP — 120 of the ~157 GEMM launches per step).  `achieved` = algorithmic FLOPs
 (2 * output pixels * K * O per launch — SURVEY.md §8d counts conv MACs only) summed over its
-launches inside the timed region / summed launch durations measured with HIP events on the
-launch stream; the figure over ALL forward/dgrad GEMM launches is reported beside it
-(`all_gemm_*`).  `traffic` is filled from profiles/ (rocprofv3 PMC pass) when available.
+launches / summed launch durations measured with HIP events on the launch stream — in eager
+steps run right after the timed region when that replays a graph (events cannot bracket a node
+of a captured graph); the figure over ALL forward/dgrad GEMM launches is reported beside it
+(`all_gemm_*`).  `gpu_busy_frac` = sum of all kernel durations of one step (torch.profiler /
+roctracer over one replay) / ms_per_step.  `traffic` is filled from profiles/ (rocprofv3 PMC
+pass of this build, see profiles/traffic.json "source") when available.
 
 cpu_baseline: the CPU oracle (oracle/torch_ref.py — bit-identical to the reference's module graph
 on CPU, see oracle/gen_golden.py; the reference tree itself is not on the GPU box) timed on the
-host cores of rank 0 on a bounded sample (same network, same train step, batch 2 at 513x1025,
-1 warm-up + 1 timed, <= 32 threads) and scaled by the pixel ratio to 1025x2049-equivalent images/sec.
+host cores of rank 0 as BASELINE.md §3 plans it: the SAME train step at the full 1025x2049,
+batch 2, fp32, 1 warm-up + 2 timed steps (<= 32 threads: oneDNN collapses when oversubscribed on
+the 256-core host); `--cpu-baseline-size HxW` bounds it for quick runs.
 """
 import argparse
 import json
@@ -87,10 +100,20 @@ class GemmTimer:
         return self.flops_all, ms * 1e-3, len(self.events_all)
 
 
-def cpu_baseline():
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(size):
     from oracle import synth, torch_ref
     import segmentron_amd
-    h, w = 513, 1025  # a quarter of the pixels of the full-size step: ~10-20 s of CPU work
+    h, w = size
     threads = min(32, os.cpu_count() or 1)  # oneDNN collapses when oversubscribed (256-core host)
     torch.set_num_threads(threads)
     model = segmentron_amd.get_segmentation_model()
@@ -98,19 +121,65 @@ def cpu_baseline():
     x = synth.synth_images(BATCH, h, w, seed=0)
     y = synth.synth_targets(BATCH, h, w, seed=0)
     times = []
-    for _ in range(2):
+    for _ in range(3):  # 1 warm-up + 2 timed
         osd = torch_ref.clone_state(sd, requires_grad=True)
         net = torch_ref.OracleNet(osd, training=True, eps_encoder=1e-3)
         t0 = time.perf_counter()
         loss = torch_ref.mix_softmax_ce(net.deeplabv3_plus_xception65(x), y)
         loss.backward()
         times.append(time.perf_counter() - t0)
+        del osd, net, loss
+    t = sum(times[1:]) / 2.0
     ratio = (h * w) / float(H * W)
-    return {"value": BATCH * ratio / times[-1], "unit": "images/sec (1025x2049-equivalent)",
-            "cores": threads, "host_cores": os.cpu_count(), "kind": "port",
+    full = (h, w) == (H, W)
+    return {"value": BATCH * ratio / t, "unit": "images/sec" if full else
+            "images/sec (1025x2049-equivalent)", "cores": threads, "host_cores": os.cpu_count(),
+            "cpu_model": _cpu_model(), "torch": torch.__version__, "kind": "port",
             "sample": "oracle (torch CPU fp32 restatement of the reference graph) train fwd+bwd, "
-                      "batch 2 @%dx%d, 1 warm-up + 1 timed (%.1f s), scaled by pixel ratio %.4f"
-                      % (h, w, times[-1], ratio)}
+                      "batch 2 @%dx%d, 1 warm-up + 2 timed (%.1f s, %.1f s)%s"
+                      % (h, w, times[1], times[2],
+                         "" if full else ", scaled by pixel ratio %.4f" % ratio)}
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` outside torchrun: start N ranks the way the driver does."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def kernel_time_of_one_step(run_step):
+    """Sum of device kernel durations of one step (ms) and the kernel count, from torch.profiler
+    (roctracer); (None, None) if the profiler is unavailable."""
+    try:
+        from torch.profiler import ProfilerActivity, profile
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            run_step()
+            torch.cuda.synchronize()
+        tot_us, n = 0.0, 0
+        for ev in prof.events():
+            if getattr(ev, "device_type", None) is not None and "cuda" in str(ev.device_type).lower():
+                dur = getattr(ev, "device_time", None)
+                if dur is None:
+                    dur = getattr(ev, "cuda_time", 0.0)
+                name = ev.name.lower()
+                if "memcpy" in name or "memset" in name:
+                    continue
+                tot_us += float(dur)
+                n += 1
+        return (tot_us * 1e-3, n) if n else (None, None)
+    except Exception as e:  # noqa: BLE001 — diagnostics only, never fail the bench for it
+        sys.stderr.write("kernel_time_of_one_step: %r\n" % (e,))
+        return None, None
 
 
 def main():
@@ -122,12 +191,18 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--height", type=int, default=H)
     ap.add_argument("--width", type=int, default=W)
+    ap.add_argument("--no-graph", action="store_true", help="eager launches (no HIP graph)")
+    ap.add_argument("--cpu-baseline-size", default="%dx%d" % (H, W))
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks"
+                 % (args.gpus, world))
     # SEG_BENCH_ONE_DEVICE=1 (test plumbing): every rank on device 0 over gloo, to exercise the
     # N > 1 code path on a single-GPU box (RCCL refuses two ranks per device)
     one_dev = os.environ.get("SEG_BENCH_ONE_DEVICE") == "1"
@@ -182,23 +257,58 @@ def main():
         return loss
 
     timer = GemmTimer()
+    # ---- launch path: one HIP graph of the whole step (single GPU), else eager
+    graph, graph_err, static_loss = None, None, None
+    use_graph = world == 1 and not args.no_graph and os.environ.get("SEG_BENCH_GRAPH", "1") != "0"
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):  # eager warm-up off the default stream (lazy init, allocator,
+        for _ in range(3):         # weight-pack caches, DDP bucket rebuild)
+            step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    if use_graph:
+        try:
+            from segmentron_amd import functional as SF
+            SF.clear_weight_cache()  # the packs must be re-issued INSIDE the capture
+            opt.zero_grad(set_to_none=True)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = model(images)
+                static_loss = torch.nn.functional.cross_entropy(out[0], targets, ignore_index=-1)
+                static_loss.backward()
+                opt.step()
+            torch.cuda.synchronize()
+        except Exception as e:  # noqa: BLE001
+            graph, graph_err = None, repr(e)[:300]
+            sys.stderr.write("bench.py: HIP-graph capture failed, running eager: %s\n" % graph_err)
+            torch.cuda.synchronize()
+            from segmentron_amd import functional as SF
+            SF.clear_weight_cache()
+
+    def run_step():
+        if graph is not None:
+            graph.replay()
+            return static_loss
+        return step()
+
     # Device pre-conditioning (untimed, reported as "prewarm_steps"): a fresh box occasionally ran
     # its first 0.5 s of steps ~25 % slow (clock / power-state ramp, lazy kernel-module loads,
     # allocator growth) — a whole default-length bench fits into that window.  Run 20 extra
     # steps first, THEN the W warm-up steps and the K timed steps of the contract.
     prewarm = 20  # fixed count: every rank must issue the same collectives
     for _ in range(prewarm):
-        step()
+        run_step()
     torch.cuda.synchronize()
     for _ in range(args.warmup):
-        step()
+        run_step()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    timer.active = True
+    timer.active = graph is None
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = step()
+        loss = run_step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -209,29 +319,53 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
+    loss_value = float(loss.item())
+    # one more step under the profiler: sum of kernel durations -> gpu_busy_frac
+    kernel_ms, n_kernels = (None, None)
+    if rank == 0 and world == 1:
+        kernel_ms, n_kernels = kernel_time_of_one_step(run_step)
+    roofline_steps = args.steps
+    if graph is not None:
+        # per-launch HIP events of the dominant kernel: eager steps (same kernels, same shapes)
+        from segmentron_amd import functional as SF
+        SF.clear_weight_cache()
+        roofline_steps = 3
+        step()
+        torch.cuda.synchronize()
+        timer.active = True
+        for _ in range(roofline_steps):
+            step()
+        torch.cuda.synchronize()
+        timer.active = False
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         value = world * BATCH * args.steps / elapsed
         flops, secs, launches = timer.result()
         achieved = flops / secs / 1e12 if secs > 0 else 0.0
-        traffic = None
+        traffic = traffic_src = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get("conv_gemm_px256_bytes_per_launch")
+            tj = json.load(open(tpath))
+            traffic = tj.get("conv_gemm_px256_bytes_per_launch")
+            traffic_src = tj.get("source")
         fa, sa, la = timer.result_all()
         full = (args.height, args.width) == (H, W)
         line = {
             "metric": "images/sec fwd+bwd DeepLabv3+_xception65 @1025x2049",
             "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "prewarm_steps": prewarm, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
+            "warmup": args.warmup, "prewarm_steps": prewarm, "ms_per_step": ms,
+            "higher_is_better": True, "scaling": "weak",
+            "launch": "hip_graph" if graph is not None else "eager",
+            "gpu_kernel_ms_per_step": kernel_ms, "kernels_per_step": n_kernels,
+            "gpu_busy_frac": (kernel_ms / ms) if kernel_ms else None,
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "DeepLabv3+_xception65 train step (fwd + CE loss + bwd + SGD) "
                                    "@%dx%d, batch %d/GPU (BASELINE.json configs[2])"
                                    % (args.height, args.width, BATCH),
                        "global_batch": world * BATCH, "bn": "SyncBN" if world > 1 else "BN",
                        "parallelism": "dp%d" % world, "full_size": full,
-                       "loss": float(loss.item())},
+                       "loss": loss_value},
             "model_flop_fraction_of_bf16_mfma_peak":
                 value / world * FLOP_FWD_BWD_PER_IMAGE / MFMA_BF16_PEAK if full else None,
             "roofline": {"bound": "mfma", "kernel": "conv_gemm_px256_kernel<%s>" % args.dtype,
@@ -239,14 +373,21 @@ def main():
                          args.dtype == "bf16" else 157.3, "unit": "TFLOP/s",
                          "frac": achieved / (MFMA_BF16_PEAK / 1e12 if args.dtype == "bf16"
                                              else 157.3),
-                         "traffic": traffic, "launches_per_step": launches / max(args.steps, 1),
-                         "kernel_ms_per_step": secs * 1e3 / max(args.steps, 1),
+                         "traffic": traffic, "traffic_source": traffic_src,
+                         "launches_per_step": launches / max(roofline_steps, 1),
+                         "kernel_ms_per_step": secs * 1e3 / max(roofline_steps, 1),
+                         "timing": "HIP events around each launch, %d eager steps%s"
+                                   % (roofline_steps, " after the timed graph replays"
+                                      if graph is not None else " (the timed region)"),
                          "all_gemm_achieved": fa / sa / 1e12 if sa > 0 else 0.0,
-                         "all_gemm_launches_per_step": la / max(args.steps, 1),
-                         "all_gemm_ms_per_step": sa * 1e3 / max(args.steps, 1)},
+                         "all_gemm_launches_per_step": la / max(roofline_steps, 1),
+                         "all_gemm_ms_per_step": sa * 1e3 / max(roofline_steps, 1)},
         }
+        if graph_err:
+            line["hip_graph_error"] = graph_err
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline()
+            ch, cw = (int(v) for v in args.cpu_baseline_size.lower().split("x"))
+            line["cpu_baseline"] = cpu_baseline((ch, cw))
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -1,14 +1,14 @@
 #!/usr/bin/env python3
 """Fixtures for the other BASELINE configs, generated from the REFERENCE (dev container only).
 
-    python oracle/gen_golden_more.py c1     # FCN resnet50 (OS16)            -> tests/golden/c1_*
-    python oracle/gen_golden_more.py c4     # PSPNet resnet50 (OS8, aux)     -> tests/golden/c4_*
+    python oracle/gen_golden_more.py c1     # FCN resnet101 (OS16)           -> tests/golden/c1_*
+    python oracle/gen_golden_more.py c4     # PSPNet resnet101 (OS8, aux)    -> tests/golden/c4_*
     python oracle/gen_golden_more.py c2     # DeepLabv3+ mobilenet_v2        -> tests/golden/c2_*
     python oracle/gen_golden_more.py c5     # HRNet hrnet_w18_small_v1       -> tests/golden/c5_*
 
-One process per model (the reference cfg singleton freezes).  resnet50 is used instead of
-resnet101 to keep the fixtures small — same blocks, same code path (BASELINE C1 as written,
-"FCN-resnet18", cannot run in the reference: fcn.py:16 hard-codes 2048 input channels, F4).
+One process per model (the reference cfg singleton freezes).  C1 / C4 use resnet101, the
+backbone BASELINE.md names (BASELINE C1 as written, "FCN-resnet18", cannot run in the reference:
+fcn.py:16 hard-codes 2048 input channels, F4).
 Each run asserts that oracle/torch_ref.py reproduces the reference bit-for-bit (forward and
 every parameter gradient) before writing:
   <tag>_state_keys.json, <tag>_bn_calib.npz, <tag>_eval.npz (logits), <tag>_train.npz
@@ -28,9 +28,9 @@ from oracle import ref_import, synth, torch_ref  # noqa: E402
 
 GOLD = os.path.join(ROOT, "tests", "golden")
 CASES = {
-    "c1": dict(yaml="configs/cityscapes_fcn.yaml", over=["MODEL.BACKBONE", "resnet50"],
+    "c1": dict(yaml="configs/cityscapes_fcn.yaml", over=["MODEL.BACKBONE", "resnet101"],
                fn="fcn_resnet", os=16, aux=False, hw=(65, 97), eps_enc=None),
-    "c4": dict(yaml="configs/cityscapes_pspnet_resnet.yaml", over=["MODEL.BACKBONE", "resnet50"],
+    "c4": dict(yaml="configs/cityscapes_pspnet_resnet.yaml", over=["MODEL.BACKBONE", "resnet101"],
                fn="pspnet_resnet", os=8, aux=True, hw=(49, 65), eps_enc=None),
     "c2": dict(yaml="configs/cityscapes_deeplabv3_plus_mobilenet.yaml", over=[],
                fn="deeplab_mobilenet", os=16, aux=False, hw=(65, 97), eps_enc=None),

@@ -164,6 +164,13 @@ def cached_pack(param, kind, builder):
     return val
 
 
+def clear_weight_cache():
+    """Drop every packed weight (HIP-graph capture needs the pack launches re-issued inside the
+    captured region; after replaying a graph that steps the optimizer the cached packs no longer
+    match the parameters although `_version` did not move)."""
+    _WCACHE.clear()
+
+
 def pack_conv_weight(w, cx, dtype):
     """[O, Cw, KH, KW] fp32 -> [O, KH*KW*cx] (`dtype`), input channels zero-padded to cx."""
     O, Cw, KH, KW = w.shape

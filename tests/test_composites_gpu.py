@@ -1,0 +1,206 @@
+"""GPU parity, teacher-forced composites at REALISTIC shapes (VERDICT r01 "what's weak" 1-2).
+
+The whole-network oracle comparisons run at 65x129 .. 161x225, where the middle flow has
+M = N*H*W < 4096 pixels: the dominant 256x128-tile GEMM, the multi-tile persistent depthwise
+kernels and the split weight-gradient reduction never execute there, and on the random-init
+(chaotic) network the bf16 path can only be bounded loosely.  Here every composite of
+SURVEY.md §8(a15-a22) gets the ORACLE'S input at the shapes of the metric's configuration
+(>= 65x129 x 728 channels, batch 2) and its forward output, input gradient and EVERY parameter
+gradient are compared with
+
+  * fp32 path : the float64 oracle (oracle/torch_ref.py, the reference graph),        bar 1e-4
+  * bf16 path : the float64-accumulating bf16 emulation (oracle/bf16_emulation.py: bf16 rounding
+                at exactly the kernels' rounding points, straight-through gradients), bar 1e-2 of
+                the tensor's scale (L2), and for context the distance to the un-rounded float64
+                oracle is printed (it is dominated by ReLU-mask flips of pre-activations within
+                bf16 rounding of zero, which no bf16 implementation can avoid).
+"""
+import pytest
+import torch
+
+from _util import DEV, quant, rnd, to_cpu_nchw, to_dev_nhwc
+from oracle import synth, torch_ref
+from oracle.bf16_emulation import Bf16EmuNet, _A, r16
+
+pytestmark = pytest.mark.gpu
+DTYPES = [torch.float32, torch.bfloat16]
+IDS = ["fp32", "bf16"]
+PFX = "encoder.m"          # "encoder." prefix: the oracle applies eps_encoder = 1e-3
+
+
+def _l2(a, b):
+    return ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
+
+
+def _mx(a, b):
+    return ((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30)).item()
+
+
+def _setup(module, seed):
+    """synthetic parameters by key name; BN eps as solver/optimizer.py:18-20 sets it"""
+    sd = synth.synth_like(module.state_dict(), seed=seed)
+    module.load_state_dict(sd)
+    for m in module.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.eps = 1e-3
+    return module.to(DEV).train(), sd
+
+
+def _ref_state(sd, dtype):
+    out = {}
+    for k, v in sd.items():
+        t = v.to(dtype) if v.is_floating_point() else v.clone()
+        if t.is_floating_point() and "running_" not in k:
+            t.requires_grad_()
+        out[PFX + "." + k] = t
+    return out
+
+
+def _compare(name, dtype, got, ref64, emu, bars):
+    """got/ref64/emu: dict tensor-name -> CPU tensor.  bars = (fp32 bar, bf16-vs-emulation bar,
+    bf16-vs-fp64 sanity bar) on the L2-relative error."""
+    worst = 0.0
+    for k, g in got.items():
+        assert torch.isfinite(g).all(), "%s %s: non-finite" % (name, k)
+        e64 = _l2(g, ref64[k])
+        if dtype == torch.float32:
+            assert e64 <= bars[0], "%s %s fp32: L2-rel %.3e vs fp64 oracle > %.1e" % (
+                name, k, e64, bars[0])
+            worst = max(worst, e64)
+        else:
+            ee = _l2(g, emu[k])
+            floor = _l2(emu[k], ref64[k])
+            assert ee <= bars[1], ("%s %s bf16: L2-rel %.3e vs bf16 emulation > %.1e "
+                                   "(max-normalised %.3e; emulation itself is %.3e from fp64)"
+                                   % (name, k, ee, bars[1], _mx(g, emu[k]), floor))
+            assert e64 <= max(bars[2], 2.0 * floor + bars[1]), (
+                "%s %s bf16: L2-rel %.3e vs fp64 oracle (emulation: %.3e)" % (name, k, e64, floor))
+            worst = max(worst, ee)
+    return worst
+
+
+def _grads(params, prefix=PFX + "."):
+    return {k[len(prefix):]: v.grad.detach().float() for k, v in params.items()
+            if v.is_leaf and v.grad is not None}
+
+
+def _hip_run(F, module_fn, inputs, dy, dtype, params):
+    """inputs: list of CPU NCHW tensors -> (y NCHW, [dx NCHW], {param: grad})."""
+    xs = [to_dev_nhwc(x, dtype).requires_grad_() for x in inputs]
+    y = module_fn(*[F.Act(x) for x in xs])
+    y.backward(to_dev_nhwc(dy, dtype))
+    out = {"y": to_cpu_nchw(y)}
+    for i, x in enumerate(xs):
+        out["dx%d" % i] = to_cpu_nchw(x.grad)
+    for k, p in params:
+        assert p.grad is not None, k
+        out["d:" + k] = p.grad.detach().float().cpu()
+    return out
+
+
+def _oracle_run(fn, inputs, dy, dtype_ref, dtype=None):
+    """dy None: draw the output gradient (representable in `dtype`) once the shape is known."""
+    xs = [x.to(dtype_ref).requires_grad_() for x in inputs]
+    y = fn(*xs)
+    if dy is None:
+        dy = quant(rnd(tuple(y.shape), 9), dtype)
+    y.backward(dy.to(y.dtype))
+    out = {"y": y.detach().float(), "_dy": dy}
+    for i, x in enumerate(xs):
+        out["dx%d" % i] = x.grad.float()
+    return out
+
+
+CASES = ["sep_relu_first_728", "sep_relu_last_1536", "sep_stride2_256_728",
+         "xception_middle_728", "xception_entry_conv_256_728", "xception_exit_1536_2048",
+         "inverted_residual_32", "aspp_2048", "deeplab_head"]
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+@pytest.mark.parametrize("case", CASES)
+def test_composite_teacher_forced(case, dtype, c3_cfg):
+    import segmentron_amd
+    from segmentron_amd import functional as F
+    from segmentron_amd.models.backbones.xception import XceptionBlock
+    from segmentron_amd.models.deeplabv3_plus import _DeepLabHead
+    from segmentron_amd.modules import InvertedResidual, SeparableConv2d, _ASPP
+    segmentron_amd.set_compute_dtype(dtype)
+    torch.manual_seed(0)
+    N, H, W = 2, 65, 129       # C3's /16 feature map at 1025x2049: M = 16770 pixels
+    bars = (1e-4, 1e-2, 6e-2)
+
+    def act_in(shape, seed, relu_like=False):
+        x = rnd(shape, seed) * 1.2 + 0.1
+        return quant(x, dtype)
+
+    if case.startswith("sep_"):
+        cin, cout, stride, dil, relu_first = {
+            "sep_relu_first_728": (728, 728, 1, 1, True),
+            "sep_relu_last_1536": (1536, 1536, 1, 2, False),
+            "sep_stride2_256_728": (256, 728, 2, 1, True)}[case]
+        h, w = (H, W) if stride == 1 else (129, 257)
+        mod, sd = _setup(SeparableConv2d(cin, cout, stride=stride, dilation=dil,
+                                         relu_first=relu_first), 3)
+        inputs = [act_in((N, cin, h, w), 1)]
+        hip_fn = lambda a: F.materialize(mod(a))
+        ora = lambda net: (lambda x: net.separable_conv(x, PFX, stride, dil, relu_first))
+        emu = lambda net: (lambda x: r16(net.sep(_A(x), PFX, stride, dil, relu_first).val()))
+    elif case.startswith("xception_"):
+        ch, stride, dil, skip, relu_first, h, w = {
+            "xception_middle_728": ([728] * 4, 1, 1, "sum", True, H, W),
+            "xception_entry_conv_256_728": ([256, 728, 728, 728], 2, 1, "conv", True, 129, 257),
+            "xception_exit_1536_2048": ([1024, 1536, 1536, 2048], 1, 2, "none", False, 33, 65),
+        }[case]
+        mod, sd = _setup(XceptionBlock(ch, stride=stride, dilation=dil,
+                                       skip_connection_type=skip, relu_first=relu_first), 4)
+        inputs = [act_in((N, ch[0], h, w), 2)]
+        hip_fn = lambda a: F.materialize(mod(a))
+        ora = lambda net: (lambda x: net.xception_block(x, PFX, stride, dil, skip, relu_first))
+        emu = lambda net: (lambda x: r16(net.block(_A(x), PFX, stride, dil, skip, relu_first).val()))
+    elif case == "inverted_residual_32":
+        mod, sd = _setup(InvertedResidual(32, 32, 1, 6), 5)
+        inputs = [act_in((N, 32, 129, 257), 3)]
+        hip_fn = lambda a: F.materialize(mod(a))
+        ora = lambda net: (lambda x: torch_ref._inverted_residual(net, x, PFX, 1, 1, True))
+        emu = lambda net: (lambda x: r16(net.inverted_residual(_A(x), PFX).val()))
+    elif case == "aspp_2048":
+        mod, sd = _setup(_ASPP(2048, 256), 6)
+        mod.dropout.p = 0.0
+        inputs = [act_in((N, 2048, 33, 65), 4)]
+        hip_fn = lambda a: F.materialize(mod(a)[0])
+        ora = lambda net: (lambda x: net.aspp(x, PFX))
+        emu = lambda net: (lambda x: r16(net.aspp(_A(x), PFX + ".").val()))
+    else:  # deeplab_head: ASPP + decoder + classifier at C3's c4 / c1 shapes (513x1025 input)
+        mod, sd = _setup(_DeepLabHead(19, 256, 2048), 7)
+        mod.aspp.dropout.p = 0.0
+        inputs = [act_in((N, 2048, 33, 65), 5), act_in((N, 256, 129, 257), 6)]
+        hip_fn = lambda a, c1: mod(a, c1)
+        ora = lambda net: (lambda x, c1: net.deeplab_head(x, c1, PFX))
+        emu = lambda net: (lambda x, c1: net.head(_A(x), _A(c1), PFX + "."))
+
+    # float64 oracle (the reference graph)
+    s64 = _ref_state(sd, torch.float64)
+    net64 = torch_ref.OracleNet(s64, training=True, eps_encoder=1e-3, drop_p=0.0)
+    ref = _oracle_run(ora(net64), inputs, None, torch.float64, dtype)
+    dy = ref.pop("_dy")
+    for k, v in _grads(s64).items():
+        ref["d:" + k] = v
+    emu_out = None
+    if dtype == torch.bfloat16:
+        s32 = _ref_state(sd, torch.float32)
+        enet = Bf16EmuNet(s32, training=True, eps_encoder=1e-3, eps_decoder=1e-3, accum64=True)
+        emu_out = _oracle_run(emu(enet), inputs, dy, torch.float32)
+        emu_out.pop("_dy")
+        for k, v in _grads(s32).items():
+            emu_out["d:" + k] = v
+    got = _hip_run(F, hip_fn, inputs, dy, dtype, list(mod.named_parameters()))
+    assert set(got) == set(ref), (sorted(set(got) ^ set(ref)))
+    worst = _compare(case, dtype, got, ref, emu_out, bars)
+    print("%s %s: worst L2-rel %.3e over %d tensors (y, dx, parameter gradients)"
+          % (case, IDS[DTYPES.index(dtype)], worst, len(got)))
+    # running statistics went through the same finalize
+    msd = mod.state_dict()
+    for k in sd:
+        if k.endswith("running_var") or k.endswith("running_mean"):
+            r = s64[PFX + "." + k].float()
+            assert _l2(msd[k].cpu(), r) < (1e-4 if dtype == torch.float32 else 2e-2), k

@@ -14,9 +14,9 @@ from conftest import GOLDEN
 from oracle import synth, torch_ref
 
 CASES = {
-    "c1": dict(model="FCN", backbone="resnet50", os=16, aux=False, fn="fcn_resnet", hw=(65, 97),
+    "c1": dict(model="FCN", backbone="resnet101", os=16, aux=False, fn="fcn_resnet", hw=(65, 97),
                aux_weight=0.4),
-    "c4": dict(model="PSPNet", backbone="resnet50", os=8, aux=True, fn="pspnet_resnet", hw=(49, 65),
+    "c4": dict(model="PSPNet", backbone="resnet101", os=8, aux=True, fn="pspnet_resnet", hw=(49, 65),
                aux_weight=0.4),
     "c2": dict(model="DeepLabV3_Plus", backbone="mobilenet_v2", os=16, aux=False,
                fn="deeplab_mobilenet", hw=(65, 97), aux_weight=0.4, tie_delta=1e-5,

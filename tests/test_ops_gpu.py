@@ -52,6 +52,8 @@ CONV_CASES = [
     (1, 10, 14, 16, 24, 3, 1, 2, 2, 2, False, True),      # dilated dense
     (2, 1, 1, 2048, 256, 1, 1, 0, 1, 0, False, False),    # ASPP image-pooling (M = batch)
     (2, 7, 9, 4096, 512, 3, 1, 1, 1, 0, False, False),    # PSP head: K = 36864
+    (2, 37, 45, 4, 64, 7, 2, 3, 1, 0, False, False),      # ResNet stem 7x7 s2 p3 (resnet.py:116)
+    (1, 29, 31, 8, 64, 7, 2, 3, 1, 2, False, True),       # the same on bf16 padding, prologue
     # 256x128-tile kernel (O >= 384, M >= 4096): ragged M / O / K tails, prologue, slice output
     (2, 45, 47, 728, 728, 1, 1, 0, 1, 0, False, False),
     (1, 65, 67, 200, 392, 1, 1, 0, 1, 3, False, True),
@@ -158,6 +160,9 @@ DW_CASES = [
     (2, 33, 37, 64, 1, 6, 3),
     (1, 16, 40, 304, 1, 1, 0),
     (1, 20, 24, 2048, 1, 12, 0),
+    (1, 40, 44, 256, 1, 18, 2),     # ASPP rate 18 (OS16, module.py:39-41)
+    (2, 50, 52, 128, 1, 24, 3),     # ASPP rates 24 / 36 (OS8)
+    (1, 75, 80, 64, 1, 36, 0),
 ]
 
 

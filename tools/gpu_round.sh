@@ -1,0 +1,27 @@
+#!/bin/bash
+# One gpurun call = parity tests + the default bench + a rocprofv3 kernel-stats pass of the same
+# bench command.  Usage (from the repo root, through gpurun):
+#   gpurun --timeout 1500 -- 'bash tools/gpu_round.sh r02a [pytest-args...]'
+# Everything lands under gpurun_out/<tag>/ (copy what is to be judged into profiles/).
+TAG=${1:-run}; shift
+OUT=$PWD/gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+python -c 'import __graft_entry__ as g; g.build()' > $OUT/build.log 2>&1 || { echo BUILD FAILED; tail -30 $OUT/build.log; exit 1; }
+if [ "${SKIP_TESTS:-0}" != "1" ]; then
+  timeout 1200 python -m pytest tests -m gpu -q -x --durations=15 "$@" > $OUT/pytest.log 2>&1
+  echo "pytest rc=$?"; tail -25 $OUT/pytest.log
+fi
+if [ "${SKIP_BENCH:-0}" != "1" ]; then
+  timeout 900 python bench.py ${BENCH_ARGS:---steps 20 --warmup 5} > $OUT/bench.json 2> $OUT/bench.err
+  echo "bench rc=$?"; cat $OUT/bench.json; tail -5 $OUT/bench.err
+fi
+if [ "${SKIP_PROF:-0}" != "1" ]; then
+  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- \
+      python $OLDPWD/bench.py --steps 10 --warmup 2 --no-cpu-baseline ${PROF_ARGS:-} > $OUT/prof.log 2>&1 )
+  echo "rocprof rc=$?"
+  f=$(find $OUT/prof -name '*kernel_stats.csv' | head -1)
+  [ -n "$f" ] && cp $f $OUT/kernel_stats.csv && head -40 $OUT/kernel_stats.csv | cut -c1-200
+  # keep the merge-back small: traces are large, the stats are what gets committed
+  find $OUT/prof -name '*kernel_trace.csv' -size +20M -delete
+fi
