@@ -29,7 +29,7 @@ launches / summed launch durations measured with HIP events on the launch stream
 steps run right after the timed region when that replays a graph (events cannot bracket a node
 of a captured graph); the figure over ALL forward/dgrad GEMM launches is reported beside it
 (`all_gemm_*`).  `gpu_busy_frac` = sum of all kernel durations of one step (torch.profiler /
-roctracer over one replay) / ms_per_step.  `traffic` is filled from profiles/ (rocprofv3 PMC
+roctracer over one eager step issuing the same kernels) / ms_per_step.  `traffic` is filled from profiles/ (rocprofv3 PMC
 pass of this build, see profiles/traffic.json "source") when available.
 
 cpu_baseline: the CPU oracle (oracle/torch_ref.py — bit-identical to the reference's module graph
@@ -320,10 +320,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
     loss_value = float(loss.item())
-    # one more step under the profiler: sum of kernel durations -> gpu_busy_frac
     kernel_ms, n_kernels = (None, None)
-    if rank == 0 and world == 1:
-        kernel_ms, n_kernels = kernel_time_of_one_step(run_step)
     roofline_steps = args.steps
     if graph is not None:
         # per-launch HIP events of the dominant kernel: eager steps (same kernels, same shapes)
@@ -337,6 +334,10 @@ def main():
             step()
         torch.cuda.synchronize()
         timer.active = False
+    # one EAGER step under the profiler (roctracer does not see the nodes of a replayed graph):
+    # sum of its kernel durations / the timed ms_per_step -> gpu_busy_frac
+    if rank == 0 and world == 1:
+        kernel_ms, n_kernels = kernel_time_of_one_step(step)
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3

@@ -9,8 +9,8 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 python -c 'import __graft_entry__ as g; g.build()' > $OUT/build.log 2>&1 || { echo BUILD FAILED; tail -30 $OUT/build.log; exit 1; }
 if [ "${SKIP_TESTS:-0}" != "1" ]; then
-  timeout 1200 python -m pytest tests -m gpu -q -x --durations=15 "$@" > $OUT/pytest.log 2>&1
-  echo "pytest rc=$?"; tail -25 $OUT/pytest.log
+  timeout 1200 python -m pytest tests -m gpu -q --durations=15 "$@" > $OUT/pytest.log 2>&1
+  echo "pytest rc=$?"; grep -E "^(FAILED|ERROR)|passed|failed" $OUT/pytest.log | tail -40
 fi
 if [ "${SKIP_BENCH:-0}" != "1" ]; then
   timeout 900 python bench.py ${BENCH_ARGS:---steps 20 --warmup 5} > $OUT/bench.json 2> $OUT/bench.err
