@@ -21,9 +21,10 @@ over the C-ABI launches — every entry point is capture-safe: no allocation, no
 the timed region replays it; `"launch": "hip_graph"` in the line says so, `--no-graph` /
 a failed capture falls back to eager launches.  N > 1 runs eager under DDP.
 
-roofline: the dominant kernel is the MFMA implicit-GEMM `conv_gemm_px256_kernel` (every 1x1
-stride-1 convolution with O >= 384, forward + data gradient: the Xception middle / exit flow and
-ASPP — 120 of the ~157 GEMM launches per step).  `achieved` = algorithmic FLOPs
+roofline: the dominant kernel is the MFMA implicit-GEMM `conv_gemm_glds_kernel` (direct-to-LDS
+256x256 tiles: every 1x1 stride-1 convolution with O >= 384 whose input needs no prologue,
+forward + data gradient: the Xception middle / exit flow — ~110 of the ~157 GEMM launches per
+step).  `achieved` = algorithmic FLOPs
 (2 * output pixels * K * O per launch — SURVEY.md §8d counts conv MACs only) summed over its
 launches / summed launch durations measured with HIP events on the launch stream — in eager
 steps run right after the timed region when that replays a graph (events cannot bracket a node
@@ -71,12 +72,15 @@ class GemmTimer:
         self.events_all, self.flops_all = [], 0.0
         hip_ops.conv_gemm = self._wrapped
 
-    def _wrapped(self, x, w_packed, O, KH, KW, stride, pad, dil, *a, **kw):
+    def _wrapped(self, x, w_packed, O, KH, KW, stride, pad, dil, pro=None, bias=None, out=None,
+                 want_stats=False, scatter=None, ep=None, tconv_out_hw=None):
+        args = (x, w_packed, O, KH, KW, stride, pad, dil, pro, bias, out, want_stats, scatter, ep,
+                tconv_out_hw)
         if not self.active:
-            return self.orig(x, w_packed, O, KH, KW, stride, pad, dil, *a, **kw)
+            return self.orig(*args)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        y, p = self.orig(x, w_packed, O, KH, KW, stride, pad, dil, *a, **kw)
+        y, p = self.orig(*args)
         e1.record()
         n, hi, wi, c = x.shape
         ho = self.K.conv_out_size(hi, KH, stride, pad, dil)
@@ -84,9 +88,11 @@ class GemmTimer:
         fl = 2.0 * n * ho * wo * KH * KW * c * O
         self.flops_all += fl
         self.events_all.append((e0, e1))
-        # the dispatch rule of seg_conv_gemm_fwd (csrc/conv_gemm_fwd.hip: gemm_use_px256)
+        # the dispatch rule of seg_conv_gemm_fwd (csrc/conv_gemm_fwd.hip: gemm_use_px256 +
+        # conv_gemm_glds_usable): the direct-to-LDS 256x256 kernel
         if (KH * KW == 1 and stride == 1 and pad == 0 and O >= 384 and n * ho * wo >= 4096
-                and kw.get("scatter") is None and kw.get("tconv_out_hw") is None):
+                and scatter is None and tconv_out_hw is None and x.dtype == torch.bfloat16
+                and (pro is None or pro[0] == 0) and bias is None and O % 8 == 0):
             self.flops += fl
             self.events.append((e0, e1))
         return y, p
@@ -369,7 +375,8 @@ def main():
                        "loss": loss_value},
             "model_flop_fraction_of_bf16_mfma_peak":
                 value / world * FLOP_FWD_BWD_PER_IMAGE / MFMA_BF16_PEAK if full else None,
-            "roofline": {"bound": "mfma", "kernel": "conv_gemm_px256_kernel<%s>" % args.dtype,
+            "roofline": {"bound": "mfma", "kernel": "conv_gemm_glds_kernel (bf16)" if args.dtype == "bf16" else
+                         "conv_gemm_px256_kernel<fp32>",
                          "achieved": achieved, "peak": MFMA_BF16_PEAK / 1e12 if
                          args.dtype == "bf16" else 157.3, "unit": "TFLOP/s",
                          "frac": achieved / (MFMA_BF16_PEAK / 1e12 if args.dtype == "bf16"

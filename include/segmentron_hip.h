@@ -67,7 +67,9 @@ int seg_conv_gemm_wgrad(int dtype, const void* x, long ldx, int N, int Hi, int W
 /* rows of the [rows][2][O] statistics buffer seg_conv_gemm_fwd writes for this geometry */
 int seg_conv_gemm_stat_rows(int N, int Ho, int Wo, int O, int KH, int KW, int stride, int pad,
                             int tconv);
-/* 1 (default): 1x1 stride-1 convs on the 256x128-tile kernel; returns the previous value */
+/* tuning knob: 2 (default) = 1x1 stride-1 convs on the direct-to-LDS 256x256 bf16 kernel where
+ * it applies (no prologue / bias, O % 8 == 0) else the 256x128-tile kernel; 1 = 256x128 only;
+ * 0 = first-generation 128x128 kernel; returns the previous value, negative = query only */
 int seg_conv_gemm_px256(int enable);
 int seg_conv_gemm_wgrad_splits(int dtype, int N, int Ho, int Wo, int O, int K);
 int seg_conv_gemm_wgrad_config(int double_buffer);

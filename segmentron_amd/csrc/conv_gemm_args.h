@@ -29,5 +29,8 @@ struct ConvGemmArgs {
 
 int px256_tiles_m(long M);
 int launch_conv_gemm_px256(int dtype, ConvGemmArgs a, hipStream_t stream);
+// direct-to-LDS 256x256 kernel (conv_gemm_glds.hip): bf16, 1x1 stride 1, no prologue
+bool conv_gemm_glds_usable(int dtype, const ConvGemmArgs& a);
+int launch_conv_gemm_glds(ConvGemmArgs a, hipStream_t stream);
 
 }  // namespace seg

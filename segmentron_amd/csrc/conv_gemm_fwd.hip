@@ -271,7 +271,10 @@ __global__ __launch_bounds__(GEMM_THREADS, (DBUF || !FAST) ? 2 : 3) void conv_ge
   }
 }
 
-static int g_gemm_px256 = 1;  // 1x1 stride-1 convs on the 256x128 kernel (conv_gemm_px256.hip)
+// 1x1 stride-1 convs: 0 = first-generation 128x128 kernel, 1 = 256x128 kernel
+// (conv_gemm_px256.hip), 2 = direct-to-LDS 256x256 kernel where it applies (conv_gemm_glds.hip:
+// bf16, no prologue), 256x128 otherwise
+static int g_gemm_px256 = 2;
 static int g_gemm_dbuf = 0;  // single LDS stage, 3 blocks/CU: measured faster on every C3 shape
                              // (gpurun_out/gemm_bench2: 709 vs 622 TF on 1536->2048 @65x129)
 
@@ -299,11 +302,12 @@ extern "C" int seg_conv_gemm_config(int double_buffer) {
   return prev;
 }
 
-// 1 (default): 1x1 / stride-1 convolutions run on the 256x128-tile kernel; 0: first-generation
+// 2 (default): 1x1 / stride-1 convolutions run on the direct-to-LDS 256x256 kernel where it
+// applies and on the 256x128-tile kernel otherwise; 1: 256x128 only; 0: first-generation
 // 128x128 kernel everywhere.  Returns the previous value; a negative argument only queries.
 extern "C" int seg_conv_gemm_px256(int enable) {
   const int prev = seg::g_gemm_px256;
-  if (enable >= 0) seg::g_gemm_px256 = enable ? 1 : 0;
+  if (enable >= 0) seg::g_gemm_px256 = enable > 2 ? 2 : enable;
   return prev;
 }
 
@@ -354,8 +358,11 @@ extern "C" int seg_conv_gemm_fwd(int dtype, const void* x, long ldx, int N, int 
   a.out_H = out_H; a.out_W = out_W; a.out_s = out_s;
   a.tiles_m = (a.M + BM - 1) / BM; a.tiles_n = (O + BN - 1) / BN;
   SEG_REQUIRE(out_s == 1 || stat_partial == nullptr, "conv_gemm_fwd: no statistics with scatter");
-  if (g_gemm_px256 && gemm_use_px256(KH, KW, stride, pad, tconv, O, a.M) && out_s == 1)
+  if (g_gemm_px256 && gemm_use_px256(KH, KW, stride, pad, tconv, O, a.M) && out_s == 1) {
+    if (g_gemm_px256 >= 2 && conv_gemm_glds_usable(dtype, a))
+      return launch_conv_gemm_glds(a, (hipStream_t)stream);
     return launch_conv_gemm_px256(dtype, a, (hipStream_t)stream);
+  }
   if (dtype == DT_BF16) return launch_conv_gemm_fwd<bf16_t>(a, (hipStream_t)stream);
   return launch_conv_gemm_fwd<float>(a, (hipStream_t)stream);
 }

@@ -8,7 +8,8 @@ SURVEY.md §8(a15-a22) gets the ORACLE'S input at the shapes of the metric's con
 (>= 65x129 x 728 channels, batch 2) and its forward output, input gradient and EVERY parameter
 gradient are compared with
 
-  * fp32 path : the float64 oracle (oracle/torch_ref.py, the reference graph),        bar 1e-4
+  * fp32 path : the float64 oracle (oracle/torch_ref.py, the reference graph): as accurate as
+                the CPU float32 oracle itself (err <= 4 x its distance to float64 + 1e-4)
   * bf16 path : the float64-accumulating bf16 emulation (oracle/bf16_emulation.py: bf16 rounding
                 at exactly the kernels' rounding points, straight-through gradients), bar 1e-2 of
                 the tensor's scale (L2), and for context the distance to the un-rounded float64
@@ -56,9 +57,12 @@ def _ref_state(sd, dtype):
     return out
 
 
-def _compare(name, dtype, got, ref64, emu, bars):
-    """got/ref64/emu: dict tensor-name -> CPU tensor.  bars = (fp32 bar, bf16-vs-emulation bar,
-    bf16-vs-fp64 sanity bar) on the L2-relative error."""
+def _compare(name, dtype, got, ref64, emu, bars, ref32=None):
+    """got/ref64/emu/ref32: dict tensor-name -> CPU tensor.  bars = (fp32 bar, bf16-vs-emulation
+    bar, bf16-vs-fp64 sanity bar) on the L2-relative error.  fp32: the HIP result must be as
+    close to the float64 oracle as the CPU float32 oracle is (x4) + the bar — train-mode BatchNorm
+    backward chains amplify fp32 rounding to 1e-4..1e-3 in ANY evaluation order (the CPU fp32
+    oracle's own dx sits 4e-4 from float64 on the 728-channel block)."""
     worst = 0.0
     # gradients that are identically zero in exact arithmetic (the bias of a BatchNorm / conv
     # in front of a training-mode BatchNorm) come out as 0 here and as 1e-13 noise in the
@@ -76,9 +80,11 @@ def _compare(name, dtype, got, ref64, emu, bars):
         assert torch.isfinite(g).all(), "%s %s: non-finite" % (name, k)
         e64 = _l2(g, ref64[k], k)
         if dtype == torch.float32:
-            assert e64 <= bars[0], "%s %s fp32: L2-rel %.3e vs fp64 oracle > %.1e" % (
-                name, k, e64, bars[0])
-            worst = max(worst, e64)
+            floor = _l2(ref32[k], ref64[k], k)
+            assert e64 <= 4 * floor + bars[0], (
+                "%s %s fp32: L2-rel %.3e vs fp64 oracle (CPU fp32 oracle: %.3e)" % (name, k, e64,
+                                                                                      floor))
+            worst = max(worst, e64 / (4 * floor + bars[0]))
         else:
             ee = _l2(g, emu[k], k)
             floor = _l2(emu[k], ref64[k], k)
@@ -98,7 +104,7 @@ def _grads(params, prefix=PFX + "."):
 
 def _hip_run(F, module_fn, inputs, dy, dtype, params):
     """inputs: list of CPU NCHW tensors -> (y NCHW, [dx NCHW], {param: grad})."""
-    xs = [to_dev_nhwc(x, dtype).requires_grad_() for x in inputs]
+    xs = [to_dev_nhwc(x.detach(), dtype).detach().requires_grad_() for x in inputs]
     y = module_fn(*[F.Act(x) for x in xs])
     y.backward(to_dev_nhwc(dy, dtype))
     out = {"y": to_cpu_nchw(y)}
@@ -112,7 +118,7 @@ def _hip_run(F, module_fn, inputs, dy, dtype, params):
 
 def _oracle_run(fn, inputs, dy, dtype_ref, dtype=None):
     """dy None: draw the output gradient (representable in `dtype`) once the shape is known."""
-    xs = [x.to(dtype_ref).requires_grad_() for x in inputs]
+    xs = [x.detach().clone().to(dtype_ref).requires_grad_() for x in inputs]
     y = fn(*xs)
     if dy is None:
         dy = quant(rnd(tuple(y.shape), 9), dtype)
@@ -197,7 +203,14 @@ def test_composite_teacher_forced(case, dtype, c3_cfg):
     dy = ref.pop("_dy")
     for k, v in _grads(s64).items():
         ref["d:" + k] = v
-    emu_out = None
+    emu_out = ref32 = None
+    if dtype == torch.float32:
+        s32 = _ref_state(sd, torch.float32)
+        net32 = torch_ref.OracleNet(s32, training=True, eps_encoder=1e-3, drop_p=0.0)
+        ref32 = _oracle_run(ora(net32), inputs, dy, torch.float32)
+        ref32.pop("_dy")
+        for k, v in _grads(s32).items():
+            ref32["d:" + k] = v
     if dtype == torch.bfloat16:
         s32 = _ref_state(sd, torch.float32)
         enet = Bf16EmuNet(s32, training=True, eps_encoder=1e-3, eps_decoder=1e-3, accum64=True)
@@ -207,9 +220,10 @@ def test_composite_teacher_forced(case, dtype, c3_cfg):
             emu_out["d:" + k] = v
     got = _hip_run(F, hip_fn, inputs, dy, dtype, list(mod.named_parameters()))
     assert set(got) == set(ref), (sorted(set(got) ^ set(ref)))
-    worst = _compare(case, dtype, got, ref, emu_out, bars)
-    print("%s %s: worst L2-rel %.3e over %d tensors (y, dx, parameter gradients)"
-          % (case, IDS[DTYPES.index(dtype)], worst, len(got)))
+    worst = _compare(case, dtype, got, ref, emu_out, bars, ref32)
+    print("%s %s: worst %s %.3e over %d tensors (y, dx, parameter gradients)"
+          % (case, IDS[DTYPES.index(dtype)], "ratio to the fp32 bound" if dtype == torch.float32
+             else "L2-rel vs the bf16 emulation", worst, len(got)))
     # running statistics went through the same finalize
     msd = mod.state_dict()
     for k in sd:

@@ -52,7 +52,7 @@ CONV_CASES = [
     (1, 10, 14, 16, 24, 3, 1, 2, 2, 2, False, True),      # dilated dense
     (2, 1, 1, 2048, 256, 1, 1, 0, 1, 0, False, False),    # ASPP image-pooling (M = batch)
     (2, 7, 9, 4096, 512, 3, 1, 1, 1, 0, False, False),    # PSP head: K = 36864
-    (2, 37, 45, 4, 64, 7, 2, 3, 1, 0, False, False),      # ResNet stem 7x7 s2 p3 (resnet.py:116)
+    (2, 37, 45, 8, 64, 7, 2, 3, 1, 0, False, False),      # ResNet stem 7x7 s2 p3 (resnet.py:116)
     (1, 29, 31, 8, 64, 7, 2, 3, 1, 2, False, True),       # the same on bf16 padding, prologue
     # 256x128-tile kernel (O >= 384, M >= 4096): ragged M / O / K tails, prologue, slice output
     (2, 45, 47, 728, 728, 1, 1, 0, 1, 0, False, False),
