@@ -71,7 +71,9 @@ int seg_conv_gemm_stat_rows(int N, int Ho, int Wo, int O, int KH, int KW, int st
  * it applies (no prologue / bias, O % 8 == 0) else the 256x128-tile kernel; 1 = 256x128 only;
  * 0 = first-generation 128x128 kernel; returns the previous value, negative = query only */
 int seg_conv_gemm_px256(int enable);
-int seg_conv_gemm_wgrad_splits(int dtype, int N, int Ho, int Wo, int O, int K);
+/* splits to allocate `partial` for; plain_1x1 = 1 when the call is a 1x1 stride-1 convolution
+ * without prologue (those run on the direct-to-LDS kernel, which wants ~one block per CU) */
+int seg_conv_gemm_wgrad_splits(int dtype, int N, int Ho, int Wo, int O, int K, int plain_1x1);
 int seg_conv_gemm_wgrad_config(int double_buffer);
 
 /* ---- nn.Conv2d, groups=C, 3x3, padding=dilation (depthwise) --------------------------------

@@ -14,24 +14,11 @@
 // The BatchNorm(+ReLU) prologue of the forward pass is re-applied to X on the fly (the
 // activated tensor is never materialised in HBM, forward or backward).
 #include "conv_gemm.h"
+#include "conv_gemm_wgrad_args.h"
 #include <cstdlib>
 
 namespace seg {
 
-struct WgradArgs {
-  const void* x;
-  const void* dy;
-  float* partial;  // [splits][O][K]
-  const float* pro_scale;
-  const float* pro_shift;
-  long ldx, lddy;
-  int N, Hi, Wi, C, Ho, Wo, O;
-  int KH, KW, stride, pad, dil;
-  int pro_mode;
-  int M, K;
-  int tiles_o, tiles_k, splits;
-  int chunk;  // pixels per split (multiple of the slab depth)
-};
 
 template <typename T> struct Transpose;
 template <> struct Transpose<float> {  // 4x4: pure renaming
@@ -249,18 +236,33 @@ __global__ __launch_bounds__(GEMM_THREADS, (DBUF || sizeof(T) == 4) ? 2 : 3) voi
 
 }  // namespace seg
 
-namespace seg { static int g_wgrad_dbuf = 0; }  // see conv_gemm_fwd.hip: single stage measured faster
+namespace seg {
+static int g_wgrad_dbuf = 0;  // see conv_gemm_fwd.hip: single stage measured faster
+static int g_wgrad_glds = 1;  // plain 1x1 bf16 weight gradients on conv_gemm_wgrad_glds.hip
+}
 // tuning knob for the weight-gradient kernel, same semantics as seg_conv_gemm_config
+// bit 0: two LDS stages in the first-generation kernel; bit 1 CLEAR (default): plain 1x1 bf16
+// weight gradients run on the direct-to-LDS transpose-read kernel, SET: first generation only
 extern "C" int seg_conv_gemm_wgrad_config(int double_buffer) {
-  const int prev = seg::g_wgrad_dbuf;
-  if (double_buffer >= 0) seg::g_wgrad_dbuf = double_buffer ? 1 : 0;
+  const int prev = seg::g_wgrad_dbuf | (seg::g_wgrad_glds ? 0 : 2);
+  if (double_buffer >= 0) {
+    seg::g_wgrad_dbuf = double_buffer & 1;
+    seg::g_wgrad_glds = (double_buffer & 2) ? 0 : 1;
+  }
   return prev;
 }
 
-extern "C" int seg_conv_gemm_wgrad_splits(int dtype, int N, int Ho, int Wo, int O, int K) {
+extern "C" int seg_conv_gemm_wgrad_splits(int dtype, int N, int Ho, int Wo, int O, int K,
+                                          int plain_1x1) {
   using namespace seg;
   const int bkp = dtype == DT_BF16 ? 64 : 32;
   const long M = (long)N * Ho * Wo;
+  if (plain_1x1 && g_wgrad_glds) {  // the call will run on conv_gemm_wgrad_glds.hip
+    WgradArgs probe = {};
+    probe.KH = probe.KW = 1; probe.stride = 1; probe.pro_mode = PRO_NONE;
+    probe.C = K; probe.O = O; probe.M = (int)M; probe.ldx = 8; probe.lddy = 8;
+    if (conv_wgrad_glds_usable(dtype, probe)) return conv_wgrad_glds_splits(M, O, K);
+  }
   const int tiles = ((O + BM - 1) / BM) * ((K + BN - 1) / BN);
   static const int target = [] {
     const char* e = getenv("SEG_WGRAD_BLOCKS");  // experiment knob: total blocks aimed for
@@ -296,7 +298,11 @@ extern "C" int seg_conv_gemm_wgrad(int dtype, const void* x, long ldx, int N, in
   a.N = N; a.Hi = Hi; a.Wi = Wi; a.C = C; a.Ho = Ho; a.Wo = Wo; a.O = O;
   a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad; a.dil = dil; a.pro_mode = pro_mode;
   a.M = N * Ho * Wo; a.K = KH * KW * C;
-  a.tiles_o = (O + BM - 1) / BM; a.tiles_k = (a.K + BN - 1) / BN; a.splits = splits;
+  a.splits = splits;
+  if (g_wgrad_glds && conv_wgrad_glds_usable(dtype, a) &&
+      splits == conv_wgrad_glds_splits(a.M, O, a.K))
+    return launch_conv_wgrad_glds(a, (hipStream_t)stream);
+  a.tiles_o = (O + BM - 1) / BM; a.tiles_k = (a.K + BN - 1) / BN;
   const int slabs = (a.M + bkp - 1) / bkp;
   a.chunk = ((slabs + splits - 1) / splits) * bkp;
   const int grid = a.tiles_o * a.tiles_k * splits;
