@@ -235,6 +235,24 @@ int seg_upsample_to_nchw_bwd(int dtype, void* gx, long ldgx, int N, int Hi, int 
 int seg_nchw_to_nhwc_pad(int dtype, const float* x, int N, int Cin, int H, int W, void* y,
                          void* stream);
 
+/* ---- fused bilinear upsample -> log-softmax -> NLL (ignore_index), mean over valid pixels ------
+ * Replaces F.interpolate(mode='bilinear', align_corners) of the head's logits
+ * (segmentron/models/deeplabv3_plus.py:44, pspnet.py:34, fcn.py:28) + F.cross_entropy
+ * (segmentron/solver/loss.py:16-46: nn.CrossEntropyLoss(ignore_index=-1)) without materialising
+ * the [N, C, H, W] float32 logits.  lo: [N, Hi, Wi, ld] logits in `dtype` (C <= 32 classes, ld a
+ * vector-padded pitch); target: int64 [N, H, W]; loss_out: float32[2] = (mean loss, 1 / number
+ * of valid pixels); ws: >= 2 * seg_upsample_ce_blocks(N, H, W) doubles.  Backward: dlo
+ * [N, Hi, Wi, lddlo] in `dtype` (channels >= C written as zeros) = grad_out[0] * dLoss/dlo,
+ * up-sampling factors up to 4.1.  Deterministic (fixed-order float64 / gather reductions). */
+int seg_upsample_ce_blocks(int N, int H, int W);
+int seg_upsample_ce_fwd(int dtype, const void* lo, long ld, int N, int Hi, int Wi, int C,
+                        const long* target, int H, int W, long ignore_index, int align_corners,
+                        double* ws, float* loss_out, void* stream);
+int seg_upsample_ce_bwd(int dtype, const void* lo, long ld, int N, int Hi, int Wi, int C,
+                        const long* target, int H, int W, long ignore_index, int align_corners,
+                        const float* loss_out, const float* grad_out, void* dlo, long lddlo,
+                        void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,303 @@
+// Fused  bilinear upsample (align_corners) -> log-softmax -> NLL(ignore_index), forward and
+// backward, on the LOW-resolution NHWC logits.  Replaces, for the train step of
+// tools/train.py:135-146, the chain
+//     F.interpolate(head(x), size, mode='bilinear', align_corners=True)    deeplabv3_plus.py:44
+//     F.cross_entropy(pred, target, ignore_index=-1)                       solver/loss.py:16-46
+// whose intermediate [N, nclass, H, W] float32 logits (319 MB at 2 x 19 x 1025 x 2049) are
+// written once and read three times by five ATen kernels.  Here they are never
+// materialised: the forward interpolates, soft-maxes and reduces per output pixel; the backward
+// recomputes the soft-max and gathers the gradient straight into the low-resolution tensor.
+//
+// Numerics follow ATen: interpolation in float32 with the tap arithmetic of resize_taps.h and
+// the same association  h0l*(w0l*x00 + w1l*x01) + h1l*(w0l*x10 + w1l*x11); log-softmax as
+// z - max - log(sum exp(z - max)); loss = sum over valid pixels / number of valid pixels
+// (reduction='mean').  Sums are taken in float64 in a fixed order: bitwise deterministic.
+#include "common.h"
+#include "resize_taps.h"
+
+namespace seg {
+
+constexpr int CE_THREADS = 256;
+
+struct CeArgs {
+  const void* lo;        // [N, Hi, Wi, ld] logits, element type T
+  const long* target;    // [N, H, W] int64
+  long ld;
+  int N, Hi, Wi, H, W, C;
+  long ignore;
+  float sh, sw;
+  int align;
+};
+
+template <typename T, int NC>
+__device__ __forceinline__ void ce_load_pixel(const T* __restrict__ p, float (&f)[NC]) {
+  constexpr int VEC = Vec<T>::N;
+#pragma unroll
+  for (int v = 0; v < NC / VEC; ++v) Vec<T>::unpack(ldg16(p + v * VEC), &f[v * VEC]);
+}
+
+// z[c] of output pixel (n, h, w): NC >= C channels are loaded (the buffer is channel-padded)
+template <typename T, int NC>
+__device__ __forceinline__ void ce_logits(const CeArgs& a, int n, int h, int w, float (&z)[NC]) {
+  const T* __restrict__ X = reinterpret_cast<const T*>(a.lo);
+  int h0, h1, w0, w1; float lh, lw;
+  taps(a.sh, h, a.Hi, a.align, h0, h1, lh);
+  taps(a.sw, w, a.Wi, a.align, w0, w1, lw);
+  const long base = (long)n * a.Hi * a.Wi;
+  float f00[NC], f01[NC], f10[NC], f11[NC];
+  ce_load_pixel<T, NC>(X + (base + (long)h0 * a.Wi + w0) * a.ld, f00);
+  ce_load_pixel<T, NC>(X + (base + (long)h0 * a.Wi + w1) * a.ld, f01);
+  ce_load_pixel<T, NC>(X + (base + (long)h1 * a.Wi + w0) * a.ld, f10);
+  ce_load_pixel<T, NC>(X + (base + (long)h1 * a.Wi + w1) * a.ld, f11);
+  const float h0l = 1.f - lh, w0l = 1.f - lw;
+#pragma unroll
+  for (int c = 0; c < NC; ++c)
+    z[c] = h0l * (w0l * f00[c] + lw * f01[c]) + lh * (w0l * f10[c] + lw * f11[c]);
+}
+
+// forward: partial[block] = (sum of -log p_target over the block's valid pixels, valid count)
+template <typename T, int NC>
+__global__ __launch_bounds__(CE_THREADS) void ce_fwd_kernel(const CeArgs a, double* partial) {
+  __shared__ double red[2][CE_THREADS / 64];
+  const long total = (long)a.N * a.H * a.W;
+  double lsum = 0.0, lcnt = 0.0;
+  for (long i = (long)blockIdx.x * CE_THREADS + threadIdx.x; i < total;
+       i += (long)gridDim.x * CE_THREADS) {
+    const long t = a.target[i];
+    if (t == a.ignore) continue;
+    const int w = (int)(i % a.W);
+    const long q = i / a.W;
+    const int h = (int)(q % a.H), n = (int)(q / a.H);
+    float z[NC];
+    ce_logits<T, NC>(a, n, h, w, z);
+    float m = z[0];
+#pragma unroll
+    for (int c = 1; c < NC; ++c) m = (c < a.C) ? fmaxf(m, z[c]) : m;
+    float s = 0.f, zt = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      if (c < a.C) s += expf(z[c] - m);
+      if (c == (int)t) zt = z[c];
+    }
+    lsum += (double)(logf(s) + m - zt);
+    lcnt += 1.0;
+  }
+  // block reduction in a fixed order (wave butterfly, then the waves in index order)
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    lsum += __shfl_xor(lsum, o, 64);
+    lcnt += __shfl_xor(lcnt, o, 64);
+  }
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { red[0][wave] = lsum; red[1][wave] = lcnt; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s = 0.0, c = 0.0;
+    for (int k = 0; k < CE_THREADS / 64; ++k) { s += red[0][k]; c += red[1][k]; }
+    partial[2 * blockIdx.x] = s;
+    partial[2 * blockIdx.x + 1] = c;
+  }
+}
+
+// out[0] = loss (mean over valid pixels), out[1] = 1 / valid count (0 if none), both float32
+__global__ void ce_finalize_kernel(const double* partial, int nblocks, float* out) {
+  __shared__ double red[2][256];
+  double s = 0.0, c = 0.0;
+  for (int i = threadIdx.x; i < nblocks; i += 256) { s += partial[2 * i]; c += partial[2 * i + 1]; }
+  red[0][threadIdx.x] = s;
+  red[1][threadIdx.x] = c;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) {
+      red[0][threadIdx.x] += red[0][threadIdx.x + o];
+      red[1][threadIdx.x] += red[1][threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const double cnt = red[1][0];
+    out[0] = cnt > 0.0 ? (float)(red[0][0] / cnt) : nanf("");  // torch: mean over nothing = nan
+    out[1] = cnt > 0.0 ? (float)(1.0 / cnt) : 0.f;
+  }
+}
+
+// backward: one block per LOW-resolution tile of LT x LT pixels.  Phase 1: the block evaluates
+// dz = (softmax - onehot) for every output pixel that touches its tile (redundantly with the
+// neighbouring tiles at the borders) into LDS; phase 2: every (pixel, channel) of the tile
+// gathers its sum over those outputs in a fixed order — separably: first along w, then along h.
+// LT = low-res tile edge, HT_MAX = most output rows / columns that can touch LT low-res rows at
+// up to 4.1x upsampling: (LT + 1.5) * 4.1 + 5.  LDS: NC * HT_MAX * (HT_MAX + LT) floats.
+template <typename T, int NC, int LT, int HT_MAX>
+__global__ __launch_bounds__(CE_THREADS) void ce_bwd_kernel(const CeArgs a, const float* gscale,
+                                                            const float* gout, void* dlo,
+                                                            long lddlo) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_ce[];
+  // dz[NC][hh][ww] (float), then tmp[NC][hh][LT] reusing nothing: separate regions
+  const int tiles_w = (a.Wi + LT - 1) / LT, tiles_h = (a.Hi + LT - 1) / LT;
+  const int tw = blockIdx.x % tiles_w, th = (blockIdx.x / tiles_w) % tiles_h;
+  const int n = blockIdx.x / (tiles_w * tiles_h);
+  const int i0 = th * LT, j0 = tw * LT;
+  const int i1 = min(a.Hi, i0 + LT) - 1, j1 = min(a.Wi, j0 + LT) - 1;
+  // output range touching rows [i0, i1] / columns [j0, j1]
+  int hlo, hhi, wlo, whi, t0, t1;
+  cand_range(a.sh, i0, a.H, a.align, hlo, t1);
+  cand_range(a.sh, i1, a.H, a.align, t0, hhi);
+  cand_range(a.sw, j0, a.W, a.align, wlo, t1);
+  cand_range(a.sw, j1, a.W, a.align, t0, whi);
+  const int nh = hhi - hlo + 1, nw = whi - wlo + 1;  // <= HT_MAX (checked on the host)
+  float* dz = reinterpret_cast<float*>(smem_ce);                  // [NC][nh][nw]
+  float* tmp = dz + (long)NC * HT_MAX * HT_MAX;                   // [NC][nh][LT]
+  const float g = gout[0] * gscale[1];  // dLoss * (1 / valid count)
+  // ---- phase 1
+  for (int p = threadIdx.x; p < nh * nw; p += CE_THREADS) {
+    const int hh = p / nw, ww = p - hh * nw;
+    const int h = hlo + hh, w = wlo + ww;
+    const long t = a.target[((long)n * a.H + h) * a.W + w];
+    float z[NC];
+    if (t != a.ignore) {
+      ce_logits<T, NC>(a, n, h, w, z);
+      float m = z[0];
+#pragma unroll
+      for (int c = 1; c < NC; ++c) m = (c < a.C) ? fmaxf(m, z[c]) : m;
+      float s = 0.f;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        z[c] = (c < a.C) ? expf(z[c] - m) : 0.f;
+        s += z[c];
+      }
+      const float inv = 1.f / s;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) z[c] = (z[c] * inv - (c == (int)t ? 1.f : 0.f)) * g;
+    } else {
+#pragma unroll
+      for (int c = 0; c < NC; ++c) z[c] = 0.f;
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) dz[((long)c * HT_MAX + hh) * HT_MAX + ww] = z[c];
+  }
+  __syncthreads();
+  // ---- phase 2a: along w.  tmp[c][hh][jj] = sum_ww weight_w(w, j0+jj) * dz[c][hh][ww]
+  const int lw_n = j1 - j0 + 1, lh_n = i1 - i0 + 1;
+  for (int p = threadIdx.x; p < NC * nh * LT; p += CE_THREADS) {
+    const int jj = p % LT, hh = (p / LT) % nh, c = p / (LT * nh);
+    float acc = 0.f;
+    if (jj < lw_n && c < a.C) {
+      int clo, chi;
+      cand_range(a.sw, j0 + jj, a.W, a.align, clo, chi);
+      clo = max(clo, wlo); chi = min(chi, whi);
+      for (int w = clo; w <= chi; ++w) {
+        const float wt = tap_weight(a.sw, w, a.Wi, a.align, j0 + jj);
+        acc = fmaf(wt, dz[((long)c * HT_MAX + hh) * HT_MAX + (w - wlo)], acc);
+      }
+    }
+    tmp[((long)c * HT_MAX + hh) * LT + jj] = acc;
+  }
+  __syncthreads();
+  // ---- phase 2b: along h, and store (channels >= C are written as zero padding)
+  T* __restrict__ D = reinterpret_cast<T*>(dlo);
+  for (int p = threadIdx.x; p < lh_n * lw_n * (int)lddlo; p += CE_THREADS) {
+    const int c = p % (int)lddlo, jj = (p / (int)lddlo) % lw_n, ii = p / ((int)lddlo * lw_n);
+    float acc = 0.f;
+    if (c < a.C) {
+      int clo, chi;
+      cand_range(a.sh, i0 + ii, a.H, a.align, clo, chi);
+      clo = max(clo, hlo); chi = min(chi, hhi);
+      for (int h = clo; h <= chi; ++h) {
+        const float wt = tap_weight(a.sh, h, a.Hi, a.align, i0 + ii);
+        acc = fmaf(wt, tmp[((long)c * HT_MAX + (h - hlo)) * LT + jj], acc);
+      }
+    }
+    Vec<T>::store1(D + (((long)n * a.Hi + i0 + ii) * a.Wi + j0 + jj) * lddlo + c, acc);
+  }
+}
+
+template <int NC, int LT, int HT_MAX> constexpr size_t ce_bwd_lds() {
+  return ((size_t)NC * HT_MAX * HT_MAX + (size_t)NC * HT_MAX * LT) * sizeof(float);
+}
+// <= 24 classes: 6 x 6 tiles (137 KiB of LDS); <= 32 classes: 4 x 4 tiles (112 KiB)
+constexpr int CE_LT24 = 6, CE_HT24 = 36, CE_LT32 = 4, CE_HT32 = 28;
+static_assert(ce_bwd_lds<24, CE_LT24, CE_HT24>() <= 160 * 1024, "LDS budget");
+static_assert(ce_bwd_lds<32, CE_LT32, CE_HT32>() <= 160 * 1024, "LDS budget");
+
+template <typename T, int NC, int LT, int HT>
+static int launch_ce_bwd(int blocks, hipStream_t st, const CeArgs& a, const float* loss_out,
+                         const float* grad_out, void* dlo, long lddlo) {
+  constexpr size_t lds = ce_bwd_lds<NC, LT, HT>();
+  static const int once = (int)hipFuncSetAttribute(
+      reinterpret_cast<const void*>(&ce_bwd_kernel<T, NC, LT, HT>),
+      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  SEG_REQUIRE(once == 0, "upsample_ce_bwd: cannot reserve %d bytes of LDS", (int)lds);
+  hipLaunchKernelGGL((ce_bwd_kernel<T, NC, LT, HT>), dim3(blocks), dim3(CE_THREADS), lds, st, a,
+                     loss_out, grad_out, dlo, lddlo);
+  return 0;
+}
+
+}  // namespace seg
+
+// loss_out: float32[2] = (mean loss, 1 / valid count); ws: >= 2 * seg_upsample_ce_blocks doubles
+extern "C" int seg_upsample_ce_blocks(int N, int H, int W) {
+  const long total = (long)N * H * W;
+  long b = (total + seg::CE_THREADS - 1) / seg::CE_THREADS;
+  return (int)(b > 4096 ? 4096 : b);
+}
+
+extern "C" int seg_upsample_ce_fwd(int dtype, const void* lo, long ld, int N, int Hi, int Wi, int C,
+                                   const long* target, int H, int W, long ignore_index,
+                                   int align_corners, double* ws, float* loss_out, void* stream) {
+  using namespace seg;
+  SEG_REQUIRE(dtype == DT_F32 || dtype == DT_BF16, "upsample_ce_fwd: bad dtype %d", dtype);
+  const int vec = dtype == DT_BF16 ? 8 : 4;
+  SEG_REQUIRE(C >= 1 && C <= 32 && ld % vec == 0 && ld >= (C + vec - 1) / vec * vec,
+              "upsample_ce_fwd: C=%d must be <= 32 and the pitch %ld a padded multiple of %d", C,
+              ld, vec);
+  SEG_REQUIRE(N > 0 && Hi > 0 && Wi > 0 && H > 0 && W > 0, "upsample_ce_fwd: empty problem");
+  CeArgs a;
+  a.lo = lo; a.target = target; a.ld = ld; a.N = N; a.Hi = Hi; a.Wi = Wi; a.H = H; a.W = W;
+  a.C = C; a.ignore = ignore_index; a.align = align_corners;
+  a.sh = host_scale(Hi, H, align_corners); a.sw = host_scale(Wi, W, align_corners);
+  const int blocks = seg_upsample_ce_blocks(N, H, W);
+  hipStream_t st = (hipStream_t)stream;
+  const int nc = C <= 24 ? 24 : 32;
+  if (dtype == DT_BF16) {
+    if (nc == 24) hipLaunchKernelGGL((ce_fwd_kernel<bf16_t, 24>), dim3(blocks), dim3(CE_THREADS), 0, st, a, ws);
+    else hipLaunchKernelGGL((ce_fwd_kernel<bf16_t, 32>), dim3(blocks), dim3(CE_THREADS), 0, st, a, ws);
+  } else {
+    if (nc == 24) hipLaunchKernelGGL((ce_fwd_kernel<float, 24>), dim3(blocks), dim3(CE_THREADS), 0, st, a, ws);
+    else hipLaunchKernelGGL((ce_fwd_kernel<float, 32>), dim3(blocks), dim3(CE_THREADS), 0, st, a, ws);
+  }
+  hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(256), 0, st, ws, blocks, loss_out);
+  return check_launch("upsample_ce_fwd");
+}
+
+extern "C" int seg_upsample_ce_bwd(int dtype, const void* lo, long ld, int N, int Hi, int Wi, int C,
+                                   const long* target, int H, int W, long ignore_index,
+                                   int align_corners, const float* loss_out, const float* grad_out,
+                                   void* dlo, long lddlo, void* stream) {
+  using namespace seg;
+  SEG_REQUIRE(dtype == DT_F32 || dtype == DT_BF16, "upsample_ce_bwd: bad dtype %d", dtype);
+  const int vec = dtype == DT_BF16 ? 8 : 4;
+  SEG_REQUIRE(C >= 1 && C <= 32 && ld % vec == 0 && lddlo >= C, "upsample_ce_bwd: bad C / pitch");
+  SEG_REQUIRE(H >= Hi && W >= Wi, "upsample_ce_bwd: the fused loss is for UP-sampling heads");
+  // a low-res tile row is touched by at most HT_MAX output rows / columns up to 4.1x
+  const float sh = host_scale(Hi, H, align_corners), sw = host_scale(Wi, W, align_corners);
+  const float smin = fminf(sh > 0.f ? sh : 1.f, sw > 0.f ? sw : 1.f);
+  SEG_REQUIRE(1.f / smin <= 4.1f,
+              "upsample_ce_bwd: scale factor %.2f too large for the fused backward", 1.f / smin);
+  CeArgs a;
+  a.lo = lo; a.target = target; a.ld = ld; a.N = N; a.Hi = Hi; a.Wi = Wi; a.H = H; a.W = W;
+  a.C = C; a.ignore = ignore_index; a.align = align_corners; a.sh = sh; a.sw = sw;
+  hipStream_t st = (hipStream_t)stream;
+  const int nc = C <= 24 ? 24 : 32;
+  const int lt = nc == 24 ? CE_LT24 : CE_LT32;
+  const int blocks = N * ((Hi + lt - 1) / lt) * ((Wi + lt - 1) / lt);
+  int rc;
+  if (dtype == DT_BF16) {
+    rc = nc == 24 ? launch_ce_bwd<bf16_t, 24, CE_LT24, CE_HT24>(blocks, st, a, loss_out, grad_out, dlo, lddlo)
+                  : launch_ce_bwd<bf16_t, 32, CE_LT32, CE_HT32>(blocks, st, a, loss_out, grad_out, dlo, lddlo);
+  } else {
+    rc = nc == 24 ? launch_ce_bwd<float, 24, CE_LT24, CE_HT24>(blocks, st, a, loss_out, grad_out, dlo, lddlo)
+                  : launch_ce_bwd<float, 32, CE_LT32, CE_HT32>(blocks, st, a, loss_out, grad_out, dlo, lddlo);
+  }
+  if (rc) return rc;
+  return check_launch("upsample_ce_bwd");
+}

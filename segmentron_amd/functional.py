@@ -11,6 +11,7 @@ deferred tensor sum correctly under plain torch autograd.
 Host code here is plumbing (allocation, weight packing, torch.autograd, torch.distributed);
 all arithmetic on activations is done by libsegmentron_hip.so.
 """
+import dataclasses
 import weakref
 
 import torch
@@ -563,6 +564,122 @@ class _LogitsFn(torch.autograd.Function):
         return gx[..., :C], None, None
 
 
+class _UpsampleCEFn(torch.autograd.Function):
+    """F.cross_entropy(F.interpolate(lo, size, 'bilinear', align_corners), target, ignore_index)
+    with reduction='mean', fused (csrc/loss.hip): the full-resolution logits never exist."""
+
+    @staticmethod
+    def forward(ctx, lo, target, out_hw, ignore_index, align):
+        out = K.upsample_ce_fwd(lo, target, out_hw, ignore_index, align)
+        ctx.save_for_backward(lo, target, out)
+        ctx.meta = (tuple(out_hw), ignore_index, align)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        lo, target, out = ctx.saved_tensors
+        out_hw, ignore_index, align = ctx.meta
+        C = lo.shape[-1]
+        pitch = _round_up(C, K.vec_of(lo.dtype))
+        dlo = K.upsample_ce_bwd(lo, target, out_hw, ignore_index, out, g, pitch, align)
+        return dlo[..., :C], None, None, None, None
+
+
+@dataclasses.dataclass(eq=False, repr=False)
+class LogitsView:
+    """What a model's forward returns per head IN TRAINING MODE instead of the materialised
+    [N, nclass, H, W] float32 logits (tools/train.py:135 `outputs = self.model(images)`): the
+    head's low-resolution NHWC logits plus the requested output size.  It behaves like that
+    tensor for every consumer —
+
+      * `F.cross_entropy(view, target, ignore_index=..)` / `nn.CrossEntropyLoss` (hence the
+        reference's own MixSoftmaxCrossEntropyLoss, solver/loss.py:16-46) dispatch here through
+        the `__torch_function__` protocol and run the fused upsample + log-softmax + NLL kernels;
+      * any other torch function, attribute, method or index materialises the full tensor once
+        (seg_upsample_to_nchw, differentiable) and forwards to it.
+
+    `lo` is an ordinary autograd-connected tensor attribute, and the class is a dataclass, so
+    DistributedDataParallel(find_unused_parameters=True) still finds the graph (its
+    `_find_tensors` walks dataclass fields)."""
+    lo: torch.Tensor
+    out_hw: tuple
+    align_corners: bool = True
+    _full: object = dataclasses.field(default=None, init=False, repr=False)
+
+    def __post_init__(self):
+        self.out_hw = tuple(int(v) for v in self.out_hw)
+
+    # -- cheap metadata, no materialisation
+    @property
+    def shape(self):
+        n, _, _, c = self.lo.shape
+        return torch.Size((n, c) + self.out_hw)
+
+    def size(self, dim=None):
+        return self.shape if dim is None else self.shape[dim]
+
+    def dim(self):
+        return 4
+
+    dtype = torch.float32
+
+    @property
+    def device(self):
+        return self.lo.device
+
+    @property
+    def requires_grad(self):
+        return self.lo.requires_grad
+
+    def materialize(self):
+        if self._full is None:
+            self._full = _LogitsFn.apply(self.lo, self.out_hw, self.align_corners)
+        return self._full
+
+    def __getattr__(self, name):  # only called when normal lookup fails
+        if name.startswith("__") and name.endswith("__"):
+            raise AttributeError(name)
+        return getattr(self.materialize(), name)
+
+    def __getitem__(self, idx):
+        return self.materialize()[idx]
+
+    def __len__(self):
+        return self.lo.shape[0]
+
+    def _fusable(self, target, weight, size_average, ignore_index, reduce, reduction,
+                 label_smoothing):
+        n, hi, wi, c = self.lo.shape
+        return (weight is None and size_average is None and reduce is None
+                and reduction == "mean" and label_smoothing == 0.0 and c <= 32
+                and isinstance(target, torch.Tensor) and target.dtype == torch.int64
+                and target.dim() == 3 and tuple(target.shape) == (n,) + self.out_hw
+                and self.align_corners and self.out_hw[0] >= hi and self.out_hw[1] >= wi
+                and self.out_hw[0] <= 4.1 * hi and self.out_hw[1] <= 4.1 * wi)
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        if func is torch.nn.functional.cross_entropy and args and isinstance(args[0], cls):
+            def bind(input, target, weight=None, size_average=None, ignore_index=-100,
+                     reduce=None, reduction="mean", label_smoothing=0.0):
+                return target, weight, size_average, ignore_index, reduce, reduction, \
+                    label_smoothing
+            b = bind(*args, **kwargs)
+            view = args[0]
+            if view._fusable(*b):
+                return _UpsampleCEFn.apply(view.lo, b[0], view.out_hw, int(b[3]),
+                                           view.align_corners)
+
+        def real(o):
+            if isinstance(o, cls):
+                return o.materialize()
+            if isinstance(o, (list, tuple)):
+                return type(o)(real(v) for v in o)
+            return o
+        return func(*real(args), **{k: real(v) for k, v in kwargs.items()})
+
+
 class _GapFn(torch.autograd.Function):
     """nn.AdaptiveAvgPool2d((1,1)) of a materialised NHWC tensor -> [N,1,1,C]."""
 
@@ -712,7 +829,11 @@ def bilinear(act, out_hw, chan_mul=None, align_corners=True, out=None):
     return _BilinearFn.apply(act.t, g, b, spec)
 
 
-def logits_to_nchw(x, out_hw, align_corners=True):
+def logits_to_nchw(x, out_hw, align_corners=True, lazy=False):
+    """Model boundary.  lazy (training): a LogitsView, so that a following cross-entropy runs
+    fused on the low-resolution logits; otherwise the materialised [N, C, H, W] float32 tensor."""
+    if lazy and align_corners:
+        return LogitsView(x, out_hw, align_corners)
     return _LogitsFn.apply(x, tuple(out_hw), align_corners)
 
 

@@ -519,3 +519,34 @@ def nchw_to_nhwc_pad(x, dtype):
     y = torch.empty((N, H, W, vec_of(dtype)), dtype=dtype, device=x.device)
     LIB.call("seg_nchw_to_nhwc_pad", _DT[dtype], _p(x), N, Cin, H, W, _p(y), _stream())
     return y
+
+
+# ----------------------------------------------------------------------------- fused loss tail
+def upsample_ce_fwd(lo, target, out_hw, ignore_index, align_corners=True):
+    """lo: NHWC logits view [N,Hi,Wi,C] of a channel-padded buffer; target int64 [N,H,W].
+    -> float32[2] device tensor (mean cross-entropy over valid pixels, 1 / valid count)."""
+    N, Hi, Wi, C, ld = nhwc(lo)
+    H, W = out_hw
+    if not target.is_cuda or target.dtype != torch.int64 or tuple(target.shape) != (N, H, W):
+        raise RuntimeError("upsample_ce: target must be an int64 HIP tensor [N, H, W] = %s, got %s"
+                           % ((N, H, W), tuple(target.shape)))
+    target = target.contiguous()
+    blocks = LIB.query("seg_upsample_ce_blocks", N, H, W)
+    ws = torch.empty(2 * blocks, dtype=torch.float64, device=lo.device)
+    out = torch.empty(2, dtype=torch.float32, device=lo.device)
+    LIB.call("seg_upsample_ce_fwd", _DT[lo.dtype], _p(lo), ld, N, Hi, Wi, C, _p(target), H, W,
+             int(ignore_index), int(align_corners), _p(ws), _p(out), _stream())
+    return out
+
+
+def upsample_ce_bwd(lo, target, out_hw, ignore_index, loss_out, grad_out, pitch,
+                    align_corners=True):
+    """-> d(loss)/d(lo) * grad_out as NHWC [N,Hi,Wi,pitch] in lo.dtype (channels >= C zero)."""
+    N, Hi, Wi, C, ld = nhwc(lo)
+    H, W = out_hw
+    grad_out = grad_out.reshape(1).to(torch.float32).contiguous()
+    dlo = torch.empty((N, Hi, Wi, pitch), dtype=lo.dtype, device=lo.device)
+    LIB.call("seg_upsample_ce_bwd", _DT[lo.dtype], _p(lo), ld, N, Hi, Wi, C,
+             _p(target.contiguous()), H, W, int(ignore_index), int(align_corners), _p(loss_out),
+             _p(grad_out), _p(dlo), pitch, _stream())
+    return dlo

@@ -19,9 +19,10 @@ class FCN(SegBaseModel):
 
     def forward(self, x):
         size = x.shape[2:]
+        lazy = self.training and torch.is_grad_enabled()  # see functional.LogitsView
         _, _, c3, c4 = self.base_forward(x)
-        outputs = [F.logits_to_nchw(self.head(c4), size, align_corners=True)]
+        outputs = [F.logits_to_nchw(self.head(c4), size, align_corners=True, lazy=lazy)]
         if self.aux:
-            outputs.append(F.logits_to_nchw(self.auxlayer(c3), size, align_corners=True))
+            outputs.append(F.logits_to_nchw(self.auxlayer(c3), size, align_corners=True, lazy=lazy))
         F.flush_bn_counters()
         return tuple(outputs)

@@ -1,6 +1,7 @@
 """PSPNet — segmentron/models/pspnet.py:13-58.  (The reference's `_PSPHead` passes a stray
 `norm_kwargs` into `_ConvBNReLU` and cannot be constructed at HEAD — SURVEY.md F3; the module tree
 here is the one that constructor intends, with the same state_dict keys.)"""
+import torch
 import torch.nn as nn
 
 from .. import functional as F
@@ -23,10 +24,11 @@ class PSPNet(SegBaseModel):
 
     def forward(self, x):
         size = x.shape[2:]
+        lazy = self.training and torch.is_grad_enabled()  # see functional.LogitsView
         _, _, c3, c4 = self.encoder(x)
-        outputs = [F.logits_to_nchw(self.head(c4), size, align_corners=True)]
+        outputs = [F.logits_to_nchw(self.head(c4), size, align_corners=True, lazy=lazy)]
         if self.aux:
-            outputs.append(F.logits_to_nchw(self.auxlayer(c3), size, align_corners=True))
+            outputs.append(F.logits_to_nchw(self.auxlayer(c3), size, align_corners=True, lazy=lazy))
         F.flush_bn_counters()
         return tuple(outputs)
 

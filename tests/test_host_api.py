@@ -152,3 +152,44 @@ def test_cfg_default_tree_equals_the_reference():
     ref = json.load(open(os.path.join(GOLDEN, "cfg_defaults.json")))
     mine = json.loads(json.dumps(plain(dict(cfg)), sort_keys=True))
     assert mine == ref
+
+
+def test_logits_view_dispatch_and_ddp_visibility():
+    """functional.LogitsView (what a training-mode forward returns per head): metadata without
+    materialisation, F.cross_entropy routed to the fused kernel only for the supported variant,
+    everything else through the materialised tensor, and the low-resolution tensor visible to
+    DistributedDataParallel's output scan (tools/train.py:110 find_unused_parameters=True)."""
+    import dataclasses
+    import torch.nn.functional as TF
+    from torch.nn.parallel.distributed import _find_tensors
+    from segmentron_amd import functional as F
+    lo = torch.randn(2, 5, 7, 19, requires_grad=True)
+    v = F.LogitsView(lo, (17, 25), True)
+    assert tuple(v.shape) == (2, 19, 17, 25) and v.size(1) == 19 and v.dim() == 4
+    assert v.dtype == torch.float32 and v.requires_grad and v._full is None
+    assert dataclasses.is_dataclass(v) and [t is lo for t in _find_tensors((v,))] == [True]
+    calls = []
+    orig_ce, orig_full = F._UpsampleCEFn.apply, F._LogitsFn.apply
+    try:
+        def fake_ce(lo_, target, out_hw, ignore, align):
+            calls.append(("fused", ignore))
+            up = TF.interpolate(lo_.permute(0, 3, 1, 2), out_hw, mode="bilinear", align_corners=True)
+            return TF.cross_entropy(up, target, ignore_index=ignore)
+
+        def fake_full(lo_, out_hw, align):
+            calls.append(("full",))
+            return TF.interpolate(lo_.permute(0, 3, 1, 2), out_hw, mode="bilinear", align_corners=align)
+        F._UpsampleCEFn.apply, F._LogitsFn.apply = fake_ce, fake_full
+        t = torch.randint(0, 19, (2, 17, 25))
+        l1 = TF.cross_entropy(v, t, ignore_index=-1)
+        l2 = torch.nn.CrossEntropyLoss(ignore_index=-1)(v, t)   # what solver/loss.py:16-46 calls
+        assert calls == [("fused", -1), ("fused", -1)] and torch.equal(l1, l2)
+        l3 = TF.cross_entropy(v, t, ignore_index=-1, reduction="sum")   # not fusable
+        assert calls[-1] == ("full",) and l3.item() > l1.item()
+        n = len(calls)
+        assert torch.argmax(v, 1).shape == (2, 17, 25) and v[..., :4, :5].shape == (2, 19, 4, 5)
+        assert v.detach().shape == (2, 19, 17, 25) and len(calls) == n   # materialised ONCE
+        l1.backward()
+        assert lo.grad is not None
+    finally:
+        F._UpsampleCEFn.apply, F._LogitsFn.apply = orig_ce, orig_full

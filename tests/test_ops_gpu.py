@@ -546,3 +546,53 @@ def test_conv_bias_before_training_batchnorm_is_dropped_exactly(dtype):
     assert_close(bn.weight.grad.cpu(), bn_r.weight.grad, dtype, "dgamma", fac=8)
     assert conv.bias.grad is not None and float(conv.bias.grad.abs().max()) == 0.0
     assert float(conv_r.bias.grad.abs().max()) < 1e-9
+
+
+# ------------------------------------------------------------------------------ fused loss tail
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+@pytest.mark.parametrize("geom", [(2, 17, 33, 65, 129, 19), (1, 33, 65, 129, 257, 21),
+                                  (2, 9, 13, 33, 49, 30), (1, 8, 8, 8, 8, 2)])
+def test_fused_upsample_cross_entropy_matches_torch(geom, dtype):
+    """seg_upsample_ce_fwd/bwd vs F.cross_entropy(F.interpolate(lo, size, 'bilinear',
+    align_corners=True), target, ignore_index=-1) in float64 (solver/loss.py:16-46 +
+    deeplabv3_plus.py:44): loss and the gradient w.r.t. the low-resolution logits."""
+    N, Hi, Wi, H, W, C = geom
+    lo = quant(rnd((N, C, Hi, Wi), 1) * 2.0, dtype)
+    g = torch.Generator().manual_seed(5)
+    target = torch.randint(0, C, (N, H, W), generator=g)
+    target[torch.rand(N, H, W, generator=g) < 0.1] = -1
+    ref_in = lo.double().requires_grad_()
+    ref = TF.cross_entropy(TF.interpolate(ref_in, (H, W), mode="bilinear", align_corners=True),
+                           target, ignore_index=-1)
+    ref.backward(torch.tensor(1.7, dtype=torch.float64))
+    vec = K().vec_of(dtype)
+    pitch = (C + 2 * vec - 1) // vec * vec
+    lod = to_dev_nhwc(lo, dtype, pitch=pitch, off=0).requires_grad_()
+    view = F().LogitsView(lod, (H, W), True)
+    loss = TF.cross_entropy(view, target.to(DEV), ignore_index=-1)   # __torch_function__ -> fused
+    assert loss.dim() == 0 and loss.dtype == torch.float32 and view._full is None
+    assert abs(loss.item() - ref.item()) <= 2e-5 * abs(ref.item()) + 1e-6
+    (loss * 1.7).backward()
+    got = to_cpu_nchw(lod.grad)
+    assert_close(got, ref_in.grad, dtype, "fused CE dlo", fac=1.0)
+    # every other consumer sees the materialised tensor
+    full = view.materialize()
+    refu = TF.interpolate(lo.double(), (H, W), mode="bilinear", align_corners=True)
+    assert tuple(view.shape) == tuple(full.shape) == (N, C, H, W)
+    assert_close(full.detach().cpu(), refu, torch.float32, "materialised logits", fac=5)
+    assert torch.equal(torch.argmax(view, 1), full.argmax(1))
+    # unsupported variants fall back to the materialised path (class weights here)
+    wts = torch.rand(C) + 0.5
+    l2 = TF.cross_entropy(view, target.to(DEV), weight=wts.to(DEV), ignore_index=-1)
+    r2 = TF.cross_entropy(refu, target, weight=wts.double(), ignore_index=-1)
+    assert abs(l2.item() - r2.item()) <= 1e-4 * abs(r2.item())
+
+
+def test_fused_cross_entropy_all_ignored_is_nan_like_torch():
+    lo = to_dev_nhwc(rnd((1, 19, 5, 7), 1), torch.float32, pitch=24, off=0).requires_grad_()
+    view = F().LogitsView(lo, (17, 25), True)
+    t = torch.full((1, 17, 25), -1, dtype=torch.long, device=DEV)
+    loss = TF.cross_entropy(view, t, ignore_index=-1)
+    assert torch.isnan(loss)
+    loss.backward()
+    assert torch.isfinite(lo.grad).all() and float(lo.grad.abs().max()) == 0.0
