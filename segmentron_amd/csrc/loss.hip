@@ -29,11 +29,20 @@ struct CeArgs {
   int align;
 };
 
+// NC channels of one pixel; vectors beyond the row pitch (narrow class counts: the buffer is
+// padded to a vector multiple of C, not to NC) are not touched
 template <typename T, int NC>
-__device__ __forceinline__ void ce_load_pixel(const T* __restrict__ p, float (&f)[NC]) {
+__device__ __forceinline__ void ce_load_pixel(const T* __restrict__ p, long ld, float (&f)[NC]) {
   constexpr int VEC = Vec<T>::N;
 #pragma unroll
-  for (int v = 0; v < NC / VEC; ++v) Vec<T>::unpack(ldg16(p + v * VEC), &f[v * VEC]);
+  for (int v = 0; v < NC / VEC; ++v) {
+    if (v * VEC < ld) {
+      Vec<T>::unpack(ldg16(p + v * VEC), &f[v * VEC]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) f[v * VEC + k] = 0.f;
+    }
+  }
 }
 
 // z[c] of output pixel (n, h, w): NC >= C channels are loaded (the buffer is channel-padded)
@@ -45,10 +54,10 @@ __device__ __forceinline__ void ce_logits(const CeArgs& a, int n, int h, int w, 
   taps(a.sw, w, a.Wi, a.align, w0, w1, lw);
   const long base = (long)n * a.Hi * a.Wi;
   float f00[NC], f01[NC], f10[NC], f11[NC];
-  ce_load_pixel<T, NC>(X + (base + (long)h0 * a.Wi + w0) * a.ld, f00);
-  ce_load_pixel<T, NC>(X + (base + (long)h0 * a.Wi + w1) * a.ld, f01);
-  ce_load_pixel<T, NC>(X + (base + (long)h1 * a.Wi + w0) * a.ld, f10);
-  ce_load_pixel<T, NC>(X + (base + (long)h1 * a.Wi + w1) * a.ld, f11);
+  ce_load_pixel<T, NC>(X + (base + (long)h0 * a.Wi + w0) * a.ld, a.ld, f00);
+  ce_load_pixel<T, NC>(X + (base + (long)h0 * a.Wi + w1) * a.ld, a.ld, f01);
+  ce_load_pixel<T, NC>(X + (base + (long)h1 * a.Wi + w0) * a.ld, a.ld, f10);
+  ce_load_pixel<T, NC>(X + (base + (long)h1 * a.Wi + w1) * a.ld, a.ld, f11);
   const float h0l = 1.f - lh, w0l = 1.f - lw;
 #pragma unroll
   for (int c = 0; c < NC; ++c)

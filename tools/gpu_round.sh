@@ -9,8 +9,13 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 python -c 'import __graft_entry__ as g; g.build()' > $OUT/build.log 2>&1 || { echo BUILD FAILED; tail -30 $OUT/build.log; exit 1; }
 if [ "${SKIP_TESTS:-0}" != "1" ]; then
-  timeout 1200 python -m pytest tests -m gpu -q --durations=15 "$@" > $OUT/pytest.log 2>&1
-  echo "pytest rc=$?"; grep -E "^(FAILED|ERROR)|passed|failed" $OUT/pytest.log | tail -40
+  # one process per file: a GPU fault (abort) in one file must not hide the others' results
+  : > $OUT/pytest.log; prc=0
+  for f in ${TEST_FILES:-tests/test_*.py}; do
+    timeout 900 python -m pytest $f -m gpu -q --durations=5 "$@" >> $OUT/pytest.log 2>&1
+    r=$?; [ $r -ne 0 ] && [ $r -ne 5 ] && { prc=$r; echo "  $f rc=$r"; }
+  done
+  echo "pytest rc=$prc"; grep -E "^(FAILED|ERROR)|passed|failed|Fatal" $OUT/pytest.log | tail -40
 fi
 if [ "${SKIP_BENCH:-0}" != "1" ]; then
   timeout 900 python bench.py ${BENCH_ARGS:---steps 20 --warmup 5} > $OUT/bench.json 2> $OUT/bench.err
