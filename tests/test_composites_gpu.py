@@ -81,6 +81,14 @@ def _compare(name, dtype, got, ref64, emu, bars, ref32=None):
         den = b.double().norm().item()
         if key.startswith("d:"):
             den = max(den, 1e-6 * gmax)
+            # BatchNorm (gamma, beta): a BN -> ReLU -> depthwise conv -> train-mode BN chain is
+            # almost invariant to gamma (exactly for beta = 0: relu(g*x) = g*relu(x) and the next
+            # BN divides the scale out again), so dgamma is the tiny residual of a cancelling
+            # sum — measure both gradients of a layer against the larger of their two norms
+            for a_, b_ in ((".weight", ".bias"), (".bias", ".weight")):
+                sib = key[:-len(a_)] + b_ if key.endswith(a_) else None
+                if sib in ref64 and ref64[sib].dim() == 1 and ref64[key].dim() == 1:
+                    den = max(den, ref64[sib].double().norm().item())
         return (a.double() - b.double()).norm().item() / max(den, 1e-30)
 
     for k, g in got.items():
