@@ -1,5 +1,7 @@
 """FCN — segmentron/models/fcn.py:12-34 (head hard-codes 2048 input channels, i.e. needs a
 Bottleneck ResNet; `resnet18` fails exactly as in the reference)."""
+import torch
+
 from .. import functional as F
 from ..modules import _FCNHead
 from .model_zoo import MODEL_REGISTRY
