@@ -136,12 +136,12 @@ __global__ void ce_finalize_kernel(const double* partial, int nblocks, float* ou
 // gathers its sum over those outputs in a fixed order — separably: first along w, then along h.
 // LT = low-res tile edge, HT_MAX = most output rows / columns that can touch LT low-res rows at
 // up to 4.1x upsampling: (LT + 1.5) * 4.1 + 5.  LDS: NC * HT_MAX * (HT_MAX + LT) floats.
+constexpr int CE_BWD_THREADS = 512;
 template <typename T, int NC, int LT, int HT_MAX>
-__global__ __launch_bounds__(CE_THREADS) void ce_bwd_kernel(const CeArgs a, const float* gscale,
-                                                            const float* gout, void* dlo,
-                                                            long lddlo) {
+__global__ __launch_bounds__(CE_BWD_THREADS) void ce_bwd_kernel(const CeArgs a, const float* gscale,
+                                                                const float* gout, void* dlo,
+                                                                long lddlo) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_ce[];
-  // dz[NC][hh][ww] (float), then tmp[NC][hh][LT] reusing nothing: separate regions
   const int tiles_w = (a.Wi + LT - 1) / LT, tiles_h = (a.Hi + LT - 1) / LT;
   const int tw = blockIdx.x % tiles_w, th = (blockIdx.x / tiles_w) % tiles_h;
   const int n = blockIdx.x / (tiles_w * tiles_h);
@@ -156,9 +156,32 @@ __global__ __launch_bounds__(CE_THREADS) void ce_bwd_kernel(const CeArgs a, cons
   const int nh = hhi - hlo + 1, nw = whi - wlo + 1;  // <= HT_MAX (checked on the host)
   float* dz = reinterpret_cast<float*>(smem_ce);                  // [NC][nh][nw]
   float* tmp = dz + (long)NC * HT_MAX * HT_MAX;                   // [NC][nh][LT]
+  float* wth = tmp + (long)NC * HT_MAX * LT;                      // [HT_MAX][LT] row weights
+  float* wtw = wth + HT_MAX * LT;                                 // [HT_MAX][LT] column weights
+  int* rng = reinterpret_cast<int*>(wtw + HT_MAX * LT);           // [2][LT][2] candidate ranges
   const float g = gout[0] * gscale[1];  // dLoss * (1 / valid count)
+  // ---- interpolation weights of every (output row, tile row) / (output column, tile column)
+  for (int p = threadIdx.x; p < 2 * HT_MAX * LT; p += CE_BWD_THREADS) {
+    const int which = p / (HT_MAX * LT), q = p - which * HT_MAX * LT;
+    const int oo = q / LT, ii = q - oo * LT;
+    if (which == 0) wth[q] = oo < nh ? tap_weight(a.sh, hlo + oo, a.Hi, a.align, i0 + ii) : 0.f;
+    else wtw[q] = oo < nw ? tap_weight(a.sw, wlo + oo, a.Wi, a.align, j0 + ii) : 0.f;
+  }
+  if (threadIdx.x < 2 * LT) {
+    const int which = threadIdx.x / LT, ii = threadIdx.x - which * LT;
+    int clo, chi;
+    if (which == 0) {
+      cand_range(a.sh, i0 + ii, a.H, a.align, clo, chi);
+      clo = max(clo, hlo) - hlo; chi = min(chi, hhi) - hlo;
+    } else {
+      cand_range(a.sw, j0 + ii, a.W, a.align, clo, chi);
+      clo = max(clo, wlo) - wlo; chi = min(chi, whi) - wlo;
+    }
+    rng[(which * LT + ii) * 2] = clo;
+    rng[(which * LT + ii) * 2 + 1] = chi;
+  }
   // ---- phase 1
-  for (int p = threadIdx.x; p < nh * nw; p += CE_THREADS) {
+  for (int p = threadIdx.x; p < nh * nw; p += CE_BWD_THREADS) {
     const int hh = p / nw, ww = p - hh * nw;
     const int h = hlo + hh, w = wlo + ww;
     const long t = a.target[((long)n * a.H + h) * a.W + w];
@@ -185,43 +208,36 @@ __global__ __launch_bounds__(CE_THREADS) void ce_bwd_kernel(const CeArgs a, cons
     for (int c = 0; c < NC; ++c) dz[((long)c * HT_MAX + hh) * HT_MAX + ww] = z[c];
   }
   __syncthreads();
-  // ---- phase 2a: along w.  tmp[c][hh][jj] = sum_ww weight_w(w, j0+jj) * dz[c][hh][ww]
+  // ---- phase 2a: along w.  tmp[c][hh][jj] = sum_ww wtw[ww][jj] * dz[c][hh][ww]
   const int lw_n = j1 - j0 + 1, lh_n = i1 - i0 + 1;
-  for (int p = threadIdx.x; p < NC * nh * LT; p += CE_THREADS) {
+  for (int p = threadIdx.x; p < a.C * nh * LT; p += CE_BWD_THREADS) {
     const int jj = p % LT, hh = (p / LT) % nh, c = p / (LT * nh);
     float acc = 0.f;
-    if (jj < lw_n && c < a.C) {
-      int clo, chi;
-      cand_range(a.sw, j0 + jj, a.W, a.align, clo, chi);
-      clo = max(clo, wlo); chi = min(chi, whi);
-      for (int w = clo; w <= chi; ++w) {
-        const float wt = tap_weight(a.sw, w, a.Wi, a.align, j0 + jj);
-        acc = fmaf(wt, dz[((long)c * HT_MAX + hh) * HT_MAX + (w - wlo)], acc);
-      }
+    if (jj < lw_n) {
+      const int clo = rng[(LT + jj) * 2], chi = rng[(LT + jj) * 2 + 1];
+      const float* row = dz + ((long)c * HT_MAX + hh) * HT_MAX;
+      for (int ww = clo; ww <= chi; ++ww) acc = fmaf(wtw[ww * LT + jj], row[ww], acc);
     }
     tmp[((long)c * HT_MAX + hh) * LT + jj] = acc;
   }
   __syncthreads();
   // ---- phase 2b: along h, and store (channels >= C are written as zero padding)
   T* __restrict__ D = reinterpret_cast<T*>(dlo);
-  for (int p = threadIdx.x; p < lh_n * lw_n * (int)lddlo; p += CE_THREADS) {
+  for (int p = threadIdx.x; p < lh_n * lw_n * (int)lddlo; p += CE_BWD_THREADS) {
     const int c = p % (int)lddlo, jj = (p / (int)lddlo) % lw_n, ii = p / ((int)lddlo * lw_n);
     float acc = 0.f;
     if (c < a.C) {
-      int clo, chi;
-      cand_range(a.sh, i0 + ii, a.H, a.align, clo, chi);
-      clo = max(clo, hlo); chi = min(chi, hhi);
-      for (int h = clo; h <= chi; ++h) {
-        const float wt = tap_weight(a.sh, h, a.Hi, a.align, i0 + ii);
-        acc = fmaf(wt, tmp[((long)c * HT_MAX + (h - hlo)) * LT + jj], acc);
-      }
+      const int clo = rng[ii * 2], chi = rng[ii * 2 + 1];
+      for (int hh = clo; hh <= chi; ++hh)
+        acc = fmaf(wth[hh * LT + ii], tmp[((long)c * HT_MAX + hh) * LT + jj], acc);
     }
     Vec<T>::store1(D + (((long)n * a.Hi + i0 + ii) * a.Wi + j0 + jj) * lddlo + c, acc);
   }
 }
 
 template <int NC, int LT, int HT_MAX> constexpr size_t ce_bwd_lds() {
-  return ((size_t)NC * HT_MAX * HT_MAX + (size_t)NC * HT_MAX * LT) * sizeof(float);
+  return ((size_t)NC * HT_MAX * HT_MAX + (size_t)NC * HT_MAX * LT + 2 * (size_t)HT_MAX * LT) *
+             sizeof(float) + 4 * (size_t)LT * sizeof(int);
 }
 // <= 24 classes: 6 x 6 tiles (137 KiB of LDS); <= 32 classes: 4 x 4 tiles (112 KiB)
 constexpr int CE_LT24 = 6, CE_HT24 = 36, CE_LT32 = 4, CE_HT32 = 28;
@@ -236,7 +252,7 @@ static int launch_ce_bwd(int blocks, hipStream_t st, const CeArgs& a, const floa
       reinterpret_cast<const void*>(&ce_bwd_kernel<T, NC, LT, HT>),
       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   SEG_REQUIRE(once == 0, "upsample_ce_bwd: cannot reserve %d bytes of LDS", (int)lds);
-  hipLaunchKernelGGL((ce_bwd_kernel<T, NC, LT, HT>), dim3(blocks), dim3(CE_THREADS), lds, st, a,
+  hipLaunchKernelGGL((ce_bwd_kernel<T, NC, LT, HT>), dim3(blocks), dim3(CE_BWD_THREADS), lds, st, a,
                      loss_out, grad_out, dlo, lddlo);
   return 0;
 }
