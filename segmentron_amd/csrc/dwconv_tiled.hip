@@ -153,6 +153,24 @@ __device__ __forceinline__ void tile_coords(const DwTiledArgs& a, int t, int& n,
 }
 
 // ------------------------------------------------------------------ forward / stride-1 dgrad
+// Logical (channel block, tile lane) of this workgroup.  A block covers only 8 channel vectors
+// (64 B of a bf16 pixel in the fused backward, 128 B in the forward) of every pixel it touches,
+// so neighbouring CHANNEL blocks of the same tile read the other halves of the same 128-byte
+// lines and the same halo rows.  Dispatch order puts consecutive workgroup ids on different
+// XCDs (private L2s): with blockIdx.x = channel block every line was fetched once per XCD that
+// needed a piece of it (rocprofv3: 149 MB fetched by the fused backward for 59 MB of operands).
+// Here every XCD owns a contiguous range of logical ids (xcd_remap) ordered channel-block
+// fastest: the blocks that share lines sit on ONE XCD and run in lockstep.
+struct LtBlock { int x, y; };
+__device__ __forceinline__ LtBlock lt_block() {
+  const int flat = blockIdx.x + gridDim.x * blockIdx.y;
+  const int L = xcd_remap(flat, gridDim.x * gridDim.y);
+  LtBlock b;
+  b.y = L / (int)gridDim.x;
+  b.x = L - b.y * (int)gridDim.x;
+  return b;
+}
+
 template <typename T, int DIL>
 __global__ __launch_bounds__(LT_THREADS, sizeof(T) == 2 ? 3 : 4) void dwconv_tiled_kernel(const DwTiledArgs a) {
   using G = TileGeom<DIL>;
@@ -161,7 +179,8 @@ __global__ __launch_bounds__(LT_THREADS, sizeof(T) == 2 ? 3 : 4) void dwconv_til
   uint4* tile = lt_smem;
   float4* wsm = reinterpret_cast<float4*>(lt_smem + G::TILE_VECS);
   const int tid = threadIdx.x;
-  const int cvb0 = blockIdx.x * LT_CVB;
+  const LtBlock lb = lt_block();
+  const int cvb0 = lb.x * LT_CVB;
   const int cx = tid & (LT_CVB - 1), row = (tid >> 3) & (LT_TH - 1), strip = tid >> 6;
   const int cv = cvb0 + cx;
   const T* __restrict__ X = reinterpret_cast<const T*>(a.x);
@@ -179,7 +198,7 @@ __global__ __launch_bounds__(LT_THREADS, sizeof(T) == 2 ? 3 : 4) void dwconv_til
   // overlap each other): no gain on the 24 MB tensors, -10 % on the large ones -> off; the fused
   // backward (2 blocks/CU, long compute phase) gains 35 % from it.
   constexpr bool PIPE = false;
-  int t = blockIdx.y, nn = 0, nh0 = 0, nw0 = 0;
+  int t = lb.y, nn = 0, nh0 = 0, nw0 = 0;
   uint4 raw[G::PER];
   unsigned okmask = 0;
   if (PIPE && t < a.ntiles) {
@@ -267,7 +286,7 @@ __global__ __launch_bounds__(LT_THREADS, sizeof(T) == 2 ? 3 : 4) void dwconv_til
       const int lcx = tid / (2 * VEC), k = tid - lcx * 2 * VEC;
       const int which = k / VEC, ci = k - which * VEC;
       const int c = (cvb0 + lcx) * VEC + ci;
-      if (c < a.C) a.partial[((long)blockIdx.y * 2 + which) * a.C + c] = tot;
+      if (c < a.C) a.partial[((long)lb.y * 2 + which) * a.C + c] = tot;
     }
   }
 }
@@ -282,7 +301,8 @@ __global__ __launch_bounds__(LT_THREADS, 2) void dwconv_wgrad_tiled_kernel(const
   extern __shared__ uint4 lt_smem[];
   uint4* tile = lt_smem;
   const int tid = threadIdx.x;
-  const int cvb0 = blockIdx.x * LT_CVB;
+  const LtBlock lb = lt_block();
+  const int cvb0 = lb.x * LT_CVB;
   const int cx = tid & (LT_CVB - 1), row = (tid >> 3) & (LT_TH - 1), strip = tid >> 6;
   const int cv = cvb0 + cx;
   const T* __restrict__ X = reinterpret_cast<const T*>(a.x);
@@ -297,7 +317,7 @@ __global__ __launch_bounds__(LT_THREADS, 2) void dwconv_wgrad_tiled_kernel(const
 #pragma unroll
     for (int i = 0; i < VEC; ++i) acc[k][i] = 0.f;
 
-  for (int t = blockIdx.y; t < a.ntiles; t += gridDim.y) {
+  for (int t = lb.y; t < a.ntiles; t += gridDim.y) {
     int n, h0, w0;
     tile_coords(a, t, n, h0, w0);
     uint4 raw[G::PER];
@@ -370,7 +390,7 @@ __global__ __launch_bounds__(LT_THREADS, 2) void dwconv_wgrad_tiled_kernel(const
     const int lcx = e / (9 * VEC), k = e - lcx * 9 * VEC;
     const int tap = k / VEC, ci = k - tap * VEC;
     const int c = (cvb0 + lcx) * VEC + ci;
-    if (c < a.C) a.partial[((long)blockIdx.y * 9 + tap) * a.C + c] = tot;
+    if (c < a.C) a.partial[((long)lb.y * 9 + tap) * a.C + c] = tot;
   }
 }
 
@@ -397,7 +417,8 @@ __global__ __launch_bounds__(LT_THREADS, DW_BWD_OCC) void dwconv_bwd_tiled_kerne
   raw_t* tile = reinterpret_cast<raw_t*>(lt_smem);
   float4* psm = reinterpret_cast<float4*>(lt_smem + G::TILE_VECS);
   const int tid = threadIdx.x;
-  const int cvb0 = blockIdx.x * LT_CVB;
+  const LtBlock lb = lt_block();
+  const int cvb0 = lb.x * LT_CVB;
   const int cx = tid & (LT_CVB - 1), row = (tid >> 3) & (LT_TH - 1), strip = tid >> 6;
   const int cv = cvb0 + cx;
   const T* __restrict__ DY = reinterpret_cast<const T*>(a.dy);
@@ -438,7 +459,7 @@ __global__ __launch_bounds__(LT_THREADS, DW_BWD_OCC) void dwconv_bwd_tiled_kerne
   DwTiledArgs dyargs = plain;
   dyargs.ldx = a.lddy;
   constexpr bool PIPE = DIL == 1;  // dilation 2 (wider halo tile) would spill with the prefetch
-  int t = blockIdx.y, nn = 0, nh0 = 0, nw0 = 0;
+  int t = lb.y, nn = 0, nh0 = 0, nw0 = 0;
   raw_t raw[G::PER], xnext[4];
   unsigned okmask = 0;
   if (PIPE && t < a.ntiles) {
@@ -590,8 +611,8 @@ __global__ __launch_bounds__(LT_THREADS, DW_BWD_OCC) void dwconv_bwd_tiled_kerne
     const int r = k / VEC, ci = k - r * VEC;
     const int c = (cvb0 + lcx) * VEC + ci;
     if (c < a.C) {
-      if (r < 9) a.partial[((long)blockIdx.y * 9 + (8 - r)) * a.C + c] = tot;  // LDS row r = tap 8-r
-      else if (a.partial_bn != nullptr) a.partial_bn[((long)blockIdx.y * 2 + (r - 9)) * a.C + c] = tot;
+      if (r < 9) a.partial[((long)lb.y * 9 + (8 - r)) * a.C + c] = tot;  // LDS row r = tap 8-r
+      else if (a.partial_bn != nullptr) a.partial_bn[((long)lb.y * 2 + (r - 9)) * a.C + c] = tot;
     }
   }
 }

@@ -5,6 +5,7 @@
 TAG=$1; PAT=$2; shift 3
 OUT=$PWD/gpurun_out/$TAG; mkdir -p $OUT
 CMD="$PWD/$1"; shift
+case "$CMD" in *.py) CMD="python $CMD";; esac
 cd /tmp && export TMPDIR=/tmp
 i=0
 for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" \
