@@ -18,7 +18,9 @@
  *     0 none, 1 relu(x), 2 x*scale[c]+shift[c], 3 relu(x*scale[c]+shift[c]); +4 = ReLU6 clamp
  *     (5 = relu6(x), 7 = relu6(x*scale[c]+shift[c]))
  *   - `stream` is a hipStream_t; all launches are asynchronous on it; no host synchronisation,
- *     no allocation, no global mutable state (re-entrant, graph-capturable)
+ *     no allocation; re-entrant and graph-capturable.  The only process-wide state are three
+ *     kernel-SELECTION knobs for A/B measurements (seg_conv_gemm_config, seg_conv_gemm_px256,
+ *     seg_conv_gemm_wgrad_config): they pick between implementations with identical results
  *   - return value 0 = ok; otherwise seg_last_error() (thread-local) describes the failure.
  *     Never aborts.
  */

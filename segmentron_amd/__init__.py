@@ -33,3 +33,4 @@ def set_compute_dtype(dtype):
 
 from .config import cfg  # noqa: E402,F401
 from .models import MODEL_REGISTRY, get_segmentation_model  # noqa: E402,F401
+from . import torch_ops  # noqa: E402,F401  (registers torch.ops.segmentron_hip.*)

@@ -564,25 +564,15 @@ class _LogitsFn(torch.autograd.Function):
         return gx[..., :C], None, None
 
 
-class _UpsampleCEFn(torch.autograd.Function):
-    """F.cross_entropy(F.interpolate(lo, size, 'bilinear', align_corners), target, ignore_index)
-    with reduction='mean', fused (csrc/loss.hip): the full-resolution logits never exist."""
-
-    @staticmethod
-    def forward(ctx, lo, target, out_hw, ignore_index, align):
-        out = K.upsample_ce_fwd(lo, target, out_hw, ignore_index, align)
-        ctx.save_for_backward(lo, target, out)
-        ctx.meta = (tuple(out_hw), ignore_index, align)
-        return out[0]
-
-    @staticmethod
-    def backward(ctx, g):
-        lo, target, out = ctx.saved_tensors
-        out_hw, ignore_index, align = ctx.meta
-        C = lo.shape[-1]
-        pitch = _round_up(C, K.vec_of(lo.dtype))
-        dlo = K.upsample_ce_bwd(lo, target, out_hw, ignore_index, out, g, pitch, align)
-        return dlo[..., :C], None, None, None, None
+def fused_cross_entropy(lo, target, out_hw, ignore_index, align_corners=True):
+    """F.cross_entropy(F.interpolate(lo, out_hw, 'bilinear', align_corners), target,
+    ignore_index) with reduction='mean', fused (csrc/loss.hip) — the full-resolution logits never
+    exist.  Issued through the registered custom operator
+    `torch.ops.segmentron_hip.upsample_cross_entropy` (segmentron_amd/torch_ops.py)."""
+    out = torch.ops.segmentron_hip.upsample_cross_entropy(lo, target, int(out_hw[0]),
+                                                          int(out_hw[1]), int(ignore_index),
+                                                          bool(align_corners))
+    return out[0]
 
 
 @dataclasses.dataclass(eq=False, repr=False)
@@ -668,7 +658,7 @@ class LogitsView:
             b = bind(*args, **kwargs)
             view = args[0]
             if view._fusable(*b):
-                return _UpsampleCEFn.apply(view.lo, b[0], view.out_hw, int(b[3]),
+                return fused_cross_entropy(view.lo, b[0], view.out_hw, int(b[3]),
                                            view.align_corners)
 
         def real(o):

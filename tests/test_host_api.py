@@ -169,7 +169,7 @@ def test_logits_view_dispatch_and_ddp_visibility():
     assert v.dtype == torch.float32 and v.requires_grad and v._full is None
     assert dataclasses.is_dataclass(v) and [t is lo for t in _find_tensors((v,))] == [True]
     calls = []
-    orig_ce, orig_full = F._UpsampleCEFn.apply, F._LogitsFn.apply
+    orig_ce, orig_full = F.fused_cross_entropy, F._LogitsFn.apply
     try:
         def fake_ce(lo_, target, out_hw, ignore, align):
             calls.append(("fused", ignore))
@@ -179,7 +179,7 @@ def test_logits_view_dispatch_and_ddp_visibility():
         def fake_full(lo_, out_hw, align):
             calls.append(("full",))
             return TF.interpolate(lo_.permute(0, 3, 1, 2), out_hw, mode="bilinear", align_corners=align)
-        F._UpsampleCEFn.apply, F._LogitsFn.apply = fake_ce, fake_full
+        F.fused_cross_entropy, F._LogitsFn.apply = fake_ce, fake_full
         t = torch.randint(0, 19, (2, 17, 25))
         l1 = TF.cross_entropy(v, t, ignore_index=-1)
         l2 = torch.nn.CrossEntropyLoss(ignore_index=-1)(v, t)   # what solver/loss.py:16-46 calls
@@ -192,4 +192,34 @@ def test_logits_view_dispatch_and_ddp_visibility():
         l1.backward()
         assert lo.grad is not None
     finally:
-        F._UpsampleCEFn.apply, F._LogitsFn.apply = orig_ce, orig_full
+        F.fused_cross_entropy, F._LogitsFn.apply = orig_ce, orig_full
+
+
+def test_torch_custom_ops_are_registered_with_fake_implementations():
+    """torch.ops.segmentron_hip.* (segmentron_amd/torch_ops.py): schemas, and shape / dtype
+    inference through FakeTensorMode — no device is touched, so this runs without a GPU."""
+    import segmentron_amd  # noqa: F401  registers the operators
+    from segmentron_amd import torch_ops
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    ns = torch.ops.segmentron_hip
+    for name in torch_ops.OPS:
+        assert hasattr(ns, name), name
+    assert "relu_in" in str(ns.conv2d.default._schema)
+    with FakeTensorMode():
+        x = torch.empty(2, 33, 65, 728, dtype=torch.bfloat16, device="cuda")
+        w = torch.empty(1024, 728, 1, 1, device="cuda")
+        y = ns.conv2d(x, w, None, 1, 0, 1, False)
+        assert tuple(y.shape) == (2, 33, 65, 1024) and y.dtype == torch.bfloat16
+        w3 = torch.empty(64, 728, 3, 3, device="cuda")
+        assert tuple(ns.conv2d(x, w3, None, 2, 1, 1, True).shape) == (2, 17, 33, 64)
+        dx, dw, db = ns.conv2d_backward(x, y, w, 1, 0, 1, False, True)
+        assert tuple(dx.shape) == tuple(x.shape) and tuple(dw.shape) == tuple(w.shape)
+        assert dw.dtype == torch.float32 and tuple(db.shape) == (1024,)
+        wd = torch.empty(728, 1, 3, 3, device="cuda")
+        assert tuple(ns.depthwise_conv3x3(x, wd, 2, 1, True).shape) == (2, 17, 33, 728)
+        assert tuple(ns.depthwise_conv3x3(x, wd, 1, 12, False).shape) == (2, 33, 65, 728)
+        assert tuple(ns.interpolate_bilinear(x, 129, 257, True).shape) == (2, 129, 257, 728)
+        lo = torch.empty(2, 257, 513, 19, dtype=torch.bfloat16, device="cuda")
+        t = torch.empty(2, 1025, 2049, dtype=torch.long, device="cuda")
+        out = ns.upsample_cross_entropy(lo, t, 1025, 2049, -1, True)
+        assert tuple(out.shape) == (2,) and out.dtype == torch.float32
