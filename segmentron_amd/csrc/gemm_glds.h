@@ -136,8 +136,12 @@ __device__ __forceinline__ void gl_read_frags(GlFrags& f, const lds_byte_t* pa, 
 
 // MFMAs of row blocks [IM0, IM1) of one k-step.  ZERO: the accumulator input is the constant 0
 // (first k-step of a tile: saves zero-filling 128 registers before the loop).
+#ifndef GL_SETPRIO
+#define GL_SETPRIO 0
+#endif
 template <int IM0, int IM1, bool ZERO = false>
 __device__ __forceinline__ void gl_mma_part(const GlFrags& f, f32x16 (&acc)[2][4]) {
+  if (GL_SETPRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
   for (int im = IM0; im < IM1; ++im) {
     const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -146,6 +150,7 @@ __device__ __forceinline__ void gl_mma_part(const GlFrags& f, f32x16 (&acc)[2][4
     acc[1][im] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.n[1], f.m[im], ZERO ? z : acc[1][im],
                                                          0, 0, 0);
   }
+  if (GL_SETPRIO) __builtin_amdgcn_s_setprio(0);
 }
 __device__ __forceinline__ void gl_mma_step(const GlFrags& f, f32x16 (&acc)[2][4]) {
   gl_mma_part<0, 4>(f, acc);

@@ -163,3 +163,28 @@ def test_syncbn_ddp_two_ranks_match_full_batch(naive):
           % ((num / den) ** 0.5, rels[len(rels) // 2], rels[-1]))
     # (ReLU near-ties can move single tensors by percents — see test_more_models.py)
     assert (num / den) ** 0.5 < 6e-2 and rels[len(rels) // 2] < 2e-3
+
+
+def test_bench_self_launches_two_ranks_and_reports_one_line():
+    """`python bench.py --gpus 2` WITHOUT a torchrun environment (how a user — or a driver without
+    its own launcher — calls it): bench.py re-launches itself under torch.distributed.run, the
+    ranks wrap the model like tools/train.py:73-79,108-111 (SyncBatchNorm + DDP), and rank 0
+    prints one JSON line.  Both ranks share the single GPU of the test box over gloo
+    (SEG_BENCH_ONE_DEVICE=1; RCCL refuses two ranks per device) at a reduced image size."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["SEG_BENCH_ONE_DEVICE"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2",
+                        "--warmup", "1", "--height", "129", "--width", "257", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 4 and d["config"]["bn"] == "SyncBN"
+    assert d["launch"] == "eager" and d["steps"] == 2 and d["value"] > 0
+    assert d["config"]["loss"] == d["config"]["loss"]  # finite (not NaN)
