@@ -90,7 +90,9 @@ class GemmTimer:
         self.events_all.append((e0, e1))
         # the dispatch rule of seg_conv_gemm_fwd (csrc/conv_gemm_fwd.hip: gemm_use_px256 +
         # conv_gemm_glds_usable): the direct-to-LDS 256x256 kernel
-        if (KH * KW == 1 and stride == 1 and pad == 0 and O >= 384 and n * ho * wo >= 4096
+        m = n * ho * wo
+        if (KH * KW == 1 and stride == 1 and pad == 0
+                and ((O >= 384 and m >= 4096) or (O >= 256 and m >= 65536))
                 and scatter is None and tconv_out_hw is None and x.dtype == torch.bfloat16
                 and (pro is None or pro[0] == 0) and bias is None and O % 8 == 0):
             self.flops += fl

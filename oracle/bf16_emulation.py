@@ -13,7 +13,8 @@ Rounding points of the HIP bf16 path (segmentron_amd/csrc):
   * 1x1 / dense conv (seg_conv_gemm_fwd): activation operand = bf16(act(raw)) staged in LDS,
     weights bf16, fp32 MFMA accumulation, raw output stored as bf16(acc [+ bias]); BN statistics
     from the fp32 accumulators (dense / strided convs) or, on the 256x128-tile kernel that runs
-    every 1x1 stride-1 conv, from the values as stored (bf16-rounded; O >= 384 and >= 4096 output pixels)
+    every 1x1 stride-1 conv, from the values as stored (bf16-rounded; O >= 384 and >= 4096 output pixels, or O >= 256 and
+    >= 65536 output pixels)
   * 1x1 conv whose input carries a LINEAR pending BN (no ReLU; csrc/fold.hip): operand = the raw
     bf16 tensor as stored, weights = bf16(W * scale), the constant W @ shift is dropped when a
     training-mode BN follows (it cancels) and added as an fp32 bias otherwise
@@ -116,7 +117,8 @@ class Bf16EmuNet:
                 y = y + (wf.view(wf.shape[0], -1) @ a.b).view(1, -1, 1, 1)
             if bnp is None:
                 return _A(r16(y))
-            px256 = stride == 1 and w.shape[0] >= 384 and y.shape[0] * y.shape[2] * y.shape[3] >= 4096
+            m_ = y.shape[0] * y.shape[2] * y.shape[3]
+            px256 = stride == 1 and ((w.shape[0] >= 384 and m_ >= 4096) or (w.shape[0] >= 256 and m_ >= 65536))
             s, b = self._bn(r16(y) if px256 else y, bnp)
             return _A(r16(y), s, b)
         w = r16(wf)
@@ -127,8 +129,9 @@ class Bf16EmuNet:
         bias = self.sd.get(p + ".bias")
         if bnp is None:
             return _A(r16(y if bias is None else y + bias.view(1, -1, 1, 1)))
-        fast = (tuple(wf.shape[2:]) == (1, 1) and stride == 1 and pad == 0 and wf.shape[0] >= 384
-                and y.shape[0] * y.shape[2] * y.shape[3] >= 4096)
+        m_ = y.shape[0] * y.shape[2] * y.shape[3]
+        fast = (tuple(wf.shape[2:]) == (1, 1) and stride == 1 and pad == 0
+                and ((wf.shape[0] >= 384 and m_ >= 4096) or (wf.shape[0] >= 256 and m_ >= 65536)))
         s, b = self._bn(r16(y) if fast else y, bnp)
         return _A(r16(y), s, b)
 

@@ -314,8 +314,11 @@ extern "C" int seg_conv_gemm_px256(int enable) {
 // The 256x128 kernel pays off where an output row is wide enough to amortise its longer
 // per-block pipeline (tools/gemm_bench.py, bf16 TFLOP/s, 128x128 -> 256x128: 728->728 @65x129
 // 419 -> 487, 1536->2048 675 -> 675, 304->256 @257x513 434 -> 430, 128->128 @513x1025 326 -> 315)
+// (r02: also O >= 256 when there are >= 256 pixel tiles — the decoder's 304->256 / 256->256
+// convs at 257x513: one 256-wide column tile per 256-pixel tile still fills the chip four times)
 static bool gemm_use_px256(int KH, int KW, int stride, int pad, int tconv, int O, long M) {
-  return KH * KW == 1 && stride == 1 && pad == 0 && !tconv && O >= 384 && M >= 4096;
+  return KH * KW == 1 && stride == 1 && pad == 0 && !tconv &&
+         ((O >= 384 && M >= 4096) || (O >= 256 && M >= 65536));
 }
 
 // rows of the statistics partial buffer [rows][2][O] the forward kernel will write

@@ -84,6 +84,71 @@ __global__ __launch_bounds__(256) void fold_bwd_reduce_kernel(
   }
 }
 
+// Vectorised version for C % 4 == 0 (every real layer): a lane owns FOUR consecutive columns
+// (16-byte loads: 1 KiB per wave instruction instead of 256 B), waves walk the rows of the
+// block's row slice.  The first version moved 15 MB in 19 us (0.8 TB/s, dword loads).
+constexpr int FOLD_RS4 = 64;
+__global__ __launch_bounds__(256) void fold_bwd_reduce4_kernel(
+    const float* __restrict__ W, const float* __restrict__ dWp, int S, const float* __restrict__ s,
+    const float* __restrict__ t, const float* __restrict__ db, float* __restrict__ dW,
+    float* __restrict__ dsdt, int O, int C) {
+  __shared__ float4 red[2][4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = (blockIdx.x * 64 + lane) * 4;
+  const int rows_per = (O + gridDim.y - 1) / gridDim.y;
+  const int o0 = blockIdx.y * rows_per, o1 = min(O, o0 + rows_per);
+  const long OC = (long)O * C;
+  float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+  if (c < C) {
+    const float4 sc = *reinterpret_cast<const float4*>(s + c);
+    const float4 tc = *reinterpret_cast<const float4*>(t + c);
+    for (int o = o0 + wave; o < o1; o += 4) {
+      const long idx = (long)o * C + c;
+      float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+      // fixed order, eight UNCONDITIONAL loads in flight per round (rows past S re-read the
+      // last split and are masked: a load behind a per-element branch would make hipcc wait
+      // vmcnt(0) after each one)
+      for (int k = 0; k < S; k += 8) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          v[u] = *reinterpret_cast<const float4*>(dWp + (long)min(k + u, S - 1) * OC + idx);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const float m = (k + u < S) ? 1.f : 0.f;
+          g.x = fmaf(m, v[u].x, g.x); g.y = fmaf(m, v[u].y, g.y);
+          g.z = fmaf(m, v[u].z, g.z); g.w = fmaf(m, v[u].w, g.w);
+        }
+      }
+      const float4 w = *reinterpret_cast<const float4*>(W + idx);
+      const float dbo = db ? db[o] : 0.f;
+      float4 out;
+      out.x = fmaf(g.x, sc.x, dbo * tc.x); out.y = fmaf(g.y, sc.y, dbo * tc.y);
+      out.z = fmaf(g.z, sc.z, dbo * tc.z); out.w = fmaf(g.w, sc.w, dbo * tc.w);
+      *reinterpret_cast<float4*>(dW + idx) = out;
+      a0.x = fmaf(w.x, g.x, a0.x); a0.y = fmaf(w.y, g.y, a0.y);
+      a0.z = fmaf(w.z, g.z, a0.z); a0.w = fmaf(w.w, g.w, a0.w);
+      a1.x = fmaf(w.x, dbo, a1.x); a1.y = fmaf(w.y, dbo, a1.y);
+      a1.z = fmaf(w.z, dbo, a1.z); a1.w = fmaf(w.w, dbo, a1.w);
+    }
+  }
+  red[0][wave][lane] = a0;
+  red[1][wave][lane] = a1;
+  __syncthreads();
+  if (wave == 0 && c < C) {
+    float* dst = dsdt + (long)blockIdx.y * 2 * C;
+    float4 r0 = red[0][0][lane], r1 = red[1][0][lane];
+#pragma unroll
+    for (int k = 1; k < 4; ++k) {
+      const float4 p = red[0][k][lane], q = red[1][k][lane];
+      r0.x += p.x; r0.y += p.y; r0.z += p.z; r0.w += p.w;
+      r1.x += q.x; r1.y += q.y; r1.z += q.z; r1.w += q.w;
+    }
+    *reinterpret_cast<float4*>(dst + c) = r0;
+    *reinterpret_cast<float4*>(dst + C + c) = r1;
+  }
+}
+
 __global__ void fold_bwd_finalize_kernel(const float* __restrict__ dsdt, int R, double count,
                                          const double* __restrict__ count_dev,
                                          const float* __restrict__ mean,
@@ -138,7 +203,7 @@ extern "C" int seg_fold_weights(int dtype, const float* W, const float* scale, c
 }
 
 extern "C" int seg_fold_bwd_rows(int O) {
-  return O < 4 * seg::FOLD_RS ? 1 : seg::FOLD_RS;
+  return O < 4 * seg::FOLD_RS ? 1 : seg::FOLD_RS4;
 }
 
 extern "C" int seg_fold_bwd_reduce(const float* W, const float* dWp, int splits, const float* scale,
@@ -146,6 +211,12 @@ extern "C" int seg_fold_bwd_reduce(const float* W, const float* dWp, int splits,
                                    int O, int C, void* stream) {
   using namespace seg;
   SEG_REQUIRE(O >= 1 && C >= 1 && splits >= 1, "fold_bwd_reduce: empty");
+  if (C % 4 == 0) {
+    hipLaunchKernelGGL(fold_bwd_reduce4_kernel, dim3((C / 4 + 63) / 64, seg_fold_bwd_rows(O)),
+                       dim3(256), 0, (hipStream_t)stream, W, dWp, splits, scale, shift, db, dW,
+                       dsdt, O, C);
+    return check_launch("fold_bwd_reduce");
+  }
   hipLaunchKernelGGL(fold_bwd_reduce_kernel, dim3((C + 63) / 64, seg_fold_bwd_rows(O)), dim3(256),
                      0, (hipStream_t)stream, W, dWp, splits, scale, shift, db, dW, dsdt, O, C);
   return check_launch("fold_bwd_reduce");
