@@ -268,36 +268,24 @@ def main():
     # ---- launch path: one HIP graph of the whole step (single GPU), else eager
     graph, graph_err, static_loss = None, None, None
     use_graph = world == 1 and not args.no_graph and os.environ.get("SEG_BENCH_GRAPH", "1") != "0"
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):  # eager warm-up off the default stream (lazy init, allocator,
-        for _ in range(3):         # weight-pack caches, DDP bucket rebuild)
-            step()
-    torch.cuda.current_stream().wait_stream(side)
-    torch.cuda.synchronize()
+    loss_fn = lambda out, tgt: torch.nn.functional.cross_entropy(out[0], tgt, ignore_index=-1)
+    from segmentron_amd import functional as SF
+    from segmentron_amd import graph as SG
     if use_graph:
-        try:
-            from segmentron_amd import functional as SF
-            SF.clear_weight_cache()  # the packs must be re-issued INSIDE the capture
-            opt.zero_grad(set_to_none=True)
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                out = model(images)
-                static_loss = torch.nn.functional.cross_entropy(out[0], targets, ignore_index=-1)
-                static_loss.backward()
-                opt.step()
-            torch.cuda.synchronize()
+        try:  # segmentron_amd/graph.py: eager warm-up on a side stream, then ONE capture
+            graph = SG.GraphedTrainStep(model, opt, images, targets, loss_fn)
+            static_loss = graph.loss
         except Exception as e:  # noqa: BLE001
             graph, graph_err = None, repr(e)[:300]
             sys.stderr.write("bench.py: HIP-graph capture failed, running eager: %s\n" % graph_err)
             torch.cuda.synchronize()
-            from segmentron_amd import functional as SF
             SF.clear_weight_cache()
+    if graph is None:
+        SG._warm(step, 3)
 
     def run_step():
         if graph is not None:
-            graph.replay()
-            return static_loss
+            return graph()
         return step()
 
     # Device pre-conditioning (untimed, reported as "prewarm_steps"): a fresh box occasionally ran
@@ -332,8 +320,7 @@ def main():
     roofline_steps = args.steps
     if graph is not None:
         # per-launch HIP events of the dominant kernel: eager steps (same kernels, same shapes)
-        from segmentron_amd import functional as SF
-        SF.clear_weight_cache()
+        graph.release()
         roofline_steps = 3
         step()
         torch.cuda.synchronize()

@@ -322,3 +322,48 @@ def test_train_step_fp32_513x1025_matches_oracle():
           "worst %s (ratio to bound %.2f)" % (gh_all, gc_all, worst[0][1], worst[0][0]))
     assert gh_all <= 3 * gc_all + 1e-4
     assert worst[0][0] <= 1.0, worst[0]
+
+
+def test_graphed_inference_and_train_step_equal_eager():
+    """segmentron_amd/graph.py: a forward pass / a whole train step captured into one HIP graph
+    replays bit-identically to the eager launches (same kernels, same order, deterministic)."""
+    import copy
+    from segmentron_amd.graph import GraphedInference, GraphedTrainStep
+    model, _ = _build(torch.bfloat16)
+    x = synth.synth_images(2, 129, 193, seed=2).cuda()
+    with torch.no_grad():
+        ref = model(x)[0].clone()
+    g = GraphedInference(model, x)
+    assert torch.equal(g()[0], ref)
+    x2 = synth.synth_images(2, 129, 193, seed=3).cuda()
+    with torch.no_grad():
+        ref2 = model(x2)[0].clone()
+    assert torch.equal(g(x2)[0], ref2) and not torch.equal(ref, ref2)
+    del g
+    # train: two optimizer steps eager vs graphed from the same initial state
+    model.train()
+    model.head.aspp.dropout.p = 0.0
+    y = synth.synth_targets(2, 129, 193, seed=2).cuda()
+    loss_fn = lambda out, t: torch.nn.functional.cross_entropy(out[0], t, ignore_index=-1)
+    twin = copy.deepcopy(model)
+    opt_a = torch.optim.SGD(model.parameters(), lr=0.01, momentum=0.9)
+    opt_b = torch.optim.SGD(twin.parameters(), lr=0.01, momentum=0.9)
+    # one REAL (eager) step on both first — it creates the optimizer's momentum buffers, which
+    # must exist before the capture (a captured first step would re-initialise them every replay)
+    step = GraphedTrainStep(twin, opt_b, x, y, loss_fn, warmup=1)
+    loss = loss_fn(model(x), y)
+    opt_a.zero_grad(set_to_none=True)
+    loss.backward()
+    opt_a.step()
+    la = []
+    for _ in range(2):
+        loss = loss_fn(model(x), y)
+        opt_a.zero_grad(set_to_none=True)
+        loss.backward()
+        opt_a.step()
+        la.append(loss.item())
+    lb = [step().item() for _ in range(2)]
+    print("eager losses %s, graphed %s" % (la, lb))
+    assert la == lb
+    for (k, p), (_, q) in zip(model.named_parameters(), twin.named_parameters()):
+        assert torch.equal(p, q), k

@@ -88,10 +88,26 @@ def main():
                 out = model(x)
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / n
+        # the same forward as ONE HIP graph (segmentron_amd/graph.py)
+        from segmentron_amd.graph import GraphedInference
+        ginf = GraphedInference(model, x)
+        for _ in range(3):
+            gout = ginf()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 20
+        for _ in range(n):
+            gout = ginf()
+        torch.cuda.synchronize()
+        dtg = (time.perf_counter() - t0) / n
+        same = bool(torch.equal(gout[0], out[0]))
         print(json.dumps({"config": tag, "model": cfg.MODEL.MODEL_NAME, "backbone": cfg.MODEL.BACKBONE,
                           "batch": B, "size": [H, W], "ms_per_batch": dt * 1e3,
-                          "images_per_sec": B / dt, "finite": bool(torch.isfinite(out[0]).all()),
+                          "images_per_sec": B / dt, "graph_ms_per_batch": dtg * 1e3,
+                          "graph_images_per_sec": B / dtg, "graph_equals_eager": same,
+                          "finite": bool(torch.isfinite(out[0]).all()),
                           "out_shape": list(out[0].shape)}), flush=True)
+        del ginf, gout
         del model, out, x
         torch.cuda.empty_cache()
 
