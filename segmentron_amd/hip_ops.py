@@ -457,8 +457,19 @@ def adaptive_avgpool_bwd(gy, in_hw):
     return gx
 
 
+_BIN_AREAS = {}
+
+
 def adaptive_bin_areas(H, W, o, device):
-    """[o, o] fp32 areas of ATen's adaptive-pool bins."""
+    """[o, o] fp32 areas of ATen's adaptive-pool bins (cached per geometry: a host-to-device
+    copy must not happen inside a HIP-graph capture)."""
+    key = (H, W, o, str(device))
+    if key not in _BIN_AREAS:
+        _BIN_AREAS[key] = _adaptive_bin_areas(H, W, o, device)
+    return _BIN_AREAS[key]
+
+
+def _adaptive_bin_areas(H, W, o, device):
     import math
     hs = [math.ceil((i + 1) * H / o) - (i * H) // o for i in range(o)]
     ws = [math.ceil((j + 1) * W / o) - (j * W) // o for j in range(o)]
