@@ -173,6 +173,31 @@ __device__ __forceinline__ void apply_prologue(float* f, int mode, const float* 
   }
 }
 
+// Same, with the channel parameters already in registers (loaded once per K slab).
+template <int N>
+__device__ __forceinline__ void apply_prologue_regs(float* f, int mode, const float (&s)[N],
+                                                    const float (&t)[N]) {
+  if (mode & PRO_AFFINE) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) f[i] = fmaf(f[i], s[i], t[i]);
+  }
+  if (mode & PRO_RELU) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) f[i] = fmaxf(f[i], 0.f);
+  }
+  if (mode & PRO_CLAMP6) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) f[i] = fminf(f[i], 6.f);
+  }
+}
+
+// v if keep else 0, component-wise (a ?: on the uint4 STRUCT becomes a select between two stack
+// addresses and sends both operands through scratch memory)
+__device__ __forceinline__ uint4 mask_u4(const uint4& v, bool keep) {
+  const unsigned m = keep ? 0xFFFFFFFFu : 0u;
+  return make_uint4(v.x & m, v.y & m, v.z & m, v.w & m);
+}
+
 // MI355X has 8 XCDs with private L2s and the dispatcher places block b on XCD b % 8
 // (speed-only assumption).  Remap so each XCD works on a contiguous range of logical tiles
 // (bijective for any block count).

@@ -24,20 +24,29 @@ namespace seg {
 //        pointers set up once and advanced by a constant per K-slab (no per-slab index math).
 // DBUF : two LDS stages, one barrier per slab (2 blocks/CU) vs one stage, two barriers per slab
 //        (3 blocks/CU).  The variant is chosen by the host (seg_conv_gemm_config).
-template <typename T, bool FAST, bool DBUF>
+// WIDE : block tile 256 pixels x 64 output channels (waves 4x1) instead of 128 x 128 (2x2): KxK
+//        convolutions with O <= 64 at large spatial sizes (network stems, the ResNet layer1
+//        3x3s) would otherwise spend half of their MFMAs and B staging on zero columns.
+template <typename T, bool FAST, bool DBUF, bool WIDE = false>
 __global__ __launch_bounds__(GEMM_THREADS, (DBUF || !FAST) ? 2 : 3) void conv_gemm_fwd_kernel(
     const ConvGemmArgs a) {
+  static_assert(!WIDE || (!FAST && !DBUF), "the wide tile exists for the general path only");
   constexpr int VEC = Vec<T>::N;
   constexpr int BK = ROW_BYTES / (int)sizeof(T);
   constexpr int NSTAGE = DBUF ? 2 : 1;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[NSTAGE * 2 * TILE_BYTES];
+  constexpr int TBM = WIDE ? 256 : BM, TBN = WIDE ? 64 : BN;   // block tile
+  constexpr int RA = TBM / 32, RB = TBN / 32;                  // staged rows per thread
+  constexpr int WMS = WIDE ? 4 : 2;                            // waves along M
+  constexpr int A_BYTES = TBM * ROW_STRIDE, B_BYTES = TBN * ROW_STRIDE;
+  static_assert(A_BYTES + B_BYTES == 2 * TILE_BYTES || WIDE, "stage layout");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NSTAGE * (A_BYTES + B_BYTES)];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = WIDE ? wave : wave >> 1, wn = WIDE ? 0 : wave & 1;
   const int L = xcd_remap(blockIdx.x, a.tiles_m * a.tiles_n);
   const int tile_m = L / a.tiles_n, tile_n = L - tile_m * a.tiles_n;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int m0 = tile_m * TBM, n0 = tile_n * TBN;
 
   // ---- staging assignment: thread -> vector column vc (16 B) of rows rb + 32*j
   const int vc = tid & 7, rb = tid >> 3;
@@ -45,18 +54,21 @@ __global__ __launch_bounds__(GEMM_THREADS, (DBUF || !FAST) ? 2 : 3) void conv_ge
   const T* __restrict__ W = reinterpret_cast<const T*>(a.w);
 
   // general path state
-  long a_base[4];
-  int a_hi0[4], a_wi0[4];
+  long a_base[RA];
+  int a_hi0[RA], a_wi0[RA];
   // fast path state: row pointers (advanced by the slab offset) and validity
-  const T* pa[4];
-  const T* pb[4];
+  const T* pa[RA];
+  const T* pb[RB];
   unsigned row_ok = 0, col_ok = 0;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int p = m0 + rb + 32 * j;
+  for (int j = 0; j < RB; ++j) {
     const int o = n0 + rb + 32 * j;
     pb[j] = W + (long)(o < a.O ? o : 0) * a.K + vc * VEC;
     if (o < a.O) col_ok |= 1u << j;
+  }
+#pragma unroll
+  for (int j = 0; j < RA; ++j) {
+    const int p = m0 + rb + 32 * j;
     if (FAST) {
       pa[j] = X + (long)(p < a.M ? p : 0) * a.ldx + vc * VEC;
       if (p < a.M) row_ok |= 1u << j;
@@ -80,19 +92,29 @@ __global__ __launch_bounds__(GEMM_THREADS, (DBUF || !FAST) ? 2 : 3) void conv_ge
   }
   const bool single_tap = (a.KH * a.KW == 1);
 
-  uint4 ra[4], rbv[4];
+  uint4 ra[RA], rbv[RB];
   unsigned a_ok_mask = 0;  // bit j: row j of the staged A slab is a real (in-bounds) pixel
-  int cur_c = 0;  // channel of this thread's A vector in the slab being staged
+  unsigned b_ok_mask = 0;  // bit j: row j of the staged B slab is a real output channel / k
+  // BatchNorm prologue parameters of this thread's channel vector in the slab being staged
+  // (fetched with the slab's data, so the LDS staging never waits on its own loads)
+  float ps[VEC], pt[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) { ps[i] = 1.f; pt[i] = 0.f; }
+  const bool affine = (a.pro_mode & PRO_AFFINE) != 0;
+  // Every load below is UNCONDITIONAL (out-of-range vectors read element 0 of the operand and
+  // are replaced by zeros afterwards): a load under a per-lane branch makes hipcc wait for it
+  // inside the branch, which serialised the 8 loads of a slab.
   auto load_slab = [&](int kt) {
     const int kv = kt * BK + vc * VEC;
     const bool kok = kv < a.K;
+    int cur_c;
     if (FAST) {
       cur_c = kv;
       a_ok_mask = kok ? row_ok : 0u;
+      const int koff = kok ? kt * BK : 0;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        ra[j] = make_uint4(0, 0, 0, 0);
-        if ((a_ok_mask >> j) & 1u) ra[j] = ldg16(pa[j] + kt * BK);
+      for (int j = 0; j < RA; ++j) {
+        ra[j] = ldg16(pa[j] + koff);  // (masked when staged)
       }
     } else {
       int c = kv, dh = 0, dw = 0;
@@ -104,8 +126,10 @@ __global__ __launch_bounds__(GEMM_THREADS, (DBUF || !FAST) ? 2 : 3) void conv_ge
         dw = (kidx - kh * a.KW) * a.dil;
       }
       cur_c = c;
+      a_ok_mask = 0;
+      long off[RA];  // (all addresses first, then the loads back to back)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < RA; ++j) {
         int hi = a_hi0[j] + dh, wi = a_wi0[j] + dw;
         bool ok = kok;
         if (a.tconv) {
@@ -118,15 +142,22 @@ __global__ __launch_bounds__(GEMM_THREADS, (DBUF || !FAST) ? 2 : 3) void conv_ge
           wi /= a.stride;
         }
         ok = ok && hi >= 0 && hi < a.Hi && wi >= 0 && wi < a.Wi;
-        ra[j] = make_uint4(0, 0, 0, 0);
-        if (ok) ra[j] = ldg16(X + (a_base[j] + (long)hi * a.Wi + wi) * a.ldx + c);
-        a_ok_mask = ok ? (a_ok_mask | (1u << j)) : (a_ok_mask & ~(1u << j));
+        off[j] = ok ? (a_base[j] + (long)hi * a.Wi + wi) * a.ldx + c : 0;
+        a_ok_mask |= ok ? (1u << j) : 0u;
       }
-    }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      rbv[j] = make_uint4(0, 0, 0, 0);
-      if (kok && ((col_ok >> j) & 1u)) rbv[j] = ldg16(pb[j] + kt * BK);
+      for (int j = 0; j < RA; ++j) ra[j] = ldg16(X + off[j]);  // (masked when staged)
+    }
+    {
+      const int koff = kok ? kt * BK : 0;
+#pragma unroll
+      for (int j = 0; j < RB; ++j) rbv[j] = ldg16(pb[j] + koff);
+      b_ok_mask = kok ? col_ok : 0u;
+    }
+    if (affine) {  // (uniform branch) channels beyond C only occur with kok == false
+      const int cc = kok ? cur_c : 0;
+      load_params<VEC>(a.pro_scale, cc, ps);
+      load_params<VEC>(a.pro_shift, cc, pt);
     }
   };
 
@@ -141,19 +172,23 @@ __global__ __launch_bounds__(GEMM_THREADS, (DBUF || !FAST) ? 2 : 3) void conv_ge
   const int nk = (a.K + BK - 1) / BK;
   auto stage = [&](int buf) {
     // registers -> LDS (fused BN/ReLU prologue on the activation operand; padding stays zero)
-    unsigned char* sA = smem + (DBUF ? buf : 0) * 2 * TILE_BYTES;
-    unsigned char* sB = sA + TILE_BYTES;
+    unsigned char* sA = smem + (DBUF ? buf : 0) * (A_BYTES + B_BYTES);
+    unsigned char* sB = sA + A_BYTES;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < RB; ++j)
+      *reinterpret_cast<uint4*>(sB + (rb + 32 * j) * ROW_STRIDE + vc * 16) =
+          mask_u4(rbv[j], (b_ok_mask >> j) & 1u);
+#pragma unroll
+    for (int j = 0; j < RA; ++j) {
       uint4 v = ra[j];
-      if (a.pro_mode != PRO_NONE && ((a_ok_mask >> j) & 1u)) {
+      if (a.pro_mode != PRO_NONE) {  // (uniform; padding and tails are zeroed AFTER the prologue)
         float f[VEC];
         Vec<T>::unpack(v, f);
-        apply_prologue<VEC>(f, a.pro_mode, a.pro_scale, a.pro_shift, cur_c);
+        apply_prologue_regs<VEC>(f, a.pro_mode, ps, pt);
         v = Vec<T>::pack(f);
       }
+      v = mask_u4(v, (a_ok_mask >> j) & 1u);
       *reinterpret_cast<uint4*>(sA + (rb + 32 * j) * ROW_STRIDE + vc * 16) = v;
-      *reinterpret_cast<uint4*>(sB + (rb + 32 * j) * ROW_STRIDE + vc * 16) = rbv[j];
     }
   };
   load_slab(0);
@@ -163,8 +198,8 @@ __global__ __launch_bounds__(GEMM_THREADS, (DBUF || !FAST) ? 2 : 3) void conv_ge
     for (int kt = 0; kt < nk; ++kt) {
       const int cur = kt & 1;
       if (kt + 1 < nk) load_slab(kt + 1);  // global loads in flight under the MFMAs
-      mma_slab<T>(smem + cur * 2 * TILE_BYTES, smem + cur * 2 * TILE_BYTES + TILE_BYTES, wm, wn,
-                  lane, acc);
+      mma_slab<T>(smem + cur * (A_BYTES + B_BYTES), smem + cur * (A_BYTES + B_BYTES) + A_BYTES,
+                  wm, wn, lane, acc);
       if (kt + 1 < nk) stage(cur ^ 1);
       __syncthreads();
     }
@@ -173,7 +208,7 @@ __global__ __launch_bounds__(GEMM_THREADS, (DBUF || !FAST) ? 2 : 3) void conv_ge
       stage(0);
       __syncthreads();
       if (kt + 1 < nk) load_slab(kt + 1);
-      mma_slab<T>(smem, smem + TILE_BYTES, wm, wn, lane, acc);
+      mma_slab<T>(smem, smem + A_BYTES, wm, wn, lane, acc);
       __syncthreads();
     }
   }
@@ -248,24 +283,30 @@ __global__ __launch_bounds__(GEMM_THREADS, (DBUF || !FAST) ? 2 : 3) void conv_ge
   }
   if (a.stat_partial != nullptr) {
     // rows beyond M were staged as zeros (after the prologue), so they add nothing.
-    float* red = reinterpret_cast<float*>(smem);  // [2 wm][2][128]
+    float* red = reinterpret_cast<float*>(smem);  // [WMS wm][2][TBN]
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       float s = csum[j] + __shfl_xor(csum[j], 32, 64);
       float q = csq[j] + __shfl_xor(csq[j], 32, 64);
       if (hh == 0) {
         const int cl = wn * 64 + j * 32 + col;
-        red[(wm * 2 + 0) * 128 + cl] = s;
-        red[(wm * 2 + 1) * 128 + cl] = q;
+        red[(wm * 2 + 0) * TBN + cl] = s;
+        red[(wm * 2 + 1) * TBN + cl] = q;
       }
     }
     __syncthreads();
-    if (tid < 128) {
+    if (tid < TBN) {
       const int o = n0 + tid;
       if (o < a.O) {
         float* dst = a.stat_partial + (long)tile_m * 2 * a.O;
-        dst[o] = red[0 * 128 + tid] + red[2 * 128 + tid];
-        dst[a.O + o] = red[1 * 128 + tid] + red[3 * 128 + tid];
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int w = 0; w < WMS; ++w) {  // (fixed order: deterministic)
+          s += red[(w * 2 + 0) * TBN + tid];
+          q += red[(w * 2 + 1) * TBN + tid];
+        }
+        dst[o] = s;
+        dst[a.O + o] = q;
       }
     }
   }
@@ -278,11 +319,19 @@ static int g_gemm_px256 = 2;
 static int g_gemm_dbuf = 0;  // single LDS stage, 3 blocks/CU: measured faster on every C3 shape
                              // (gpurun_out/gemm_bench2: 709 vs 622 TF on 1536->2048 @65x129)
 
+// The 256 x 64 tile of the general path: few output channels, many pixels.
+static bool gemm_use_wide(int KH, int KW, int stride, int pad, int tconv, int O, long M) {
+  const bool fast = KH * KW == 1 && stride == 1 && pad == 0 && !tconv;
+  return !fast && O <= 64 && M >= 16384;
+}
+
 template <typename T>
 static int launch_conv_gemm_fwd(const ConvGemmArgs& a, hipStream_t stream) {
   const dim3 grid(a.tiles_m * a.tiles_n), block(GEMM_THREADS);
   const bool fast = a.KH * a.KW == 1 && a.stride == 1 && a.pad == 0 && !a.tconv;
-  if (fast) {
+  if (gemm_use_wide(a.KH, a.KW, a.stride, a.pad, a.tconv, a.O, a.M)) {
+    hipLaunchKernelGGL((conv_gemm_fwd_kernel<T, false, false, true>), grid, block, 0, stream, a);
+  } else if (fast) {
     if (g_gemm_dbuf) hipLaunchKernelGGL((conv_gemm_fwd_kernel<T, true, true>), grid, block, 0, stream, a);
     else hipLaunchKernelGGL((conv_gemm_fwd_kernel<T, true, false>), grid, block, 0, stream, a);
   } else {
@@ -327,6 +376,7 @@ extern "C" int seg_conv_gemm_stat_rows(int N, int Ho, int Wo, int O, int KH, int
   const long M = (long)N * Ho * Wo;
   if (seg::g_gemm_px256 && gemm_use_px256(KH, KW, stride, pad, tconv, O, M))
     return seg::px256_tiles_m(M);
+  if (seg::gemm_use_wide(KH, KW, stride, pad, tconv, O, M)) return (int)((M + 255) / 256);
   return (int)((M + seg::BM - 1) / seg::BM);
 }
 
@@ -360,6 +410,10 @@ extern "C" int seg_conv_gemm_fwd(int dtype, const void* x, long ldx, int N, int 
   a.M = N * Ho * Wo; a.K = KH * KW * C;
   a.out_H = out_H; a.out_W = out_W; a.out_s = out_s;
   a.tiles_m = (a.M + BM - 1) / BM; a.tiles_n = (O + BN - 1) / BN;
+  if (gemm_use_wide(KH, KW, stride, pad, tconv, O, a.M)) {
+    a.tiles_m = (a.M + 255) / 256;
+    a.tiles_n = (O + 63) / 64;
+  }
   SEG_REQUIRE(out_s == 1 || stat_partial == nullptr, "conv_gemm_fwd: no statistics with scatter");
   if (g_gemm_px256 && gemm_use_px256(KH, KW, stride, pad, tconv, O, a.M) && out_s == 1) {
     if (g_gemm_px256 >= 2 && conv_gemm_glds_usable(dtype, a))

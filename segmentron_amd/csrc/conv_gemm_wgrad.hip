@@ -50,7 +50,7 @@ template <> struct Transpose<bf16_t> {  // 8x8 of 16-bit
 };
 
 template <typename T, bool DBUF>
-__global__ __launch_bounds__(GEMM_THREADS, (DBUF || sizeof(T) == 4) ? 2 : 3) void conv_gemm_wgrad_kernel(
+__global__ __launch_bounds__(GEMM_THREADS, 2) void conv_gemm_wgrad_kernel(
     const WgradArgs a) {
   constexpr int VEC = Vec<T>::N;
   constexpr int BKP = ROW_BYTES / (int)sizeof(T);  // pixels per slab (64 bf16 / 32 f32)
@@ -119,53 +119,76 @@ __global__ __launch_bounds__(GEMM_THREADS, (DBUF || sizeof(T) == 4) ? 2 : 3) voi
       b_vec[q] = true;
     }
   }
+  // BatchNorm prologue parameters of each block's channel vector (loop-invariant per thread)
+  float ps[NBLK][VEC], pt[NBLK][VEC];
+  const bool affine = (a.pro_mode & PRO_AFFINE) != 0;
+#pragma unroll
+  for (int q = 0; q < NBLK; ++q) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) { ps[q][i] = 1.f; pt[q][i] = 0.f; }
+    if (affine) {  // (uniform)
+      const int cc = (b_op[q] == 1 && b_colok[q]) ? b_c[q] : 0;
+      load_params<VEC>(a.pro_scale, cc, ps[q]);
+      load_params<VEC>(a.pro_shift, cc, pt[q]);
+    }
+  }
   uint4 regs[NBLK][VEC];
+  unsigned okm[NBLK];  // bit j: pixel row j of block q is real (masked when staged)
+  // Every load of the slab is UNCONDITIONAL (rows that
+  // do not exist read element 0 of their operand and are zeroed when staged): loads under
+  // per-lane branches, each followed by its own prologue, serialised on the memory latency, and
+  // the per-pixel p -> (n, ho, wo) divisions are replaced by one division per block and slab.
   auto load_slab = [&](int p0) {
 #pragma unroll
     for (int q = 0; q < NBLK; ++q) {
-      const long ld = b_op[q] == 0 ? a.lddy : a.ldx;
+      const bool is_x = b_op[q] == 1;
+      const long ld = is_x ? a.ldx : a.lddy;
       const T* base = b_ptr[q] + (long)(p0 - p_begin) * ld;
+      const int pf = p0 + b_pg[q] * VEC;
+      okm[q] = 0;
+      if (!is_x && !b_vec[q]) {  // ragged channel tail of dY (e.g. O = 19): element-wise
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          uint4 v = make_uint4(0, 0, 0, 0);
+          if (pf + j < p_end && b_colok[q]) {
+            const int o = o0 + b_v[q] * VEC;
+            float f[VEC];
+#pragma unroll
+            for (int i = 0; i < VEC; ++i)
+              f[i] = (o + i < a.O) ? Vec<T>::load1(base + j * ld + i) : 0.f;
+            v = Vec<T>::pack(f);
+            okm[q] |= 1u << j;
+          }
+          regs[q][j] = v;
+        }
+        continue;
+      }
+      int wo = 0, ho = 0, n = 0;
+      if (is_x && !simple) {
+        wo = pf % a.Wo;
+        const int t = pf / a.Wo;
+        ho = t % a.Ho;
+        n = t / a.Ho;
+      }
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
-        const int p = p0 + b_pg[q] * VEC + j;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (p < p_end && b_colok[q]) {
-          if (b_op[q] == 0) {
-            if (b_vec[q]) {
-              v = ldg16(base + j * ld);
-            } else {  // ragged channel tail (e.g. O = 19): element-wise
-              const int o = o0 + b_v[q] * VEC;
-              float f[VEC];
-#pragma unroll
-              for (int i = 0; i < VEC; ++i)
-                f[i] = (o + i < a.O) ? Vec<T>::load1(base + j * ld + i) : 0.f;
-              v = Vec<T>::pack(f);
-            }
-          } else {
-            const T* src = base + j * ld;
-            bool ok = true;
-            if (!simple) {
-              const int wo = p % a.Wo;
-              const int t = p / a.Wo;
-              const int ho = t % a.Ho;
-              const int n = t / a.Ho;
-              const int hi = ho * a.stride - a.pad + b_dh[q];
-              const int wi = wo * a.stride - a.pad + b_dw[q];
-              ok = hi >= 0 && hi < a.Hi && wi >= 0 && wi < a.Wi;
-              src = X + (((long)n * a.Hi + hi) * a.Wi + wi) * a.ldx + b_c[q];
-            }
-            if (ok) {
-              v = ldg16(src);
-              if (a.pro_mode != PRO_NONE) {
-                float f[VEC];
-                Vec<T>::unpack(v, f);
-                apply_prologue<VEC>(f, a.pro_mode, a.pro_scale, a.pro_shift, b_c[q]);
-                v = Vec<T>::pack(f);
-              }
-            }
-          }
+        bool ok = pf + j < p_end && b_colok[q];
+        const T* sp = base + j * ld;
+        if (is_x && !simple) {
+          const int hi = ho * a.stride - a.pad + b_dh[q];
+          const int wi = wo * a.stride - a.pad + b_dw[q];
+          ok = ok && hi >= 0 && hi < a.Hi && wi >= 0 && wi < a.Wi;
+          sp = X + (((long)n * a.Hi + hi) * a.Wi + wi) * a.ldx + b_c[q];
+          ++wo;
+          const bool wrap = wo == a.Wo;
+          wo = wrap ? 0 : wo;
+          ho += wrap ? 1 : 0;
+          const bool wrap2 = ho == a.Ho;
+          ho = wrap2 ? 0 : ho;
+          n += wrap2 ? 1 : 0;
         }
-        regs[q][j] = v;
+        regs[q][j] = ldg16(ok ? sp : (is_x ? X : DY));
+        okm[q] |= ok ? (1u << j) : 0u;
       }
     }
   };
@@ -183,8 +206,24 @@ __global__ __launch_bounds__(GEMM_THREADS, (DBUF || sizeof(T) == 4) ? 2 : 3) voi
     unsigned char* sB = sA + TILE_BYTES;
 #pragma unroll
     for (int q = 0; q < NBLK; ++q) {
+      const bool pro = a.pro_mode != PRO_NONE && b_op[q] == 1;
+      uint4 r[VEC];
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        uint4 v = regs[q][j];
+        if (a.pro_mode != PRO_NONE) {  // (uniform; the activation operand only)
+          float f[VEC];
+          Vec<T>::unpack(v, f);
+          apply_prologue_regs<VEC>(f, a.pro_mode, ps[q], pt[q]);
+          const uint4 u = Vec<T>::pack(f);
+          const unsigned m = pro ? 0xFFFFFFFFu : 0u;
+          v = make_uint4((u.x & m) | (v.x & ~m), (u.y & m) | (v.y & ~m), (u.z & m) | (v.z & ~m),
+                         (u.w & m) | (v.w & ~m));
+        }
+        r[j] = mask_u4(v, (okm[q] >> j) & 1u);
+      }
       uint4 w[VEC];
-      Transpose<T>::run(regs[q], w);
+      Transpose<T>::run(r, w);
       unsigned char* dst = (b_op[q] == 0 ? sA : sB) + (b_v[q] * VEC) * ROW_STRIDE + b_pg[q] * 16;
 #pragma unroll
       for (int i = 0; i < VEC; ++i) *reinterpret_cast<uint4*>(dst + i * ROW_STRIDE) = w[i];

@@ -36,6 +36,69 @@ __global__ __launch_bounds__(256) void fold_weights_kernel(const float* __restri
   if (lane == 0 && bprime) bprime[o] = acc;
 }
 
+// Tiled version (C % 4 == 0, O % 8 == 0): blocks [0, tiles) scale one 64(o) x 64(c) tile each
+// and emit it twice — row-major (Wp) straight from the registers, and transposed (WpT) through
+// an LDS tile, 16 bytes of consecutive o per store (the wave-per-row kernel above writes WpT as
+// 2-byte stores one row apart: 11 us for 728x728).  Blocks [tiles, tiles + ceil(O/4)) compute
+// b'[o] = W[o,:] . t, one wave per row.
+template <typename T>
+__global__ __launch_bounds__(256) void fold_weights_tiled_kernel(
+    const float* __restrict__ W, const float* __restrict__ s, const float* __restrict__ t,
+    T* __restrict__ Wp, T* __restrict__ WpT, float* __restrict__ bprime, int O, int C,
+    int tiles_c, int tiles) {
+  constexpr int VEC = Vec<T>::N;
+  __shared__ float tile[64][65];
+  const int tid = threadIdx.x;
+  if ((int)blockIdx.x >= tiles) {  // ---- row dot products
+    const int lane = tid & 63;
+    const int o = ((int)blockIdx.x - tiles) * 4 + (tid >> 6);
+    if (o >= O || bprime == nullptr) return;
+    float acc = 0.f;
+    for (int c = lane * 4; c < C; c += 256) {
+      const float4 w = *reinterpret_cast<const float4*>(W + (long)o * C + c);
+      const float4 tt = *reinterpret_cast<const float4*>(t + c);
+      acc = fmaf(w.x, tt.x, fmaf(w.y, tt.y, fmaf(w.z, tt.z, fmaf(w.w, tt.w, acc))));
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) bprime[o] = acc;
+    return;
+  }
+  const int to = blockIdx.x / tiles_c, tc = blockIdx.x - to * tiles_c;
+  const int o0 = to * 64, c0 = tc * 64;
+  const int cq = tid & 15, r = tid >> 4;
+  const int c = c0 + cq * 4;
+  float4 sv = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c < C) sv = *reinterpret_cast<const float4*>(s + c);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int ro = r + 16 * i, o = o0 + ro;
+    float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (o < O && c < C) w = *reinterpret_cast<const float4*>(W + (long)o * C + c);
+    const float f[4] = {w.x * sv.x, w.y * sv.y, w.z * sv.z, w.w * sv.w};
+    if (o < O && c < C) HVec<T>::store(Wp + (long)o * C + c, f);
+    tile[ro][cq * 4 + 0] = f[0];
+    tile[ro][cq * 4 + 1] = f[1];
+    tile[ro][cq * 4 + 2] = f[2];
+    tile[ro][cq * 4 + 3] = f[3];
+  }
+  if (WpT == nullptr) return;
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int idx = tid + 256 * i;
+    const int og = idx & 7, cl = idx >> 3;  // 8 consecutive o of column cl
+    const int o = o0 + og * 8, cc = c0 + cl;
+    if (cc < C && o < O) {  // (O % 8 == 0: the 8 rows exist together)
+      float f[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) f[k] = tile[og * 8 + k][cl];
+      T* dst = WpT + (long)cc * O + o;
+#pragma unroll
+      for (int k = 0; k < 8; k += VEC) Vec<T>::store(dst + k, f + k);
+    }
+  }
+}
+
 // dWp arrives as the weight-gradient GEMM's split partials [S][O*C] (summed here in a fixed
 // order: the separate column-sum pass and its 2x2 MB round trip are gone).  Lanes run along c
 // (256 contiguous bytes per row and wave), a block owns 64 columns x one of RS row ranges and
@@ -192,6 +255,19 @@ extern "C" int seg_fold_weights(int dtype, const float* W, const float* scale, c
   using namespace seg;
   SEG_REQUIRE(dtype == DT_F32 || dtype == DT_BF16, "fold_weights: bad dtype %d", dtype);
   SEG_REQUIRE(O >= 1 && C >= 1 && W && scale && shift && Wp, "fold_weights: bad arguments");
+  if (C % 4 == 0 && O % 8 == 0) {
+    const int tiles_c = (C + 63) / 64, tiles = tiles_c * ((O + 63) / 64);
+    const dim3 grid(tiles + (bprime ? (O + 3) / 4 : 0));
+    if (dtype == DT_BF16)
+      hipLaunchKernelGGL((fold_weights_tiled_kernel<bf16_t>), grid, dim3(256), 0,
+                         (hipStream_t)stream, W, scale, shift, (bf16_t*)Wp, (bf16_t*)WpT, bprime,
+                         O, C, tiles_c, tiles);
+    else
+      hipLaunchKernelGGL((fold_weights_tiled_kernel<float>), grid, dim3(256), 0,
+                         (hipStream_t)stream, W, scale, shift, (float*)Wp, (float*)WpT, bprime, O,
+                         C, tiles_c, tiles);
+    return check_launch("fold_weights");
+  }
   const dim3 grid((O + 3) / 4);
   if (dtype == DT_BF16)
     hipLaunchKernelGGL((fold_weights_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, W,

@@ -58,6 +58,12 @@ CONV_CASES = [
     (2, 45, 47, 728, 728, 1, 1, 0, 1, 0, False, False),
     (1, 65, 67, 200, 392, 1, 1, 0, 1, 3, False, True),
     (2, 33, 63, 264, 1000, 1, 1, 0, 1, 2, True, False),
+    # 256x64-tile general path (KxK, O <= 64, M >= 16384): ragged M, prologue + statistics,
+    # the conv2 data-gradient shape (64 -> 32), a strided stem, a slice output with ragged O
+    (1, 131, 129, 32, 64, 3, 1, 1, 1, 3, False, False),
+    (1, 130, 127, 64, 32, 3, 1, 1, 1, 0, False, False),
+    (1, 261, 259, 8, 32, 3, 2, 1, 1, 0, False, False),
+    (1, 129, 131, 16, 24, 3, 1, 2, 2, 2, False, True),
 ]
 
 
@@ -124,6 +130,8 @@ WGRAD_CASES = [
     (2, 13, 11, 8, 32, 3, 2, 1, 1, 0),
     (1, 12, 20, 256, 19, 1, 1, 0, 1, 3),     # ragged dy channels
     (2, 7, 9, 4096, 512, 3, 1, 1, 1, 0),     # PSP head: K = 36864, one pixel split
+    (1, 131, 129, 32, 64, 3, 1, 1, 1, 3),    # xception conv2 geometry across image-row wraps
+    (2, 67, 70, 8, 32, 3, 2, 1, 1, 2),       # strided stem, two images, prologue
 ]
 
 
@@ -365,6 +373,25 @@ def test_errors_are_reported_not_fatal():
 
 
 # ------------------------------------------------------------------------------ BN fold
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+@pytest.mark.parametrize("O,C", [(136, 200), (728, 728), (40, 72), (19, 50), (256, 2048)])
+def test_fold_weights_pack_transpose_and_bias(dtype, O, C):
+    """W' = W diag(s) row-major and transposed, b' = W t — the tiled kernel (C % 4 == 0 and
+    O % 8 == 0, ragged 64x64 tiles) and the wave-per-row fallback (19 x 50)."""
+    w = rnd((O, C), 11, 0.3)
+    s, t = torch.rand(C) + 0.5, rnd((C,), 12, 0.4)
+    Km = K()
+    wp, wpt, bp = Km.fold_weights(w.to(DEV), s.to(DEV), t.to(DEV), dtype, want_transpose=True)
+    ref = (w.double() * s.double()[None, :])
+    tol = 0 if dtype == torch.float32 else 2 ** -8
+    got, gott = wp.cpu().double(), wpt.cpu().double()
+    assert got.shape == (O, C) and gott.shape == (C, O)
+    assert ((got - ref).abs() <= tol * ref.abs() + 1e-7).all()
+    assert torch.equal(gott, got.t())
+    bref = w.double() @ t.double()
+    assert (bp.cpu().double() - bref).abs().max() <= 1e-5 * (w.abs().double() @ t.abs().double()).max()
+
+
 @pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
 def test_fold_linear_bn_into_pointwise_matches_autograd(dtype):
     """relu_first SeparableConv2d tail: dw_raw -> BN_train(bn_depth) -> 1x1 conv -> (BN_train

@@ -106,6 +106,7 @@ int main(int argc, char** argv) {
     }
     // feature set 0: plain + statistics; 1: bias + slice output (pitch O+24, input pitch K+16);
     // 2: folded-BN epilogue correction
+    const int alt = getenv("GL_ALT") ? atoi(getenv("GL_ALT")) : 1;  // variant in the 'v1' column
     for (int feat = 0; feat < 3; ++feat) {
       const long ldx = feat == 1 ? s.K + 16 : s.K, ldy = feat == 1 ? s.O + 24 : s.O;
       if (feat == 2 && s.O % 8) continue;
@@ -128,7 +129,7 @@ int main(int argc, char** argv) {
         if (which == 1 && !conv_gemm_glds_usable(1, a)) { printf("glds not usable?\n"); continue; }
         CK(hipMemset(dy, 0xFF, (size_t)s.M * ldy * 2));  // NaN pattern: unwritten outputs show up
         CK(hipMemset(dstat, 0, 512 * 2 * 4096 * 4));
-        int rc = which ? launch_conv_gemm_glds_variant(a, 0, 3) : launch_conv_gemm_px256(1, a, 0);
+        int rc = which ? launch_conv_gemm_glds_variant(a, 0, alt > 1 ? alt : 3) : launch_conv_gemm_px256(1, a, 0);
         CK(hipDeviceSynchronize());
         if (rc) { printf("launch failed rc=%d\n", rc); bad++; continue; }
         CK(hipMemcpy(hy.data(), dy, (size_t)s.M * ldy * 2, hipMemcpyDeviceToHost));
@@ -164,7 +165,7 @@ int main(int argc, char** argv) {
       // which: 0 = px256, 1 = glds variant 1 (two 64-k stages), 2 = glds variant 3 (ring)
       auto run = [&](int which) {
         return which == 0 ? launch_conv_gemm_px256(1, a, 0)
-                          : launch_conv_gemm_glds_variant(a, 0, which == 1 ? 1 : 3);
+                          : launch_conv_gemm_glds_variant(a, 0, which == 1 ? alt : 3);
       };
       float ms[3] = {0, 0, 0};
       for (int rep = 0; rep < 3; ++rep)
