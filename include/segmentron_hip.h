@@ -67,11 +67,13 @@ int seg_conv_gemm_wgrad(int dtype, const void* x, long ldx, int N, int Hi, int W
                         int stride, int pad, int dil, int pro_mode, const float* pro_scale,
                         const float* pro_shift, float* partial, int splits, void* stream);
 /* rows of the [rows][2][O] statistics buffer seg_conv_gemm_fwd writes for this geometry */
-int seg_conv_gemm_stat_rows(int N, int Ho, int Wo, int O, int KH, int KW, int stride, int pad,
-                            int tconv);
+int seg_conv_gemm_stat_rows(int dtype, int N, int Ho, int Wo, int C, int O, int KH, int KW,
+                            int stride, int pad, int dil, int tconv, int has_bias);
 /* tuning knob: 2 (default) = 1x1 stride-1 convs on the direct-to-LDS 256x256 bf16 kernel where
  * it applies (no prologue / bias, O % 8 == 0) else the 256x128-tile kernel; 1 = 256x128 only;
- * 0 = first-generation 128x128 kernel; returns the previous value, negative = query only */
+ * 0 = first-generation 128x128 kernel; +4 = keep 3x3 stride-1 bf16 convolutions with C, O in
+ * {32, 64} at >= 65536 pixels on the implicit GEMM instead of the direct halo-tile kernel;
+ * returns the previous value, negative = query only */
 int seg_conv_gemm_px256(int enable);
 /* splits to allocate `partial` for; plain_1x1 = 1 when the call is a 1x1 stride-1 convolution
  * without prologue (those run on the direct-to-LDS kernel, which wants ~one block per CU) */

@@ -33,4 +33,9 @@ int launch_conv_gemm_px256(int dtype, ConvGemmArgs a, hipStream_t stream);
 bool conv_gemm_glds_usable(int dtype, const ConvGemmArgs& a);
 int launch_conv_gemm_glds(ConvGemmArgs a, hipStream_t stream);
 
+// direct 3x3 stride-1 kernel for few channels at large spatial sizes (conv3x3_direct.hip)
+bool conv3x3_direct_usable(int dtype, const ConvGemmArgs& a);
+int conv3x3_direct_blocks(int N, int H, int W);
+int launch_conv3x3_direct(const ConvGemmArgs& a, hipStream_t stream);
+
 }  // namespace seg

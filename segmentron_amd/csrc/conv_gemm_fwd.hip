@@ -316,6 +316,7 @@ __global__ __launch_bounds__(GEMM_THREADS, (DBUF || !FAST) ? 2 : 3) void conv_ge
 // (conv_gemm_px256.hip), 2 = direct-to-LDS 256x256 kernel where it applies (conv_gemm_glds.hip:
 // bf16, no prologue), 256x128 otherwise
 static int g_gemm_px256 = 2;
+static int g_conv3x3_direct = 1;  // bit 2 of seg_conv_gemm_px256's argument CLEARS it (A/B runs)
 static int g_gemm_dbuf = 0;  // single LDS stage, 3 blocks/CU: measured faster on every C3 shape
                              // (gpurun_out/gemm_bench2: 709 vs 622 TF on 1536->2048 @65x129)
 
@@ -355,8 +356,11 @@ extern "C" int seg_conv_gemm_config(int double_buffer) {
 // applies and on the 256x128-tile kernel otherwise; 1: 256x128 only; 0: first-generation
 // 128x128 kernel everywhere.  Returns the previous value; a negative argument only queries.
 extern "C" int seg_conv_gemm_px256(int enable) {
-  const int prev = seg::g_gemm_px256;
-  if (enable >= 0) seg::g_gemm_px256 = enable > 2 ? 2 : enable;
+  const int prev = seg::g_gemm_px256 | (seg::g_conv3x3_direct ? 0 : 4);
+  if (enable >= 0) {
+    seg::g_gemm_px256 = (enable & 3) > 2 ? 2 : (enable & 3);
+    seg::g_conv3x3_direct = (enable & 4) ? 0 : 1;
+  }
   return prev;
 }
 
@@ -371,11 +375,21 @@ static bool gemm_use_px256(int KH, int KW, int stride, int pad, int tconv, int O
 }
 
 // rows of the statistics partial buffer [rows][2][O] the forward kernel will write
-extern "C" int seg_conv_gemm_stat_rows(int N, int Ho, int Wo, int O, int KH, int KW, int stride,
-                                       int pad, int tconv) {
+extern "C" int seg_conv_gemm_stat_rows(int dtype, int N, int Ho, int Wo, int C, int O, int KH,
+                                       int KW, int stride, int pad, int dil, int tconv,
+                                       int has_bias) {
   const long M = (long)N * Ho * Wo;
   if (seg::g_gemm_px256 && gemm_use_px256(KH, KW, stride, pad, tconv, O, M))
     return seg::px256_tiles_m(M);
+  {  // the direct 3x3 kernel (stride 1, pad 1: the input has the output's size)
+    seg::ConvGemmArgs probe = {};
+    probe.KH = KH; probe.KW = KW; probe.stride = stride; probe.pad = pad; probe.dil = dil;
+    probe.tconv = tconv; probe.out_s = 1; probe.C = C; probe.O = O; probe.ldx = 8; probe.ldy = 8;
+    probe.Ho = probe.Hi = Ho; probe.Wo = probe.Wi = Wo; probe.M = (int)M;
+    probe.bias = has_bias ? reinterpret_cast<const float*>(&probe) : nullptr;
+    if (seg::g_conv3x3_direct && seg::conv3x3_direct_usable(dtype, probe))
+      return seg::conv3x3_direct_blocks(N, Ho, Wo);
+  }
   if (seg::gemm_use_wide(KH, KW, stride, pad, tconv, O, M)) return (int)((M + 255) / 256);
   return (int)((M + seg::BM - 1) / seg::BM);
 }
@@ -420,6 +434,8 @@ extern "C" int seg_conv_gemm_fwd(int dtype, const void* x, long ldx, int N, int 
       return launch_conv_gemm_glds(a, (hipStream_t)stream);
     return launch_conv_gemm_px256(dtype, a, (hipStream_t)stream);
   }
+  if (g_conv3x3_direct && conv3x3_direct_usable(dtype, a))
+    return launch_conv3x3_direct(a, (hipStream_t)stream);
   if (dtype == DT_BF16) return launch_conv_gemm_fwd<bf16_t>(a, (hipStream_t)stream);
   return launch_conv_gemm_fwd<float>(a, (hipStream_t)stream);
 }

@@ -64,6 +64,13 @@ CONV_CASES = [
     (1, 130, 127, 64, 32, 3, 1, 1, 1, 0, False, False),
     (1, 261, 259, 8, 32, 3, 2, 1, 1, 0, False, False),
     (1, 129, 131, 16, 24, 3, 1, 2, 2, 2, False, True),
+    # direct halo-tile 3x3 kernel (bf16, stride 1, C/O in {32, 64}, >= 65536 pixels): ragged
+    # tile rows / columns, BatchNorm+ReLU prologue with zero padding, statistics, two images,
+    # channel-slice input and output
+    (1, 260, 257, 32, 64, 3, 1, 1, 1, 3, False, False),
+    (1, 259, 261, 64, 32, 3, 1, 1, 1, 0, False, False),
+    (2, 131, 259, 32, 32, 3, 1, 1, 1, 2, False, True),
+    (2, 129, 257, 64, 32, 3, 1, 1, 1, 3, False, False),
 ]
 
 
@@ -93,9 +100,13 @@ def test_conv_gemm_fwd(case, dtype):
     assert_close(got, ref, dtype, "conv y")
     if partial is not None:
         nb = ref - (0 if b is None else b.view(1, -1, 1, 1).double())
-        if dtype == torch.bfloat16 and k == 1 and stride == 1 and pad == 0 and O >= 384 \
-                and N * ref.shape[2] * ref.shape[3] >= 4096:
-            # the 256x128 kernel takes the statistics of the values AS STORED (bf16-rounded):
+        M = N * ref.shape[2] * ref.shape[3]
+        direct = k == 3 and stride == 1 and pad == 1 and dil == 1 and M >= 65536 and \
+            (C, O) in ((32, 32), (32, 64), (64, 32))
+        if dtype == torch.bfloat16 and (direct or (k == 1 and stride == 1 and pad == 0
+                                                   and O >= 384 and M >= 4096)):
+            # the 256x128 and direct-3x3 kernels take the statistics of the values AS STORED
+            # (bf16-rounded):
             # that is the tensor the consumer's normalisation is applied to
             nb = quant(nb.float(), dtype).double()
         sums = K().colsum(partial.view(partial.shape[0], -1)).cpu()
