@@ -75,9 +75,11 @@ int seg_conv_gemm_stat_rows(int dtype, int N, int Ho, int Wo, int C, int O, int 
  * {32, 64} at >= 65536 pixels on the implicit GEMM instead of the direct halo-tile kernel;
  * returns the previous value, negative = query only */
 int seg_conv_gemm_px256(int enable);
-/* splits to allocate `partial` for; plain_1x1 = 1 when the call is a 1x1 stride-1 convolution
- * without prologue (those run on the direct-to-LDS kernel, which wants ~one block per CU) */
-int seg_conv_gemm_wgrad_splits(int dtype, int N, int Ho, int Wo, int O, int K, int plain_1x1);
+/* splits to allocate `partial` for (same geometry arguments as the seg_conv_gemm_wgrad call:
+ * plain 1x1 convolutions run on the direct-to-LDS kernel, which wants ~one block per CU; the
+ * 3x3 stride-1 stems with 32 input channels on persistent blocks, one partial each) */
+int seg_conv_gemm_wgrad_splits(int dtype, int N, int Ho, int Wo, int C, int O, int KH, int KW,
+                               int stride, int pad, int dil, int pro_mode);
 int seg_conv_gemm_wgrad_config(int double_buffer);
 
 /* ---- nn.Conv2d, groups=C, 3x3, padding=dilation (depthwise) --------------------------------

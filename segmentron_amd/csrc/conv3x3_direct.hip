@@ -266,4 +266,201 @@ int launch_conv3x3_direct(const ConvGemmArgs& a, hipStream_t stream) {
   return launch_d3<64, 1>(a, stream);
 }
 
+
+// =============================================================================================
+// Weight gradient of the same geometry (C = 32 input channels, O = 32 * NOG output channels):
+//     dW[o][kh][kw][c] = sum_p dy[p][o] * act(x)[p + (kh-1, kw-1)][c]
+// The first-generation kernel gathers every 64-pixel slab of x nine times (once per tap) with
+// per-slab index math and reduces 128x128 tiles of which half are padding (conv2: 422 us).
+// Here a block stages the x halo tile (prologue applied, pixel pitch 96 B) and the dy tile
+// (pixel pitch 2*O + 16 B) ONCE per 8x32-pixel tile; both are pixel-major, which is the WRONG
+// way round for MFMA operands whose k index is the pixel — the fragments are read with gfx950's
+// ds_read_b64_tr_b16 (lane = channel, 4 consecutive pixels per read; the pitches put the four
+// pixel rows of a 16-lane read into disjoint bank ranges).  3 * NOG waves: wave w owns kernel
+// row kh = w / NOG and output-channel group og = w % NOG, i.e. three [32 o][32 c] accumulators
+// (kw = 0..2) that live in registers over ALL tiles of the persistent block; per 16-pixel
+// k-step it reads one dy fragment and three x fragments (shifted by kw) for three MFMAs.
+// Every block writes one fp32 partial [O][9*C]; the caller sums them in a fixed order
+// (seg_colsum), as for the other weight-gradient kernels.
+typedef short d3_v4i16 __attribute__((ext_vector_type(4)));
+typedef short d3_v8i16 __attribute__((ext_vector_type(8)));
+
+template <int NOG> struct D3WGeom {
+  static constexpr int C = 32, O = 32 * NOG;
+  static constexpr int THREADS = 64 * 3 * NOG;
+  static constexpr int XP = 96;                       // x halo pixel pitch (bytes)
+  static constexpr int DP = O * 2 + 16;               // dy pixel pitch (bytes)
+  static constexpr int X_BYTES = D3_HH * D3_HW * XP;
+  static constexpr int DY_BYTES = D3_TH * D3_TW * DP;
+  static constexpr int LDS_BYTES = X_BYTES + DY_BYTES;
+  static constexpr int XVEC = D3_HH * D3_HW * (C / 8), DVEC = D3_TH * D3_TW * (O / 8);
+  static constexpr int XPER = (XVEC + THREADS - 1) / THREADS;
+  static constexpr int DPER = (DVEC + THREADS - 1) / THREADS;
+};
+
+__device__ __forceinline__ bf16x8 d3_tr_frag(const d3_lds_t* p, int second_off) {
+  typedef __attribute__((address_space(3))) d3_v4i16 lds_v4;
+  const d3_v4i16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)p);
+  const d3_v4i16 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(p + second_off));
+  const d3_v8i16 v = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int NOG, bool PRO>
+__global__ __launch_bounds__(D3WGeom<NOG>::THREADS, 2) void conv3x3_wgrad_direct_kernel(
+    const void* __restrict__ xv, long ldx, const void* __restrict__ dyv, long lddy,
+    const float* __restrict__ pro_scale, const float* __restrict__ pro_shift, int pro_mode,
+    float* __restrict__ partial, int N, int H, int Wd, int tiles_h, int tiles_w, int ntiles) {
+  using G = D3WGeom<NOG>;
+  typedef bf16_t T;
+  constexpr int C = G::C, O = G::O;
+  extern __shared__ __attribute__((aligned(16))) unsigned char d3_smem[];
+  unsigned char* xs = d3_smem;
+  unsigned char* ds = d3_smem + G::X_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kh = wave / NOG, og = wave % NOG;
+  const T* __restrict__ X = reinterpret_cast<const T*>(xv);
+  const T* __restrict__ DY = reinterpret_cast<const T*>(dyv);
+
+  const int xvec = tid % (C / 8), dvec = tid % (O / 8);  // (THREADS % 8 == 0: fixed per thread)
+  float ps[8], pt[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { ps[i] = 1.f; pt[i] = 0.f; }
+  if (PRO && (pro_mode & PRO_AFFINE)) {
+    load_params<8>(pro_scale, xvec * 8, ps);
+    load_params<8>(pro_shift, xvec * 8, pt);
+  }
+  f32x16 acc[3];
+#pragma unroll
+  for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[kw][e] = 0.f;
+
+  // transpose-read lane addressing: group g = lane >> 4, i = lane & 15 -> pixel 8*(g >> 1) +
+  // (i >> 2) (+4 for the second read) of the k-step, channels (g & 1)*16 + (i & 3)*4 .. +3
+  const int g = lane >> 4, i = lane & 15;
+  const int prow = 8 * (g >> 1) + (i >> 2), cq = (g & 1) * 16 + (i & 3) * 4;
+  const d3_lds_t* a_base = (const d3_lds_t*)ds + prow * G::DP + (og * 32 + cq) * 2;
+  const d3_lds_t* b_base = (const d3_lds_t*)xs + (kh * D3_HW + prow) * G::XP + cq * 2;
+
+  const int nblk = gridDim.x;
+  const int L = xcd_remap(blockIdx.x, nblk);
+  const int per = (ntiles + nblk - 1) / nblk;
+  const int t_end = min(ntiles, (L + 1) * per);
+  for (int t = L * per; t < t_end; ++t) {
+    const int tw = t % tiles_w, tq = t / tiles_w;
+    const int th = tq % tiles_h, n = tq / tiles_h;
+    const int h0 = th * D3_TH, w0 = tw * D3_TW;
+    // ---- stage: all loads first (unconditional, clamped), then prologue / mask / LDS
+    uint4 rx[G::XPER], rd[G::DPER];
+    unsigned okx = 0, okd = 0;
+#pragma unroll
+    for (int q = 0; q < G::XPER; ++q) {
+      const int idx = tid + q * G::THREADS;
+      const int pix = idx / (C / 8);
+      const int hr = pix / D3_HW, hc = pix - hr * D3_HW;
+      const int hi = h0 - 1 + hr, wi = w0 - 1 + hc;
+      const bool ok = idx < G::XVEC && hi >= 0 && hi < H && wi >= 0 && wi < Wd;
+      const long off = ok ? (((long)n * H + hi) * Wd + wi) * ldx + xvec * 8 : 0;
+      rx[q] = ldg16(X + off);
+      okx |= ok ? (1u << q) : 0u;
+    }
+#pragma unroll
+    for (int q = 0; q < G::DPER; ++q) {
+      const int idx = tid + q * G::THREADS;
+      const int pix = idx / (O / 8);
+      const int r = pix / D3_TW, c = pix - r * D3_TW;
+      const int ho = h0 + r, wo = w0 + c;
+      const bool ok = idx < G::DVEC && ho < H && wo < Wd;
+      const long off = ok ? (((long)n * H + ho) * Wd + wo) * lddy + dvec * 8 : 0;
+      rd[q] = ldg16(DY + off);
+      okd |= ok ? (1u << q) : 0u;
+    }
+#pragma unroll
+    for (int q = 0; q < G::XPER; ++q) {
+      const int idx = tid + q * G::THREADS;
+      uint4 v = rx[q];
+      if (PRO) {
+        float f[8];
+        Vec<T>::unpack(v, f);
+        apply_prologue_regs<8>(f, pro_mode, ps, pt);
+        v = Vec<T>::pack(f);
+      }
+      v = mask_u4(v, (okx >> q) & 1u);
+      if (idx < G::XVEC)
+        *reinterpret_cast<uint4*>(xs + (idx / (C / 8)) * G::XP + xvec * 16) = v;
+    }
+#pragma unroll
+    for (int q = 0; q < G::DPER; ++q) {
+      const int idx = tid + q * G::THREADS;
+      if (idx < G::DVEC)
+        *reinterpret_cast<uint4*>(ds + (idx / (O / 8)) * G::DP + dvec * 16) =
+            mask_u4(rd[q], (okd >> q) & 1u);
+    }
+    __syncthreads();
+    // ---- 16 k-steps of 16 pixels: output row r, column half hf
+#pragma unroll
+    for (int r = 0; r < D3_TH; ++r) {
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const bf16x8 fa = d3_tr_frag(a_base + (r * D3_TW + hf * 16) * G::DP, 4 * G::DP);
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const bf16x8 fb =
+              d3_tr_frag(b_base + (r * D3_HW + hf * 16 + kw) * G::XP, 4 * G::XP);
+          acc[kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[kw], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();  // tiles are consumed: the next one may overwrite them
+  }
+  // ---- this block's partial: dW[o][kh][kw][c], o = og*32 + row, c = lane & 31
+  float* P = partial + (long)blockIdx.x * O * (9 * C);
+  const int c = lane & 31, hh = lane >> 5;
+#pragma unroll
+  for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int o = og * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+      P[(long)o * (9 * C) + (kh * 3 + kw) * C + c] = acc[kw][e];
+    }
+}
+
+bool conv3x3_wgrad_direct_usable(int dtype, int C, int O, int KH, int KW, int stride, int pad,
+                                 int dil, long M, long ldx, long lddy) {
+  return dtype == DT_BF16 && KH == 3 && KW == 3 && stride == 1 && pad == 1 && dil == 1 && C == 32 &&
+         (O == 32 || O == 64) && M >= 65536 && (ldx % 8) == 0 && (lddy % 8) == 0;
+}
+
+int launch_conv3x3_wgrad_direct(const void* x, long ldx, const void* dy, long lddy, int N, int H,
+                                int W, int O, int pro_mode, const float* pro_scale,
+                                const float* pro_shift, float* partial, hipStream_t stream) {
+  const int tiles_h = (H + D3_TH - 1) / D3_TH, tiles_w = (W + D3_TW - 1) / D3_TW;
+  const int ntiles = N * tiles_h * tiles_w;
+  const dim3 grid(conv3x3_direct_blocks(N, H, W));
+  const bool pro = pro_mode != PRO_NONE;
+#define SEG_D3W(NOG, P)                                                                         \
+  hipLaunchKernelGGL((conv3x3_wgrad_direct_kernel<NOG, P>), grid, dim3(D3WGeom<NOG>::THREADS),  \
+                     D3WGeom<NOG>::LDS_BYTES, stream, x, ldx, dy, lddy, pro_scale, pro_shift,   \
+                     pro_mode, partial, N, H, W, tiles_h, tiles_w, ntiles)
+  static const int once = [] {
+    int rc = (int)hipFuncSetAttribute(
+        reinterpret_cast<const void*>(&conv3x3_wgrad_direct_kernel<2, true>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, D3WGeom<2>::LDS_BYTES);
+    rc |= (int)hipFuncSetAttribute(
+        reinterpret_cast<const void*>(&conv3x3_wgrad_direct_kernel<2, false>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, D3WGeom<2>::LDS_BYTES);
+    return rc;
+  }();
+  if (once != 0) {
+    set_error("conv3x3_wgrad_direct: cannot reserve %d bytes of LDS", D3WGeom<2>::LDS_BYTES);
+    return 2;
+  }
+  if (O == 64) { if (pro) SEG_D3W(2, true); else SEG_D3W(2, false); }
+  else { if (pro) SEG_D3W(1, true); else SEG_D3W(1, false); }
+#undef SEG_D3W
+  return check_launch("conv_gemm_wgrad (direct 3x3)");
+}
+
 }  // namespace seg

@@ -278,30 +278,36 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_gemm_wgrad_kernel(
 namespace seg {
 static int g_wgrad_dbuf = 0;  // see conv_gemm_fwd.hip: single stage measured faster
 static int g_wgrad_glds = 1;  // plain 1x1 bf16 weight gradients on conv_gemm_wgrad_glds.hip
+static int g_wgrad_direct = 1;  // 3x3 stride-1 stems (C = 32) on conv3x3_direct.hip
 }
 // tuning knob for the weight-gradient kernel, same semantics as seg_conv_gemm_config
 // bit 0: two LDS stages in the first-generation kernel; bit 1 CLEAR (default): plain 1x1 bf16
 // weight gradients run on the direct-to-LDS transpose-read kernel, SET: first generation only
 extern "C" int seg_conv_gemm_wgrad_config(int double_buffer) {
-  const int prev = seg::g_wgrad_dbuf | (seg::g_wgrad_glds ? 0 : 2);
+  const int prev = seg::g_wgrad_dbuf | (seg::g_wgrad_glds ? 0 : 2) | (seg::g_wgrad_direct ? 0 : 4);
   if (double_buffer >= 0) {
     seg::g_wgrad_dbuf = double_buffer & 1;
     seg::g_wgrad_glds = (double_buffer & 2) ? 0 : 1;
+    seg::g_wgrad_direct = (double_buffer & 4) ? 0 : 1;
   }
   return prev;
 }
 
-extern "C" int seg_conv_gemm_wgrad_splits(int dtype, int N, int Ho, int Wo, int O, int K,
-                                          int plain_1x1) {
+extern "C" int seg_conv_gemm_wgrad_splits(int dtype, int N, int Ho, int Wo, int C, int O, int KH,
+                                          int KW, int stride, int pad, int dil, int pro_mode) {
   using namespace seg;
   const int bkp = dtype == DT_BF16 ? 64 : 32;
   const long M = (long)N * Ho * Wo;
+  const int K = KH * KW * C;
+  const bool plain_1x1 = KH == 1 && KW == 1 && stride == 1 && pad == 0 && pro_mode == PRO_NONE;
   if (plain_1x1 && g_wgrad_glds) {  // the call will run on conv_gemm_wgrad_glds.hip
     WgradArgs probe = {};
     probe.KH = probe.KW = 1; probe.stride = 1; probe.pro_mode = PRO_NONE;
     probe.C = K; probe.O = O; probe.M = (int)M; probe.ldx = 8; probe.lddy = 8;
     if (conv_wgrad_glds_usable(dtype, probe)) return conv_wgrad_glds_splits(M, O, K);
   }
+  if (g_wgrad_direct && conv3x3_wgrad_direct_usable(dtype, C, O, KH, KW, stride, pad, dil, M, 8, 8))
+    return conv3x3_direct_blocks(N, Ho, Wo);  // one partial per persistent block
   const int tiles = ((O + BM - 1) / BM) * ((K + BN - 1) / BN);
   static const int target = [] {
     const char* e = getenv("SEG_WGRAD_BLOCKS");  // experiment knob: total blocks aimed for
@@ -341,6 +347,11 @@ extern "C" int seg_conv_gemm_wgrad(int dtype, const void* x, long ldx, int N, in
   if (g_wgrad_glds && conv_wgrad_glds_usable(dtype, a) &&
       splits == conv_wgrad_glds_splits(a.M, O, a.K))
     return launch_conv_wgrad_glds(a, (hipStream_t)stream);
+  if (g_wgrad_direct &&
+      conv3x3_wgrad_direct_usable(dtype, C, O, KH, KW, stride, pad, dil, a.M, ldx, lddy) &&
+      Hi == Ho && Wi == Wo && splits == conv3x3_direct_blocks(N, Ho, Wo))
+    return launch_conv3x3_wgrad_direct(x, ldx, dy, lddy, N, Ho, Wo, O, pro_mode, pro_scale,
+                                       pro_shift, partial, (hipStream_t)stream);
   a.tiles_o = (O + BM - 1) / BM; a.tiles_k = (a.K + BN - 1) / BN;
   const int slabs = (a.M + bkp - 1) / bkp;
   a.chunk = ((slabs + splits - 1) / splits) * bkp;

@@ -143,8 +143,8 @@ def conv_wgrad(x, dy, O, KH, KW, stride, pad, dil, pro=None, raw_partial=False):
     assert Nd == N and Od == O
     mode, ps, pt = _pro(pro)
     K = KH * KW * C
-    plain = int(KH == 1 and KW == 1 and stride == 1 and pad == 0 and mode == PRO_NONE)
-    splits = LIB.query("seg_conv_gemm_wgrad_splits", _DT[x.dtype], N, Ho, Wo, O, K, plain)
+    splits = LIB.query("seg_conv_gemm_wgrad_splits", _DT[x.dtype], N, Ho, Wo, C, O, KH, KW,
+                       stride, pad, dil, mode)
     partial = torch.empty((splits, O * K), dtype=torch.float32, device=x.device)
     LIB.call("seg_conv_gemm_wgrad", _DT[x.dtype], _p(x), ldx, N, Hi, Wi, C, _p(dy), lddy, Ho, Wo,
              O, KH, KW, stride, pad, dil, mode, _p(ps), _p(pt), _p(partial), splits, _stream())

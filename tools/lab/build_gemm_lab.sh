@@ -10,5 +10,5 @@ $H $F -c tools/lab/gemm_lab.hip -o /tmp/gemm_lab.o
 $H --offload-arch=gfx950 /tmp/gemm_lab.o segmentron_amd/csrc/core.o segmentron_amd/csrc/conv_gemm_px256.o /tmp/conv_gemm_glds_lab.o -o tools/lab/gemm_lab
 echo built tools/lab/gemm_lab
 $H $F -c tools/lab/wgrad_lab.hip -o /tmp/wgrad_lab.o
-$H --offload-arch=gfx950 /tmp/wgrad_lab.o segmentron_amd/csrc/core.o segmentron_amd/csrc/conv_gemm_wgrad.o segmentron_amd/csrc/conv_gemm_wgrad_glds.o -o tools/lab/wgrad_lab
+$H --offload-arch=gfx950 /tmp/wgrad_lab.o segmentron_amd/csrc/core.o segmentron_amd/csrc/conv_gemm_wgrad.o segmentron_amd/csrc/conv_gemm_wgrad_glds.o segmentron_amd/csrc/conv3x3_direct.o -o tools/lab/wgrad_lab
 echo built tools/lab/wgrad_lab

@@ -67,7 +67,7 @@ int main(int argc, char** argv) {
     float ms[2] = {0, 0}; int splits[2] = {0, 0};
     for (int which = 0; which < 2; ++which) {  // 0 = first generation, 1 = glds
       seg_conv_gemm_wgrad_config(which ? 0 : 2);
-      const int S = seg_conv_gemm_wgrad_splits(1, 1, 1, s.M, s.O, s.C, which);
+      const int S = seg_conv_gemm_wgrad_splits(1, 1, 1, s.M, s.C, s.O, 1, 1, 1, 0, 1, 0);
       splits[which] = S;
       if ((size_t)S * n * 4 > ((size_t)300 << 20)) { printf("partials do not fit\n"); bad++; continue; }
       CK(hipMemset(dpart, 0xFF, (size_t)S * n * 4));
