@@ -14,6 +14,9 @@ _ROOT = os.path.dirname(_PKG)
 LIB_PATH = os.environ.get("SEGMENTRON_HIP_LIB") or os.path.join(_PKG, "libsegmentron_hip.so")
 HEADER_PATH = os.path.join(_ROOT, "include", "segmentron_hip.h")
 
+# SEG_TRACE_CALLS=1: print every C-ABI launch and synchronise after it (locating a GPU fault)
+_TRACE = os.environ.get("SEG_TRACE_CALLS") == "1"
+
 _CTYPES = {"int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float,
            "double": ctypes.c_double}
 
@@ -61,9 +64,17 @@ class _Lib:
 
     def call(self, name, *args):
         dll = self.load()
+        if _TRACE:  # debugging aid: name + scalar arguments of every launch, synchronised
+            import sys
+            import torch
+            sys.stderr.write("[seg] %s %s\n" % (name, " ".join(
+                str(a) for a in args if isinstance(a, (int, float)) and abs(a) < (1 << 31))))
+            sys.stderr.flush()
         rc = getattr(dll, name)(*args)
         if rc != 0:
             raise RuntimeError("%s failed (%d): %s" % (name, rc, dll.seg_last_error().decode()))
+        if _TRACE:
+            torch.cuda.synchronize()
 
     def query(self, name, *args):
         return getattr(self.load(), name)(*args)

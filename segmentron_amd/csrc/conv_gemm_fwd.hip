@@ -63,14 +63,14 @@ __global__ __launch_bounds__(GEMM_THREADS, (DBUF || !FAST) ? 2 : 3) void conv_ge
 #pragma unroll
   for (int j = 0; j < RB; ++j) {
     const int o = n0 + rb + 32 * j;
-    pb[j] = W + (long)(o < a.O ? o : 0) * a.K + vc * VEC;
+    pb[j] = W + (long)(o < a.O ? o : 0) * a.K;
     if (o < a.O) col_ok |= 1u << j;
   }
 #pragma unroll
   for (int j = 0; j < RA; ++j) {
     const int p = m0 + rb + 32 * j;
     if (FAST) {
-      pa[j] = X + (long)(p < a.M ? p : 0) * a.ldx + vc * VEC;
+      pa[j] = X + (long)(p < a.M ? p : 0) * a.ldx;
       if (p < a.M) row_ok |= 1u << j;
       a_base[j] = 0; a_hi0[j] = 0; a_wi0[j] = 0;
     } else {
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(GEMM_THREADS, (DBUF || !FAST) ? 2 : 3) void conv_ge
     if (FAST) {
       cur_c = kv;
       a_ok_mask = kok ? row_ok : 0u;
-      const int koff = kok ? kt * BK : 0;
+      const int koff = kok ? kv : 0;  // (a k range that does not exist reads the row start)
 #pragma unroll
       for (int j = 0; j < RA; ++j) {
         ra[j] = ldg16(pa[j] + koff);  // (masked when staged)
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(GEMM_THREADS, (DBUF || !FAST) ? 2 : 3) void conv_ge
       for (int j = 0; j < RA; ++j) ra[j] = ldg16(X + off[j]);  // (masked when staged)
     }
     {
-      const int koff = kok ? kt * BK : 0;
+      const int koff = kok ? kv : 0;
 #pragma unroll
       for (int j = 0; j < RB; ++j) rbv[j] = ldg16(pb[j] + koff);
       b_ok_mask = kok ? col_ok : 0u;
