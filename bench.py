@@ -245,10 +245,9 @@ def main():
     params = [{"params": model.parameters(), "lr": cfg.SOLVER.LR}]
     sgd = dict(lr=cfg.SOLVER.LR, momentum=cfg.SOLVER.MOMENTUM,
                weight_decay=cfg.SOLVER.WEIGHT_DECAY)  # solver/optimizer.py:45-66
-    try:  # torch's single-kernel multi-tensor SGD (same update rule; 27 launches -> a few)
-        opt = torch.optim.SGD(params, fused=True, **sgd)
-    except (TypeError, RuntimeError, ValueError):
-        opt = torch.optim.SGD(params, **sgd)
+    # the reference's optimizer (solver/optimizer.py:45-50) on the multi-tensor HIP kernel
+    from segmentron_amd.solver.optimizer import FusedSGD
+    opt = FusedSGD(params, **sgd)
 
     g = torch.Generator().manual_seed(rank)
     images = torch.randn(BATCH, 3, args.height, args.width, generator=g).to(dev)

@@ -259,6 +259,17 @@ int seg_upsample_ce_bwd(int dtype, const void* lo, long ld, int N, int Hi, int W
                         const float* loss_out, const float* grad_out, void* dlo, long lddlo,
                         void* stream);
 
+/* ---- torch.optim.SGD(momentum, weight_decay) step over many tensors -------------------------
+ * Replaces the optimizer the reference builds in segmentron/solver/optimizer.py:45-50 (dampening
+ * 0, no Nesterov): d = g + wd*p; m = first ? d : momentum*m + d; p -= lr*m, fp32.
+ * params / grads / bufs: HOST arrays of ntensors device pointers; numel / group: host arrays;
+ * lr_dev / wd_dev: DEVICE float arrays indexed by parameter group (a captured graph of the step
+ * follows the LR schedule: the host rewrites these floats between replays). */
+int seg_sgd_multi_tensor(int ntensors, const void* const* params, const void* const* grads,
+                         const void* const* bufs, const long* numel, const int* group,
+                         const float* lr_dev, const float* wd_dev, float momentum, int first,
+                         void* stream);
+
 #ifdef __cplusplus
 }
 #endif

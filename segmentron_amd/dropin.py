@@ -28,7 +28,7 @@ SHIM_DIR = os.path.join(_PKG_DIR, "shims")
 
 # modules of segmentron_amd with no reference counterpart (never aliased)
 _PRIVATE = {"_lib", "hip_ops", "functional", "parallel", "dropin", "shims", "torch_ops", "graph",
-            "csrc", "solver"}
+            "csrc"}
 # reference packages that replace our minimal stand-ins when the reference tree is available:
 # segmentron_amd.data.dataloader only carries the NUM_CLASS table the model constructors read
 _PREFER_REFERENCE = ("data",)

@@ -561,3 +561,25 @@ def upsample_ce_bwd(lo, target, out_hw, ignore_index, loss_out, grad_out, pitch,
              _p(target.contiguous()), H, W, int(ignore_index), int(align_corners), _p(loss_out),
              _p(grad_out), _p(dlo), pitch, _stream())
     return dlo
+
+
+# ----------------------------------------------------------------------------- optimizer
+def sgd_multi_tensor(params, grads, bufs, groups, lr_dev, wd_dev, momentum, first):
+    """One fused SGD(momentum, weight decay) step over lists of fp32 device tensors
+    (csrc/optim.hip); `groups[i]` indexes the DEVICE float arrays lr_dev / wd_dev."""
+    import ctypes
+    n = len(params)
+    for p, g, b in zip(params, grads, bufs):
+        if not (p.is_cuda and g.is_cuda and b.is_cuda):
+            raise RuntimeError("segmentron_amd SGD needs HIP device tensors (no CPU fallback)")
+        if not (p.dtype == g.dtype == b.dtype == torch.float32):
+            raise RuntimeError("segmentron_amd SGD: parameters / gradients / buffers are fp32")
+        if not (p.is_contiguous() and g.is_contiguous() and b.is_contiguous()):
+            raise RuntimeError("segmentron_amd SGD: non-contiguous tensor")
+        if g.numel() != p.numel() or b.numel() != p.numel():
+            raise RuntimeError("segmentron_amd SGD: size mismatch")
+    vp = ctypes.c_void_p * n
+    LIB.call("seg_sgd_multi_tensor", n, vp(*[p.data_ptr() for p in params]),
+             vp(*[g.data_ptr() for g in grads]), vp(*[b.data_ptr() for b in bufs]),
+             (ctypes.c_long * n)(*[p.numel() for p in params]), (ctypes.c_int * n)(*groups),
+             _p(lr_dev), _p(wd_dev), float(momentum), int(bool(first)), _stream())
