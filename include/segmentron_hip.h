@@ -270,6 +270,19 @@ int seg_sgd_multi_tensor(int ntensors, const void* const* params, const void* co
                          const float* lr_dev, const float* wd_dev, float momentum, int first,
                          void* stream);
 
+/* ---- pixAcc / mIoU counters ------------------------------------------------------------------
+ * Replaces segmentron/utils/score.py:83-113 (batch_pix_accuracy: argmax of the logits TRUNCATED
+ * to integers; batch_intersection_union: argmax + three torch.histc on the CPU).  counters:
+ * int64 [2 + 3*nclass] = correct, labelled, inter[nclass], pred[nclass], lab[nclass], ACCUMULATED
+ * (zero them to start an evaluation).  _nchw takes fp32 NCHW logits; _upsample takes the
+ * network's low-resolution NHWC logits and applies the final bilinear resize on the fly with
+ * seg_upsample_to_nchw's arithmetic. */
+int seg_metric_update_nchw(const float* logits, int N, int C, int H, int W, const long* target,
+                           int nclass, long* counters, void* stream);
+int seg_metric_update_upsample(int dtype, const void* lo, long ld, int N, int Hi, int Wi, int C,
+                               const long* target, int H, int W, int align_corners, int nclass,
+                               long* counters, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -12,6 +12,7 @@ Host code here is plumbing (allocation, weight packing, torch.autograd, torch.di
 all arithmetic on activations is done by libsegmentron_hip.so.
 """
 import dataclasses
+import os
 import weakref
 
 import torch
@@ -817,6 +818,27 @@ def bilinear(act, out_hw, chan_mul=None, align_corners=True, out=None):
     spec = ResizeSpec(act, tuple(out_hw), chan_mul, align_corners, out)
     g, b = act.params
     return _BilinearFn.apply(act.t, g, b, spec)
+
+
+_LAZY_EVAL = [os.environ.get("SEG_LAZY_EVAL_LOGITS") == "1"]
+
+
+def lazy_eval_logits(enable=None):
+    """Evaluation-mode forwards return a LogitsView too (default off; SEG_LAZY_EVAL_LOGITS=1):
+    utils.score.SegmentationMetric then takes pixAcc / mIoU through the pending resize and the
+    [N, nclass, H, W] tensor is only materialised for consumers that really need it.  Returns
+    the previous setting; None only queries."""
+    prev = _LAZY_EVAL[0]
+    if enable is not None:
+        _LAZY_EVAL[0] = bool(enable)
+    return prev
+
+
+def want_lazy_logits(training):
+    """The rule every model's forward applies at its output boundary."""
+    if training:
+        return torch.is_grad_enabled()
+    return _LAZY_EVAL[0] and not torch.is_grad_enabled()
 
 
 def logits_to_nchw(x, out_hw, align_corners=True, lazy=False):

@@ -583,3 +583,39 @@ def sgd_multi_tensor(params, grads, bufs, groups, lr_dev, wd_dev, momentum, firs
              vp(*[g.data_ptr() for g in grads]), vp(*[b.data_ptr() for b in bufs]),
              (ctypes.c_long * n)(*[p.numel() for p in params]), (ctypes.c_int * n)(*groups),
              _p(lr_dev), _p(wd_dev), float(momentum), int(bool(first)), _stream())
+
+
+# ----------------------------------------------------------------------------- metrics
+def metric_counters(nclass, device):
+    """Zeroed int64 [2 + 3*nclass]: correct, labelled, inter[], pred[], lab[] (csrc/metric.hip)."""
+    return torch.zeros(2 + 3 * nclass, dtype=torch.int64, device=device)
+
+
+def metric_update_nchw(logits, target, nclass, counters):
+    """logits fp32 NCHW, target int64 [N,H,W]: accumulates score.py:83-113's counts."""
+    if not (logits.is_cuda and target.is_cuda and counters.is_cuda):
+        raise RuntimeError("segmentron_amd metrics need HIP device tensors (no CPU fallback)")
+    if logits.dtype != torch.float32 or not logits.is_contiguous():
+        logits = logits.float().contiguous()
+    if target.dtype != torch.int64 or not target.is_contiguous():
+        target = target.long().contiguous()
+    N, C, H, W = logits.shape
+    assert tuple(target.shape) == (N, H, W) and counters.numel() == 2 + 3 * nclass
+    LIB.call("seg_metric_update_nchw", _p(logits), N, C, H, W, _p(target), nclass, _p(counters),
+             _stream())
+    return counters
+
+
+def metric_update_upsample(lo, target, align_corners, nclass, counters):
+    """lo: NHWC logits [N,Hi,Wi,C]; the counts are taken on their bilinear upsample to the
+    target's [H, W] without materialising it."""
+    if not (lo.is_cuda and target.is_cuda and counters.is_cuda):
+        raise RuntimeError("segmentron_amd metrics need HIP device tensors (no CPU fallback)")
+    N, Hi, Wi, C, ld = nhwc(lo)
+    if target.dtype != torch.int64 or not target.is_contiguous():
+        target = target.long().contiguous()
+    assert target.shape[0] == N and counters.numel() == 2 + 3 * nclass
+    H, W = target.shape[1:]
+    LIB.call("seg_metric_update_upsample", _DT[lo.dtype], _p(lo), ld, N, Hi, Wi, C, _p(target), H,
+             W, int(bool(align_corners)), nclass, _p(counters), _stream())
+    return counters

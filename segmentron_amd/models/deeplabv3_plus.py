@@ -30,7 +30,7 @@ class DeepLabV3Plus(SegBaseModel):
 
     def forward(self, x):
         size = x.shape[2:]
-        lazy = self.training and torch.is_grad_enabled()  # see functional.LogitsView
+        lazy = F.want_lazy_logits(self.training)  # see functional.LogitsView
         c1, _, c3, c4 = self.encoder(x)
         y = self.head(c4, c1)  # NHWC logits at c1 resolution
         outputs = [F.logits_to_nchw(y, size, align_corners=True, lazy=lazy)]

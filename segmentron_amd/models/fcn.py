@@ -21,7 +21,7 @@ class FCN(SegBaseModel):
 
     def forward(self, x):
         size = x.shape[2:]
-        lazy = self.training and torch.is_grad_enabled()  # see functional.LogitsView
+        lazy = F.want_lazy_logits(self.training)  # see functional.LogitsView
         _, _, c3, c4 = self.base_forward(x)
         outputs = [F.logits_to_nchw(self.head(c4), size, align_corners=True, lazy=lazy)]
         if self.aux:

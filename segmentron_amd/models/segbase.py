@@ -62,12 +62,19 @@ class SegBaseModel(nn.Module):
                 # for the configs' square-ish crops, e.g. 1025x2049 around 1024x2048)
                 if padh or padw:
                     cur = TF.pad(cur, (0, padh, 0, padw))
-            out = self.forward(cur)[0][..., :height, :width]
+            out = _crop(self.forward(cur)[0], height, width)
             if flip:
-                out = out + self.forward(cur.flip(3))[0].flip(3)[..., :height, :width]
+                out = out + _crop(self.forward(cur.flip(3))[0].flip(3), height, width)
             score = _resize(out, h, w)
             scores = score if scores is None else scores + score
         return scores
+
+
+def _crop(out, h, w):
+    """out[..., :h, :w]; the identity keeps a pending LogitsView pending."""
+    if out.shape[2] == h and out.shape[3] == w:
+        return out
+    return out[..., :h, :w]
 
 
 def _resize(img, h, w):

@@ -367,3 +367,82 @@ def test_graphed_inference_and_train_step_equal_eager():
     assert la == lb
     for (k, p), (_, q) in zip(model.named_parameters(), twin.named_parameters()):
         assert torch.equal(p, q), k
+
+
+def _build_eval(extra):
+    import segmentron_amd
+    from segmentron_amd.config import cfg, reset_cfg
+    reset_cfg()
+    cfg.update_from_list(C3_OVERRIDES + extra)
+    cfg.PHASE = "test"
+    cfg.check_and_freeze()
+    segmentron_amd.set_compute_dtype(torch.float32)
+    model = segmentron_amd.get_segmentation_model()
+    sd = _state()
+    model.load_state_dict(sd, strict=True)
+    for _, m in model.encoder.named_modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.eps = 1e-3
+    return model.cuda().eval(), sd
+
+
+def test_evaluate_pipeline_multiscale_flip_pad_matches_oracle():
+    """SegBaseModel.evaluate end to end on the HIP path — two scales, flip, a crop
+    size that forces zero padding — against the same glue (pinned to the reference's own method
+    by tests/test_host_api.py::test_evaluate_glue_matches_the_reference_fixture) around the CPU
+    oracle's forward.  Bar: 1e-3 of the score scale, identical arg-max except at oracle ties."""
+    from segmentron_amd.models.segbase import SegBaseModel
+    model, sd = _build_eval(["TEST.SCALES", "[0.75, 1.0]", "TEST.FLIP", "True",
+                             "TEST.CROP_SIZE", "(81, 145)"])
+    x = synth.synth_images(1, 65, 129, seed=3)
+    with torch.no_grad():
+        got = model.evaluate(x.cuda()).cpu()
+
+    net = torch_ref.OracleNet({k: v.clone() for k, v in sd.items()}, training=False,
+                              eps_encoder=1e-3)
+
+    class Oracle:
+        def forward(self, img):
+            return tuple(net.deeplabv3_plus_xception65(img))
+
+    torch.set_num_threads(min(16, os.cpu_count()))
+    with torch.no_grad():
+        ref = SegBaseModel.evaluate(Oracle(), x)
+    assert tuple(got.shape) == tuple(ref.shape) == (1, 19, 65, 129)
+    rel = _rel(got, ref)
+    bad = got.argmax(1) != ref.argmax(1)
+    top2 = ref.topk(2, dim=1).values
+    gap = (top2[:, 0] - top2[:, 1])[bad]
+    print("evaluate(): max-rel %.3e, argmax mismatches %d (largest oracle top-2 gap %.2e)"
+          % (rel, int(bad.sum()), gap.max().item() if gap.numel() else 0.0))
+    assert rel < 1e-3
+    assert gap.numel() == 0 or gap.max().item() < 1e-3 * ref.abs().max().item()
+
+
+def test_lazy_eval_logits_feed_the_fused_metric():
+    """SEG_LAZY_EVAL_LOGITS / functional.lazy_eval_logits: evaluate() hands the pending
+    LogitsView through and SegmentationMetric counts through the resize — same counters as on
+    the materialised tensor."""
+    from segmentron_amd import functional as F
+    from segmentron_amd.utils.score import SegmentationMetric
+    model, _ = _build_eval(["TEST.CROP_SIZE", "None"])
+    x = synth.synth_images(2, 65, 129, seed=4).cuda()
+    y = synth.synth_targets(2, 65, 129, seed=4).cuda()
+    prev = F.lazy_eval_logits(True)
+    try:
+        with torch.no_grad():
+            view = model.evaluate(x)
+        assert isinstance(view, F.LogitsView) and view._full is None
+        m1 = SegmentationMetric(19, False)
+        m1.update(view, y)
+        assert view._full is None
+    finally:
+        F.lazy_eval_logits(prev)
+    with torch.no_grad():
+        full = model.evaluate(x)
+    assert isinstance(full, torch.Tensor)
+    m2 = SegmentationMetric(19, False)
+    m2.update(full, y)
+    assert torch.equal(m1._cnt, m2._cnt)
+    assert m1.get() == m2.get()
+    assert torch.equal(view.materialize(), full)
