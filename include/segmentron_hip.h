@@ -283,6 +283,24 @@ int seg_metric_update_upsample(int dtype, const void* lo, long ld, int N, int Hi
                                const long* target, int H, int W, int align_corners, int nclass,
                                long* counters, void* stream);
 
+/* ---- criss-cross attention (CCNet) ------------------------------------------------------------
+ * Replaces the reference's CUDA extension segmentron/modules/csrc/criss_cross_attention/
+ * ca_cuda.cu:8-177 (+ the softmax of cc_attention.py:66), NHWC.  Entry z of pixel (y, x):
+ * z < W -> (y, z); else i = z - W, (i < y ? i : i + 1, x).  L = W + H - 1 <= 512.
+ * att / de: fp32 [N, H, W, L].
+ *   seg_cca_attention     : att = softmax_z(q[p] . k[partner(p, z)])
+ *   seg_cca_map           : out = gamma * sum_z w b[partner] (+ res); transposed = 1 sums over
+ *                           the pixels attending TO p (dv, dk); raw (nullable) = the plain sum
+ *   seg_cca_attention_bwd : de = softmax backward of dA = scale * dout[p] . v[partner(p, z)] */
+int seg_cca_attention(int dtype, const void* q, long ldq, const void* k, long ldk, int N, int H,
+                      int W, int C, float* att, void* stream);
+int seg_cca_attention_bwd(int dtype, const void* dout, long lddo, const void* v, long ldv, int N,
+                          int H, int W, int C, const float* att, const float* scale, float* de,
+                          void* stream);
+int seg_cca_map(int dtype, const float* wt, const void* b, long ldb, int N, int H, int W, int C,
+                int transposed, const float* gamma, const void* res, long ldres, void* out,
+                long ldo, void* raw, long ldraw, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -5,6 +5,7 @@
     python oracle/gen_golden_more.py c4     # PSPNet resnet101 (OS8, aux)    -> tests/golden/c4_*
     python oracle/gen_golden_more.py c2     # DeepLabv3+ mobilenet_v2        -> tests/golden/c2_*
     python oracle/gen_golden_more.py c5     # HRNet hrnet_w18_small_v1       -> tests/golden/c5_*
+    python oracle/gen_golden_more.py c6     # CCNet resnet101 (stubbed _C)   -> tests/golden/c6_*
 
 One process per model (the reference cfg singleton freezes).  C1 / C4 use resnet101, the
 backbone BASELINE.md names (BASELINE C1 as written, "FCN-resnet18", cannot run in the reference:
@@ -37,12 +38,46 @@ CASES = {
     # HRNet needs H, W divisible by 32 (nearest x2 upsamples must meet the stride-2 conv sizes)
     "c5": dict(yaml="configs/cityscapes_hrnet_w18_small_v1.yaml", over=[], fn="hrnet_seg", os=16,
                aux=False, hw=(64, 128), eps_enc=None, mom=0.01),
+    # CCNet: the model is disabled in the reference (models/__init__.py:11) because its CUDA
+    # extension `segmentron._C` is not built; a stub `_C` backed by oracle.torch_ref's restatement
+    # of ca_cuda.cu lets the REFERENCE's own module tree / wiring / autograd glue run on the CPU
+    "c6": dict(yaml="configs/cityscapes_ccnet_resnet.yaml", over=[], fn="ccnet_resnet", os=16,
+               aux=False, hw=(65, 97), eps_enc=None, pre="ccnet"),
 }
+
+
+def _install_ccnet():
+    """segmentron._C stand-in (ca.h:25-73 entry points) + explicit import of models.ccnet."""
+    import types
+    from oracle import ref_import as ri
+    ri._install_stubs()
+    if ri.REFERENCE_ROOT not in sys.path:
+        sys.path.insert(0, ri.REFERENCE_ROOT)
+    import segmentron
+    assert segmentron.__file__.startswith(ri.REFERENCE_ROOT)
+    C = types.ModuleType("segmentron._C")
+
+    def _grads(fn, args, dout):
+        leaves = [a.detach().requires_grad_(True) for a in args]
+        with torch.enable_grad():
+            out = fn(*leaves)
+        return torch.autograd.grad(out, leaves, dout)
+
+    C.ca_forward = lambda t, f: torch_ref.cca_weight(t, f)
+    C.ca_backward = lambda dw, t, f: _grads(torch_ref.cca_weight, (t, f), dw)
+    C.ca_map_forward = lambda w, g: torch_ref.cca_map(w, g)
+    C.ca_map_backward = lambda dout, w, g: _grads(torch_ref.cca_map, (w, g), dout)
+    sys.modules["segmentron._C"] = C
+    segmentron._C = C
+    import segmentron.models.ccnet  # noqa: F401  (registers CCNet in MODEL_REGISTRY)
+
 
 
 def main(tag):
     c = CASES[tag]
     torch.set_num_threads(min(16, os.cpu_count()))
+    if c.get("pre") == "ccnet":
+        _install_ccnet()
     model, cfg = ref_import.build_reference_model(c["yaml"], c["over"])
     ref_import.apply_bn_attrs(model, cfg)
     sd0 = model.state_dict()

@@ -444,6 +444,109 @@ OracleNet.fcn_resnet = _fcn_resnet
 OracleNet.pspnet_resnet = _pspnet_resnet
 
 
+# ---------------------------------------------------------------------------------------------
+# Criss-cross attention (CCNet).  The reference computes these with its CUDA extension
+# (segmentron/modules/csrc/criss_cross_attention/ca_cuda.cu), which cannot be built here (CUDA);
+# `cca_weight` / `cca_map` restate the forward kernels with tensor algebra (their backward kernels,
+# ca_cuda.cu:39-94 and :125-177, are the analytic gradients — autograd supplies them), and
+# `cca_weight_loops` / `cca_map_loops` follow the kernel source statement by statement (pure
+# Python, small cases only) to pin the algebra: tests/test_cca.py.
+def _cca_col_index(H, device):
+    """idx[y, i] = i < y ? i : i + 1   (ca_cuda.cu:27-28): the column partner of entry W + i."""
+    y = torch.arange(H, device=device).view(H, 1)
+    i = torch.arange(H - 1, device=device).view(1, H - 1)
+    return torch.where(i < y, i, i + 1)
+
+
+def cca_weight(t, f):
+    """ca_forward_kernel, ca_cuda.cu:8-37.  t, f: [N, C, H, W] -> energy [N, W + H - 1, H, W]."""
+    N, C, H, W = t.shape
+    row = torch.einsum("ncyx,ncyi->niyx", t, f)                 # z < W : f at (y, z)
+    full = torch.einsum("ncyx,ncjx->nyxj", t, f)                # f at (j, x) for every j
+    idx = _cca_col_index(H, t.device)                           # [H, H-1]
+    col = torch.gather(full, 3, idx.view(1, H, 1, H - 1).expand(N, H, W, H - 1))
+    return torch.cat([row, col.permute(0, 3, 1, 2)], dim=1)
+
+
+def cca_map(weight, g):
+    """ca_map_forward_kernel, ca_cuda.cu:96-123.  weight [N, W+H-1, H, W], g [N, C, H, W]."""
+    N, C, H, W = g.shape
+    out = torch.einsum("ncyi,niyx->ncyx", g, weight[:, :W])
+    idx = _cca_col_index(H, g.device)
+    wcol = weight[:, W:].permute(0, 2, 3, 1)                    # [N, y, x, i']
+    full = torch.zeros(N, H, W, H, dtype=weight.dtype, device=weight.device)
+    full = full.scatter(3, idx.view(1, H, 1, H - 1).expand(N, H, W, H - 1), wcol)  # [n,y,x,i]
+    return out + torch.einsum("ncix,nyxi->ncyx", g, full)
+
+
+def cca_weight_loops(t, f):
+    N, C, H, W = t.shape
+    L = H + W - 1
+    w = torch.zeros(N, L, H, W, dtype=t.dtype)
+    for b in range(N):
+        for y in range(H):
+            for x in range(W):
+                for z in range(L):
+                    for pl in range(C):
+                        _t = t[b, pl, y, x]
+                        if z < W:
+                            w[b, z, y, x] += _t * f[b, pl, y, z]
+                        else:
+                            i = z - W
+                            j = i if i < y else i + 1
+                            w[b, W + i, y, x] += _t * f[b, pl, j, x]
+    return w
+
+
+def cca_map_loops(weight, g):
+    N, C, H, W = g.shape
+    out = torch.zeros_like(g)
+    for b in range(N):
+        for pl in range(C):
+            for y in range(H):
+                for x in range(W):
+                    for i in range(W):
+                        out[b, pl, y, x] += g[b, pl, y, i] * weight[b, i, y, x]
+                    for i in range(H):
+                        if i == y:
+                            continue
+                        j = i if i < y else i - 1
+                        out[b, pl, y, x] += g[b, pl, i, x] * weight[b, W + j, y, x]
+    return out
+
+
+def _criss_cross_attention(self, x, p):
+    """CrissCrossAttention.forward — segmentron/modules/cc_attention.py:60-72."""
+    q = self.conv(x, p + ".query_conv")
+    k = self.conv(x, p + ".key_conv")
+    v = self.conv(x, p + ".value_conv")
+    att = F.softmax(cca_weight(q, k), 1)
+    return self.sd[p + ".gamma"] * cca_map(att, v) + x
+
+
+def _ccnet_resnet(self, x, recurrence=2):
+    """CCNet.forward + _CCHead + _RCCAModule — segmentron/models/ccnet.py:28-86."""
+    size = x.shape[2:]
+    _, _, c3, c4 = _resnet(self, x)
+    p = "head.rcca."
+    out = F.relu(self.bn(self.conv(c4, p + "conva.0", 1, 1), p + "conva.1"))
+    for _ in range(recurrence):
+        out = _criss_cross_attention(self, out, p + "cca")
+    out = F.relu(self.bn(self.conv(out, p + "convb.0", 1, 1), p + "convb.1"))
+    out = torch.cat([c4, out], dim=1)
+    out = self.bn(self.conv(out, p + "bottleneck.0", 1, 1), p + "bottleneck.1")
+    out = F.dropout2d(out, self.drop_p, self.training)
+    out = self.conv(out, "head.out")
+    outs = [F.interpolate(out, size, mode="bilinear", align_corners=True)]
+    if self.aux:
+        outs.append(F.interpolate(self.fcn_head(c3, "auxlayer"), size, mode="bilinear",
+                                  align_corners=True))
+    return tuple(outs)
+
+
+OracleNet.ccnet_resnet = _ccnet_resnet
+
+
 def mix_softmax_ce(outputs, target, aux_weight=0.4, ignore_index=-1):
     """MixSoftmaxCrossEntropyLoss — segmentron/solver/loss.py:16-46 (sum of per-output CE,
     aux outputs weighted by cfg.SOLVER.AUX_WEIGHT)."""

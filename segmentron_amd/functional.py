@@ -748,6 +748,44 @@ class _CatFn(torch.autograd.Function):
         return (None,) + tuple(outs)
 
 
+class _CCAFn(torch.autograd.Function):
+    """Criss-cross attention of one recurrence (cc_attention.py:60-72):
+        out = gamma * sum_z softmax_z(q . k[partner])_z * v[partner] + x
+    q/k [N,H,W,C/8], v/x [N,H,W,C], plain NHWC tensors; gamma the module's [1] parameter (read on
+    the device).  The energies never reach HBM (softmax inside the kernel); backward re-derives
+    dA in the same fused way (csrc/cca.hip)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, x, gamma):
+        g32 = gamma.detach().float().contiguous()
+        att = K.cca_attention(q, k)
+        out, raw = K.cca_map(att, v, gamma=g32, res=x, want_raw=True)
+        ctx.save_for_backward(q, k, v, att, raw, g32)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, att, raw, g32 = ctx.saved_tensors
+        if K.nhwc(dout)[4] % K.vec_of(dout.dtype) != 0 or not dout.is_contiguous():
+            dout = dout.contiguous()
+        dq = dk = dv = dx = dgamma = None
+        # d gamma = <dout, raw>
+        if ctx.needs_input_grad[4]:
+            sums = K.bn_bwd_reduce(dout, raw, (PRO_NONE, None, None))
+            C = dout.shape[-1]
+            dgamma = sums[C:2 * C].sum().float().view(1)
+        de = K.cca_attention_bwd(dout, v, att, g32)
+        if ctx.needs_input_grad[2]:
+            dv = K.cca_map(att, dout, transposed=True, gamma=g32)
+        if ctx.needs_input_grad[0]:
+            dq = K.cca_map(de, k)
+        if ctx.needs_input_grad[1]:
+            dk = K.cca_map(de, q, transposed=True)
+        if ctx.needs_input_grad[3]:
+            dx = dout
+        return dq, dk, dv, dx, dgamma
+
+
 # ----------------------------------------------------------------------------- functional API
 def conv_bn(act, conv, bn=None, out=None):
     """conv (nn.Conv2d, groups=1) [+ BatchNorm statistics].  Returns an Act whose BN (if any) and
@@ -821,6 +859,11 @@ def bilinear(act, out_hw, chan_mul=None, align_corners=True, out=None):
 
 
 _LAZY_EVAL = [os.environ.get("SEG_LAZY_EVAL_LOGITS") == "1"]
+
+
+def criss_cross_attention(q, k, v, x, gamma):
+    """Plain NHWC tensors -> gamma * CCA(q, k, v) + x (one recurrence of RCCA)."""
+    return _CCAFn.apply(q, k, v, x, gamma)
 
 
 def lazy_eval_logits(enable=None):

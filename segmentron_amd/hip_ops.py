@@ -619,3 +619,36 @@ def metric_update_upsample(lo, target, align_corners, nclass, counters):
     LIB.call("seg_metric_update_upsample", _DT[lo.dtype], _p(lo), ld, N, Hi, Wi, C, _p(target), H,
              W, int(bool(align_corners)), nclass, _p(counters), _stream())
     return counters
+
+
+# ----------------------------------------------------------------------------- criss-cross attention
+def cca_attention(q, k):
+    """q, k NHWC [N,H,W,C'] -> fp32 attention [N,H,W,W+H-1] = softmax over the criss-cross set."""
+    N, H, W, C, ldq = nhwc(q)
+    ldk = nhwc(k)[4]
+    att = torch.empty((N, H, W, H + W - 1), dtype=torch.float32, device=q.device)
+    LIB.call("seg_cca_attention", _DT[q.dtype], _p(q), ldq, _p(k), ldk, N, H, W, C, _p(att),
+             _stream())
+    return att
+
+
+def cca_attention_bwd(dout, v, att, scale=None):
+    """dE (fp32, like att): softmax backward of dA = scale * dout . v[partner]."""
+    N, H, W, C, lddo = nhwc(dout)
+    ldv = nhwc(v)[4]
+    de = torch.empty_like(att)
+    LIB.call("seg_cca_attention_bwd", _DT[v.dtype], _p(dout), lddo, _p(v), ldv, N, H, W, C,
+             _p(att), _p(scale), _p(de), _stream())
+    return de
+
+
+def cca_map(wt, b, transposed=False, gamma=None, res=None, want_raw=False):
+    """out[p] = gamma * sum_z wt(p, z) * b[partner(p, z)] (+ res[p]); transposed: summed over the
+    pixels attending TO p.  -> out, or (out, raw sum) with want_raw."""
+    N, H, W, C, ldb = nhwc(b)
+    out = torch.empty((N, H, W, C), dtype=b.dtype, device=b.device)
+    raw = torch.empty_like(out) if want_raw else None
+    ldres = nhwc(res)[4] if res is not None else 0
+    LIB.call("seg_cca_map", _DT[b.dtype], _p(wt), _p(b), ldb, N, H, W, C, int(bool(transposed)),
+             _p(gamma), _p(res), ldres, _p(out), C, _p(raw), C, _stream())
+    return (out, raw) if want_raw else out

@@ -4,3 +4,4 @@ from .deeplabv3_plus import DeepLabV3Plus  # noqa: F401
 from .fcn import FCN  # noqa: F401
 from .pspnet import PSPNet  # noqa: F401
 from .hrnet_seg import HighResolutionNet  # noqa: F401
+from .ccnet import CCNet  # noqa: F401

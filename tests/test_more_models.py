@@ -25,6 +25,10 @@ CASES = {
     "c5": dict(model="HRNet", backbone="hrnet_w18_small_v1", os=16, aux=False, fn="hrnet_seg",
                hw=(64, 128), aux_weight=0.4, momentum=0.01, tie_delta=1e-5,
                yaml="configs/cityscapes_hrnet_w18_small_v1.yaml"),
+    # CCNet: fixtures from the reference's own module tree with the CUDA extension
+    # stood in by the oracle's restatement of ca_cuda.cu (oracle/gen_golden_more.py c6)
+    "c6": dict(model="CCNet", backbone="resnet101", os=16, aux=False, fn="ccnet_resnet",
+               hw=(65, 97), aux_weight=0.4),
 }
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
