@@ -14,6 +14,8 @@ layouts — the same conventions as the C-ABI (include/segmentron_hip.h).
     y  = torch.ops.segmentron_hip.interpolate_bilinear(x, out_h, out_w, align_corners)
     lo = torch.ops.segmentron_hip.upsample_cross_entropy(logits, target, out_h, out_w,
                                                          ignore_index, align_corners)   # [2]
+    out, att, raw = torch.ops.segmentron_hip.criss_cross_attention(q, k, v, x, gamma)
+    cnt = torch.ops.segmentron_hip.segmentation_counts(logits_nchw, target, nclass)
 
 The module tree (segmentron_amd.modules / .models) drives the same C-ABI wrappers
 (segmentron_amd.hip_ops) directly through its deferred-BatchNorm autograd layer
@@ -278,6 +280,74 @@ def _uce_bwd(ctx, g):
 
 upsample_cross_entropy.register_autograd(_uce_bwd, setup_context=_uce_setup)
 
+# ----------------------------------------------------------------------------- criss-cross attention
+@torch.library.custom_op(_NS + "::criss_cross_attention", mutates_args=())
+def criss_cross_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, x: torch.Tensor,
+                          gamma: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """gamma * CCA(q, k, v) + x on NHWC tensors (cc_attention.py:60-72).  -> (out, attention
+    fp32 [N,H,W,W+H-1], un-scaled aggregation) — the last two are what backward needs."""
+    g32 = gamma.detach().float().contiguous()
+    att = K.cca_attention(q, k)
+    out, raw = K.cca_map(att, v, gamma=g32, res=x, want_raw=True)
+    return out, att, raw
+
+
+@criss_cross_attention.register_fake
+def _(q, k, v, x, gamma):
+    N, H, W, _ = v.shape
+    return (v.new_empty(v.shape), v.new_empty((N, H, W, H + W - 1), dtype=torch.float32),
+            v.new_empty(v.shape))
+
+
+@torch.library.custom_op(_NS + "::criss_cross_attention_backward", mutates_args=())
+def criss_cross_attention_backward(dout: torch.Tensor, q: torch.Tensor, k: torch.Tensor,
+                                   v: torch.Tensor, att: torch.Tensor, raw: torch.Tensor,
+                                   gamma: torch.Tensor
+                                   ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+    """-> (dq, dk, dv, dgamma[1]); dx is dout itself."""
+    g32 = gamma.detach().float().contiguous()
+    dout = dout.contiguous()
+    C = dout.shape[-1]
+    dgamma = K.bn_bwd_reduce(dout, raw, (K.PRO_NONE, None, None))[C:2 * C].sum().float().view(1)
+    de = K.cca_attention_bwd(dout, v, att, g32)
+    return (K.cca_map(de, k), K.cca_map(de, q, transposed=True),
+            K.cca_map(att, dout, transposed=True, gamma=g32), dgamma)
+
+
+@criss_cross_attention_backward.register_fake
+def _(dout, q, k, v, att, raw, gamma):
+    return (q.new_empty(q.shape), k.new_empty(k.shape), v.new_empty(v.shape),
+            gamma.new_empty((1,), dtype=torch.float32))
+
+
+def _cca_setup(ctx, inputs, output):
+    q, k, v, x, gamma = inputs
+    ctx.save_for_backward(q, k, v, output[1], output[2], gamma)
+
+
+def _cca_bwd(ctx, dout, datt, draw):
+    q, k, v, att, raw, gamma = ctx.saved_tensors
+    dq, dk, dv, dg = criss_cross_attention_backward(dout, q, k, v, att, raw, gamma)
+    return dq, dk, dv, dout, dg.to(gamma.dtype)
+
+
+criss_cross_attention.register_autograd(_cca_bwd, setup_context=_cca_setup)
+
+
+# ----------------------------------------------------------------------------- metric counters
+@torch.library.custom_op(_NS + "::segmentation_counts", mutates_args=())
+def segmentation_counts(logits: torch.Tensor, target: torch.Tensor, nclass: int) -> torch.Tensor:
+    """pixAcc / mIoU counts of fp32 NCHW logits (utils/score.py:83-113) -> int64 [2 + 3*nclass]:
+    correct, labelled, inter[], pred[], lab[]."""
+    return K.metric_update_nchw(logits, target, nclass, K.metric_counters(nclass, logits.device))
+
+
+@segmentation_counts.register_fake
+def _(logits, target, nclass):
+    return logits.new_empty((2 + 3 * nclass,), dtype=torch.int64)
+
+
 OPS = ("conv2d", "conv2d_backward", "depthwise_conv3x3", "depthwise_conv3x3_backward",
        "interpolate_bilinear", "interpolate_bilinear_backward", "upsample_cross_entropy",
-       "upsample_cross_entropy_backward")
+       "upsample_cross_entropy_backward", "criss_cross_attention",
+       "criss_cross_attention_backward", "segmentation_counts")

@@ -223,3 +223,14 @@ def test_torch_custom_ops_are_registered_with_fake_implementations():
         t = torch.empty(2, 1025, 2049, dtype=torch.long, device="cuda")
         out = ns.upsample_cross_entropy(lo, t, 1025, 2049, -1, True)
         assert tuple(out.shape) == (2,) and out.dtype == torch.float32
+        q = torch.empty(2, 49, 49, 64, dtype=torch.bfloat16, device="cuda")
+        v = torch.empty(2, 49, 49, 512, dtype=torch.bfloat16, device="cuda")
+        gam = torch.empty(1, device="cuda")
+        o, att, raw = ns.criss_cross_attention(q, q, v, v, gam)
+        assert tuple(o.shape) == tuple(v.shape) and tuple(att.shape) == (2, 49, 49, 97)
+        assert att.dtype == torch.float32 and raw.dtype == torch.bfloat16
+        dq, dk, dv, dg = ns.criss_cross_attention_backward(o, q, q, v, att, raw, gam)
+        assert tuple(dq.shape) == tuple(q.shape) and tuple(dv.shape) == tuple(v.shape)
+        cnt = ns.segmentation_counts(torch.empty(2, 19, 65, 129, device="cuda"),
+                                     torch.empty(2, 65, 129, dtype=torch.long, device="cuda"), 19)
+        assert tuple(cnt.shape) == (59,) and cnt.dtype == torch.int64

@@ -95,3 +95,32 @@ def test_opcheck_schema_fake_and_autograd_registration():
     lo = to_dev_nhwc(rnd((1, 19, 5, 7), 4), torch.float32, pitch=24, off=0).requires_grad_()
     t = torch.randint(0, 19, (1, 17, 25), device=DEV)
     opcheck(NS.upsample_cross_entropy.default, (lo, t, 17, 25, -1, True), test_utils=utils)
+
+
+def test_criss_cross_attention_op_matches_functional_and_gradcheck_shapes():
+    """torch.ops.segmentron_hip.criss_cross_attention == functional.criss_cross_attention
+    (same kernels), forward and every gradient."""
+    from segmentron_amd import functional as F
+    g = torch.Generator().manual_seed(2)
+    mk = lambda c: torch.randn(2, 11, 14, c, generator=g).cuda()
+    base = [mk(8), mk(8), mk(64), mk(64), torch.tensor([0.6]).cuda()]
+    dout = mk(64)
+    res = []
+    for fn in (lambda *a: NS.criss_cross_attention(*a)[0], F.criss_cross_attention):
+        ins = [t.clone().requires_grad_() for t in base]
+        out = fn(*ins)
+        out.backward(dout)
+        res.append([out.detach()] + [t.grad for t in ins])
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+
+
+def test_segmentation_counts_op():
+    g = torch.Generator().manual_seed(3)
+    logits = (torch.randn(2, 7, 33, 41, generator=g) * 3).cuda()
+    tgt = torch.randint(-1, 7, (2, 33, 41), generator=g).cuda()
+    cnt = NS.segmentation_counts(logits, tgt, 7).cpu()
+    pred = logits.argmax(1).cpu()
+    t = tgt.cpu()
+    assert int(cnt[1]) == int((t >= 0).sum())
+    assert int(cnt[2:9].sum()) == int(((pred == t) & (t >= 0)).sum())
