@@ -259,6 +259,17 @@ int seg_upsample_ce_bwd(int dtype, const void* lo, long ld, int N, int Hi, int W
                         const float* loss_out, const float* grad_out, void* dlo, long lddlo,
                         void* stream);
 
+/* ---- stride-2 depthwise 3x3 (padding 1, dilation 1): fused backward --------------------------
+ * One pass over dy [N,(H+1)/2,(W+1)/2,C] and x [N,H,W,C] (+ prologue): g = masked data gradient,
+ * partial_w [grid_y][9][C] (reduce with seg_dwconv3x3_wgrad_finalize), partial_bn [grid_y][2][C]
+ * (nullable) = (sum g, sum g*x_raw).  w_c9: torch's [C,1,3,3] fp32.  grid_y from
+ * seg_dwconv3x3_s2_grid_y. */
+int seg_dwconv3x3_s2_grid_y(int C, int N, int H, int W);
+int seg_dwconv3x3_s2_bwd_fused(int dtype, const void* dy, long lddy, const void* x, long ldx, int N,
+                               int H, int W, int C, const float* w_c9, int pro_mode,
+                               const float* pro_scale, const float* pro_shift, void* g, long ldg,
+                               float* partial_w, float* partial_bn, int grid_y, void* stream);
+
 /* ---- torch.optim.SGD(momentum, weight_decay) step over many tensors -------------------------
  * Replaces the optimizer the reference builds in segmentron/solver/optimizer.py:45-50 (dampening
  * 0, no Nesterov): d = g + wd*p; m = first ? d : momentum*m + d; p -= lr*m, fp32.

@@ -392,11 +392,16 @@ class _DwFn(torch.autograd.Function):
         dx = dgamma = dbeta = None
         tiled = K.dw_tiled(s.stride, s.dil)
         big = x.numel() * x.element_size() >= (40 << 20)
-        if s.stride == 1 and ctx.needs_input_grad[0] and (tiled or big):
+        strided = s.stride == 2 and s.dil == 1 and C % 4 == 0 and weight.dtype == torch.float32
+        if ctx.needs_input_grad[0] and ((s.stride == 1 and (tiled or big)) or strided):
             # one pass over (dy, x): masked data gradient + weight-gradient partials + BN sums
-            # (LDS-tiled for dil <= 2; the strip version only pays on large tensors)
+            # (LDS-tiled for dil <= 2; the strip version only pays on large tensors; stride 2 on
+            # its own kernel, csrc/dwconv_s2.hip)
             bn = s.bn_in
-            if tiled:
+            if strided:
+                g, dW, pb = K.dwconv_bwd_fused_s2(x, dy, weight.detach().contiguous(), s.pro,
+                                                  want_bn=bn is not None)
+            elif tiled:
                 g, dW, pb = K.dwconv_bwd_fused(x, dy, weight.detach(), s.dil, s.pro,
                                                want_bn=bn is not None, torch_layout=True)
             else:

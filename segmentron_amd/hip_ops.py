@@ -235,6 +235,25 @@ def dwconv_bwd_fused(x, dy, w, dil, pro=None, want_bn=False, torch_layout=False)
     return g, colsum(pw, f64=False).view(9, C), pb
 
 
+def dwconv_bwd_fused_s2(x, dy, w, pro=None, want_bn=False):
+    """stride-2 (pad 1, dil 1) depthwise backward in one pass over dy and x: returns (g masked by
+    the prologue's ReLU, dW fp32 [C,1,3,3], bn_partial fp32 [gy, 2C] | None).  w: the [C,1,3,3]
+    parameter."""
+    N, H, W, C, ldx = nhwc(x)
+    Nd, Ho, Wo, Cd, lddy = nhwc(dy)
+    assert (Nd, Ho, Wo, Cd) == (N, (H + 1) // 2, (W + 1) // 2, C) and tuple(w.shape) == (C, 1, 3, 3)
+    mode, ps, pt = _pro(pro)
+    g = torch.empty((N, H, W, C), dtype=x.dtype, device=x.device)
+    gy = LIB.query("seg_dwconv3x3_s2_grid_y", C, N, H, W)
+    pw = torch.empty((gy, 9 * C), dtype=torch.float32, device=x.device)
+    pb = torch.empty((gy, 2 * C), dtype=torch.float32, device=x.device) if want_bn else None
+    LIB.call("seg_dwconv3x3_s2_bwd_fused", _DT[x.dtype], _p(dy), lddy, _p(x), ldx, N, H, W, C,
+             _p(w), mode, _p(ps), _p(pt), _p(g), C, _p(pw), _p(pb), gy, _stream())
+    dW = torch.empty((C, 1, 3, 3), dtype=torch.float32, device=x.device)
+    LIB.call("seg_dwconv3x3_wgrad_finalize", _p(pw), gy, C, _p(dW), _stream())
+    return g, dW, pb
+
+
 def dwconv_wgrad(x, dy, stride, dil, pro=None, torch_layout=False):
     """-> fp32 [9, C], or with torch_layout the parameter's own [C, 1, 3, 3]."""
     N, Hi, Wi, C, ldx = nhwc(x)

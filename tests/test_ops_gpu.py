@@ -29,6 +29,8 @@ def _act_ref(x, mode, scale, shift):
         x = x * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
     if mode & 1:
         x = torch.relu(x)
+    if mode & 4:  # ReLU6
+        x = x.clamp(max=6.0)
     return x
 
 
@@ -186,6 +188,12 @@ DW_CASES = [
     (1, 40, 44, 256, 1, 18, 2),     # ASPP rate 18 (OS16, module.py:39-41)
     (2, 50, 52, 128, 1, 24, 3),     # ASPP rates 24 / 36 (OS8)
     (1, 75, 80, 64, 1, 36, 0),
+    # stride 2 (fused one-pass backward, csrc/dwconv_s2.hip): odd / even sizes, ragged tiles,
+    # ReLU6 prologue (MobileNetV2), several tiles per persistent block
+    (1, 40, 37, 64, 2, 1, 1),
+    (2, 16, 32, 256, 2, 1, 2),
+    (1, 33, 47, 96, 2, 1, 7),
+    (2, 129, 131, 32, 2, 1, 3),
 ]
 
 
@@ -228,6 +236,21 @@ def test_dwconv_fwd_dgrad_wgrad(case, dtype):
         assert torch.equal(K().dwconv_dgrad(dyd, w4, stride, dil, (H, W)), g)
         dW4 = K().dwconv_wgrad(to_dev_nhwc(x, dtype), dyd, stride, dil, pro, torch_layout=True)
         assert_close(dW4.cpu(), dW.t().reshape(C, 1, 3, 3).cpu().double(), torch.float32, "dw wgrad layout", fac=2)
+    if stride == 2 and dil == 1:  # fused one-pass backward of the strided layers
+        gf, dW4, pb = K().dwconv_bwd_fused_s2(to_dev_nhwc(x, dtype), dyd, w.to(DEV), pro, want_bn=True)
+        act = xa.detach()
+        mask = ((act > 0) & ((act < 6) if (mode & 4) else torch.ones_like(act, dtype=torch.bool))).double() \
+            if (mode & 1) else torch.ones_like(act)
+        gref = xa.grad * mask
+        assert_close(to_cpu_nchw(gf), gref, dtype, "fused s2 dw dgrad")
+        assert_close(dW4.cpu(), wd.grad, torch.float32, "fused s2 dw wgrad",
+                     fac=20 if dtype == torch.float32 else 100)
+        sums = K().colsum(pb).cpu()
+        assert_close(sums[:C], gref.sum((0, 2, 3)), torch.float32, "fused s2 sum g",
+                     scale=gref.abs().sum((0, 2, 3)).max().item(), fac=300 if dtype == torch.bfloat16 else 5)
+        assert_close(sums[C:], (gref * x.double()).sum((0, 2, 3)), torch.float32, "fused s2 sum gx",
+                     scale=(gref * x.double()).abs().sum((0, 2, 3)).max().item(),
+                     fac=300 if dtype == torch.bfloat16 else 5)
     if stride == 1:  # fused one-pass backward: masked dgrad + wgrad + BN-backward sums
         gf, dWf, pb = K().dwconv_bwd_fused(to_dev_nhwc(x, dtype), dyd, w9c, dil, pro, want_bn=True)
         if K().dw_tiled(stride, dil):  # same kernel fed with the [C,1,3,3] parameter
