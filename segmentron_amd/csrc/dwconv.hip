@@ -17,9 +17,16 @@
 // blockIdx.y (deterministic: LDS tree over the strips of a block, fp64 finish in bn_finalize).
 #include "common.h"
 #include "dwconv_tiled.h"
+#include <cstdlib>
 #include <type_traits>
 
 namespace seg {
+
+// SEG_DW_ROW=0 (environment, A/B runs): wide-dilation layers back on the strip kernels
+static const int g_dw_row = [] {
+  const char* e = getenv("SEG_DW_ROW");
+  return e ? atoi(e) : 1;
+}();
 
 constexpr int DW_TW = 4;
 constexpr int DW_THREADS = 256;
@@ -466,6 +473,8 @@ extern "C" int seg_dwconv_grid_y(int dtype, int C, int N, int Ho, int Wo, int st
   const int tiled_stride = kind == 0 ? stride : 1;  // kinds 1/2 describe a stride-1 layer's backward
   if ((kind == 0 || stride == 1) && dw_tiled_supported(tiled_stride, dil))
     return dw_tiled_grid_y(dtype, C, N, Ho, Wo, kind);
+  if (g_dw_row && (kind == 0 || kind == 1) && dw_row_supported(stride, dil) && C % 4 == 0)
+    return dw_row_grid_y(dtype, C, N, Ho, Wo, dil);  // stride 1: Ho x Wo is the input size too
   const int vec = dtype == DT_BF16 ? 8 : 4;
   const int CV = C / vec;
   const int l = pick_cvb_log2(CV);
@@ -497,6 +506,11 @@ extern "C" int seg_dwconv3x3(int dtype, int mode, const void* x, long ldx, int N
                            pro_shift, y, ldy, stat_partial, grid_y, (hipStream_t)stream);
   }
   SEG_REQUIRE(w_layout == 0, "dwconv3x3: the strip kernels take tap-major [9][C] weights");
+  if (g_dw_row && mode == MODE_FWD && dw_row_supported(stride, dil) && C % 4 == 0) {
+    SEG_REQUIRE(Ho == Hi && Wo == Wi, "dwconv3x3: stride 1 keeps the size");
+    return launch_dw_row_fwd(dtype, x, ldx, N, Hi, Wi, C, w9c, dil, pro_mode, pro_scale, pro_shift,
+                             y, ldy, stat_partial, grid_y, (hipStream_t)stream);
+  }
   DwArgs a;
   a.x = x; a.w = w9c; a.y = y; a.pro_scale = pro_scale; a.pro_shift = pro_shift;
   a.stat_partial = stat_partial; a.ldx = ldx; a.ldy = ldy;
@@ -584,6 +598,9 @@ extern "C" int seg_dwconv3x3_bwd_fused(int dtype, const void* dy, long lddy, con
                                (hipStream_t)stream);
   }
   SEG_REQUIRE(w_layout == 0, "dwconv3x3_bwd_fused: the strip kernel takes tap-major weights");
+  if (g_dw_row && dw_row_supported(1, dil))
+    return launch_dw_row_bwd(dtype, dy, lddy, x, ldx, N, H, W, C, w9c, dil, pro_mode, pro_scale,
+                             pro_shift, g, ldg, partial_w, partial_bn, grid_y, (hipStream_t)stream);
   DwBwdArgs a;
   a.dy = dy; a.x = x; a.g = g; a.w = w9c; a.pro_scale = pro_scale; a.pro_shift = pro_shift;
   a.partial_w = partial_w; a.partial_bn = partial_bn;

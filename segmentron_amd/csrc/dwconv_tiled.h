@@ -17,4 +17,14 @@ int launch_dw_wgrad_finalize(const float* partial, int R, int C, float* out, hip
 int launch_dw_wgrad_tiled(int dtype, const void* x, long ldx, int N, int H, int W, int C,
                           const void* dy, long lddy, int dil, int pro_mode, const float* sc,
                           const float* sh, float* partial, int grid_y, hipStream_t st);
+// row-segment kernels for stride 1 with wide dilation (dwconv_row.hip)
+bool dw_row_supported(int stride, int dil);
+int dw_row_grid_y(int dtype, int C, int N, int H, int W, int dil);
+int launch_dw_row_fwd(int dtype, const void* x, long ldx, int N, int H, int W, int C,
+                      const float* w9c, int dil, int pro_mode, const float* sc, const float* sh,
+                      void* y, long ldy, float* stat_partial, int grid_y, hipStream_t st);
+int launch_dw_row_bwd(int dtype, const void* dy, long lddy, const void* x, long ldx, int N, int H,
+                      int W, int C, const float* w9c, int dil, int pro_mode, const float* sc,
+                      const float* sh, void* g, long ldg, float* partial_w, float* partial_bn,
+                      int grid_y, hipStream_t st);
 }  // namespace seg

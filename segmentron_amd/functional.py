@@ -393,7 +393,7 @@ class _DwFn(torch.autograd.Function):
         tiled = K.dw_tiled(s.stride, s.dil)
         big = x.numel() * x.element_size() >= (40 << 20)
         strided = s.stride == 2 and s.dil == 1 and C % 4 == 0 and weight.dtype == torch.float32
-        if ctx.needs_input_grad[0] and ((s.stride == 1 and (tiled or big)) or strided):
+        if ctx.needs_input_grad[0] and ((s.stride == 1 and (tiled or big or s.dil > 2)) or strided):
             # one pass over (dy, x): masked data gradient + weight-gradient partials + BN sums
             # (LDS-tiled for dil <= 2; the strip version only pays on large tensors; stride 2 on
             # its own kernel, csrc/dwconv_s2.hip)
