@@ -280,7 +280,12 @@ def main():
             torch.cuda.synchronize()
             SF.clear_weight_cache()
     if graph is None:
-        SG._warm(step, 3)
+        # eager path (N > 1, --no-graph): warm up on the CURRENT stream — a side-stream warm-up
+        # (the graph-capture recipe) leaves the 440 AccumulateGrad nodes bound to that stream and
+        # every later step pays a cross-stream event pair per parameter (+13 ms/step of host time)
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
 
     def run_step():
         if graph is not None:
@@ -300,44 +305,61 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    timer.active = graph is None
+    step_ends = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = run_step()
+        step_ends.append(time.perf_counter())
     torch.cuda.synchronize()
+    if os.environ.get("SEG_BENCH_HOST_PROFILE") == "1" and rank == 0:
+        sys.stderr.write("host-side issue time per step (ms): %s; drain %.1f\n" % (
+            " ".join("%.1f" % ((b - a) * 1e3) for a, b in zip([t0] + step_ends, step_ends)),
+            (time.perf_counter() - step_ends[-1]) * 1e3))
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    timer.active = False
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
     loss_value = float(loss.item())
     kernel_ms, n_kernels = (None, None)
-    roofline_steps = args.steps
+    # per-launch HIP events of the dominant kernel: three EAGER steps (same kernels, same shapes)
+    # AFTER the timed region — event pairs around every launch slow the launch-bound eager path
+    # itself down (2 x 157 timed events per step), so they must not sit in the timed steps of an
+    # eager (N > 1) run either
+    roofline_steps = 3
     if graph is not None:
-        # per-launch HIP events of the dominant kernel: eager steps (same kernels, same shapes)
         graph.release()
-        roofline_steps = 3
         step()
+    torch.cuda.synchronize()
+    timer.active = True
+    for _ in range(roofline_steps):
+        # An eager step is launch-bound (the host needs longer to issue the ~1200 launches
+        # than the GPU to run them), and an event pair around a launch then also measures
+        # the queue running dry.  Give the host a head start: the GPU spins ~60 ms first, so
+        # every kernel of the step is already queued when its turn comes and e0 -> e1 is the
+        # kernel's duration alone.
         torch.cuda.synchronize()
-        timer.active = True
-        for _ in range(roofline_steps):
-            # An eager step is launch-bound (the host needs longer to issue the ~1200 launches
-            # than the GPU to run them), and an event pair around a launch then also measures
-            # the queue running dry.  Give the host a head start: the GPU spins ~60 ms first, so
-            # every kernel of the step is already queued when its turn comes and e0 -> e1 is the
-            # kernel's duration alone.
-            torch.cuda.synchronize()
-            try:
-                torch.cuda._sleep(int(1.5e8))
-            except Exception:  # noqa: BLE001 — no spin kernel in this build: measure as is
-                pass
+        try:
+            torch.cuda._sleep(int(1.5e8))
+        except Exception:  # noqa: BLE001 — no spin kernel in this build: measure as is
+            pass
+        step()
+    torch.cuda.synchronize()
+    timer.active = False
+    if os.environ.get("SEG_BENCH_HOST_PROFILE") == "1" and rank == 0:
+        # where the host time of an eager step goes (stderr; diagnostics for the N > 1 path)
+        import cProfile
+        import pstats
+        pr = cProfile.Profile()
+        pr.enable()
+        for _ in range(3):
             step()
         torch.cuda.synchronize()
-        timer.active = False
+        pr.disable()
+        pstats.Stats(pr, stream=sys.stderr).sort_stats("tottime").print_stats(25)
     # one EAGER step under the profiler (roctracer does not see the nodes of a replayed graph):
     # sum of its kernel durations / the timed ms_per_step -> gpu_busy_frac
     if rank == 0 and world == 1:
@@ -383,9 +405,9 @@ def main():
                          "launches_per_step": launches / max(roofline_steps, 1),
                          "kernel_ms_per_step": secs * 1e3 / max(roofline_steps, 1),
                          "timing": "HIP events around each launch, %d eager steps with the launch queue kept "
-                                   "full (GPU spin-wait head start)%s"
-                                   % (roofline_steps, " after the timed graph replays"
-                                      if graph is not None else " (the timed region)"),
+                                   "full (GPU spin-wait head start) after the timed %s"
+                                   % (roofline_steps, "graph replays" if graph is not None
+                                      else "eager steps"),
                          "all_gemm_achieved": fa / sa / 1e12 if sa > 0 else 0.0,
                          "all_gemm_launches_per_step": la / max(roofline_steps, 1),
                          "all_gemm_ms_per_step": sa * 1e3 / max(roofline_steps, 1)},

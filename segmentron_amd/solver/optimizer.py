@@ -42,6 +42,7 @@ class FusedSGD(optim.Optimizer):
         if len({g["momentum"] for g in self.param_groups}) > 1:
             raise ValueError("FusedSGD: one momentum for all parameter groups")
         self._hyper_dev, self._hyper_host = None, None
+        self._plans = {}
 
     # -- device copy of (lr, weight_decay) per group
     def sync_hyperparameters(self):
@@ -80,28 +81,40 @@ class FusedSGD(optim.Optimizer):
         fresh, old = ([], [], [], []), ([], [], [], [])
         for gi, group in enumerate(self.param_groups):
             for p in group["params"]:
-                if p.grad is None:
+                g = p.grad
+                if g is None:
                     continue
-                if p.grad.is_sparse:
-                    raise RuntimeError("FusedSGD does not support sparse gradients")
                 st = self.state[p]
-                dst = old
-                if momentum != 0.0 and "momentum_buffer" not in st:
-                    st["momentum_buffer"] = torch.empty_like(p, memory_format=torch.contiguous_format)
-                    dst = fresh
-                elif momentum == 0.0:
-                    # no state kept: the kernel still wants a buffer to write m into
-                    st.setdefault("_scratch", torch.empty_like(p, memory_format=torch.contiguous_format))
-                    dst = fresh
-                buf = st["momentum_buffer"] if momentum != 0.0 else st["_scratch"]
-                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                buf = st.get("momentum_buffer") if momentum != 0.0 else st.get("_scratch")
+                dst = old if (buf is not None and momentum != 0.0) else fresh
+                if buf is None:
+                    if g.is_sparse:
+                        raise RuntimeError("FusedSGD does not support sparse gradients")
+                    buf = torch.empty_like(p, memory_format=torch.contiguous_format)
+                    st["momentum_buffer" if momentum != 0.0 else "_scratch"] = buf
+                if not g.is_contiguous():
+                    g = g.contiguous()
                 dst[0].append(p)
                 dst[1].append(g)
                 dst[2].append(buf)
                 dst[3].append(gi)
         for first, (ps, gs, bs, gi) in ((True, fresh), (False, old)):
-            if ps:
-                K.sgd_multi_tensor(ps, gs, bs, gi, lr_dev, wd_dev, momentum, first)
+            if not ps:
+                continue
+            # the pointer tables of parameters / buffers are rebuilt only when the set changes
+            key = (first, len(ps), ps[0].data_ptr(), ps[-1].data_ptr(), bs[0].data_ptr(),
+                   bs[-1].data_ptr())
+            plan = self._plans.get(first)
+            if plan is None or plan[0] != key or any(a is not b for a, b in zip(plan[1], ps)):
+                for p, g, b in zip(ps, gs, bs):
+                    K.sgd_check(p, g, b)
+                plan = (key, list(ps), K.sgd_plan(ps, bs, gi))
+                self._plans[first] = plan
+            else:
+                g0 = gs[0]
+                if not (g0.is_cuda and g0.dtype == torch.float32):
+                    raise RuntimeError("segmentron_amd SGD: gradients must be fp32 HIP tensors")
+            K.sgd_multi_tensor(plan[2], gs, lr_dev, wd_dev, momentum, first)
         return loss
 
     def state_dict(self):
