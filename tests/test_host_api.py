@@ -234,3 +234,32 @@ def test_torch_custom_ops_are_registered_with_fake_implementations():
         cnt = ns.segmentation_counts(torch.empty(2, 19, 65, 129, device="cuda"),
                                      torch.empty(2, 65, 129, dtype=torch.long, device="cuda"), 19)
         assert tuple(cnt.shape) == (59,) and cnt.dtype == torch.int64
+
+
+def test_kernel_selection_queries_of_the_c_library():
+    """The host-side dispatch rules of libsegmentron_hip.so that size the partial buffers
+    (no device needed): which forward / weight-gradient kernel a geometry runs on decides how
+    many statistics rows / split partials the caller must allocate."""
+    from segmentron_amd import _lib
+    q = _lib.LIB.query
+    BF16, F32 = 1, 0
+    # xception conv2 [2,513,1025,32] -> 64, 3x3 s1 p1: bf16 = direct halo-tile kernel (one row per
+    # persistent block, 512), fp32 = implicit GEMM's 256x64 tile (one row per 256 pixels)
+    M = 2 * 513 * 1025
+    assert q("seg_conv_gemm_stat_rows", BF16, 2, 513, 1025, 32, 64, 3, 3, 1, 1, 1, 0, 0) == 512
+    assert q("seg_conv_gemm_stat_rows", F32, 2, 513, 1025, 32, 64, 3, 3, 1, 1, 1, 0, 0) == (M + 255) // 256
+    # a bias keeps the conv on the implicit GEMM; dilation 2 likewise
+    assert q("seg_conv_gemm_stat_rows", BF16, 2, 513, 1025, 32, 64, 3, 3, 1, 1, 1, 0, 1) == (M + 255) // 256
+    assert q("seg_conv_gemm_stat_rows", BF16, 2, 513, 1025, 32, 64, 3, 3, 1, 2, 2, 0, 0) == (M + 255) // 256
+    # small map: first-generation 128-pixel tiles; 1x1 with O >= 384: the 256-pixel-tile kernels
+    assert q("seg_conv_gemm_stat_rows", BF16, 2, 33, 65, 32, 64, 3, 3, 1, 1, 1, 0, 0) == (2 * 33 * 65 + 127) // 128
+    assert q("seg_conv_gemm_stat_rows", BF16, 2, 65, 129, 728, 728, 1, 1, 1, 0, 1, 0, 0) == (2 * 65 * 129 + 255) // 256
+    # weight gradient: conv2 on the direct kernel (one partial per persistent block); plain 1x1
+    # 728x728 on the direct-to-LDS kernel (~one block per CU: 36 tiles x 7 splits)
+    assert q("seg_conv_gemm_wgrad_splits", BF16, 2, 513, 1025, 32, 64, 3, 3, 1, 1, 1, 3) == 512
+    assert q("seg_conv_gemm_wgrad_splits", BF16, 2, 65, 129, 728, 728, 1, 1, 1, 0, 1, 0) == 7
+    # depthwise: stride-2 fused backward (one resident set of 768 blocks over the channel blocks),
+    # wide dilation = row chains (images x phases x segments), capped the same way
+    assert q("seg_dwconv3x3_s2_grid_y", 128, 2, 513, 1025) == 768 // 4
+    assert q("seg_dwconv_grid_y", BF16, 2048, 2, 65, 129, 1, 18, 0) == min(2 * 18 * 1, 768 // 64)
+    assert q("seg_dwconv_grid_y", BF16, 2048, 2, 65, 129, 1, 6, 1) == min(2 * 6 * 1, 768 // 64)
