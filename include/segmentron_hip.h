@@ -68,7 +68,7 @@ int seg_conv_gemm_wgrad(int dtype, const void* x, long ldx, int N, int Hi, int W
                         const float* pro_shift, float* partial, int splits, void* stream);
 /* rows of the [rows][2][O] statistics buffer seg_conv_gemm_fwd writes for this geometry */
 int seg_conv_gemm_stat_rows(int dtype, int N, int Ho, int Wo, int C, int O, int KH, int KW,
-                            int stride, int pad, int dil, int tconv, int has_bias);
+                            int stride, int pad, int dil, int tconv, int has_bias, int pro_mode);
 /* tuning knob: 2 (default) = 1x1 stride-1 convs on the direct-to-LDS 256x256 bf16 kernel where
  * it applies (no prologue / bias, O % 8 == 0) else the 256x128-tile kernel; 1 = 256x128 only;
  * 0 = first-generation 128x128 kernel; +4 = keep 3x3 stride-1 bf16 convolutions with C, O in

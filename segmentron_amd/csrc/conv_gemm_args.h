@@ -32,6 +32,9 @@ int launch_conv_gemm_px256(int dtype, ConvGemmArgs a, hipStream_t stream);
 // direct-to-LDS 256x256 kernel (conv_gemm_glds.hip): bf16, 1x1 stride 1, no prologue
 bool conv_gemm_glds_usable(int dtype, const ConvGemmArgs& a);
 int launch_conv_gemm_glds(ConvGemmArgs a, hipStream_t stream);
+// the same pipeline as an implicit GEMM for stride-1 KxK convolutions (C % 32 == 0, no prologue)
+bool conv_gemm_glds_kxk_usable(int dtype, const ConvGemmArgs& a);
+int launch_conv_gemm_glds_kxk(ConvGemmArgs a, hipStream_t stream);
 
 // direct 3x3 stride-1 kernel for few channels at large spatial sizes (conv3x3_direct.hip)
 bool conv3x3_direct_usable(int dtype, const ConvGemmArgs& a);

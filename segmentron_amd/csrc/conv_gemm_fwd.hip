@@ -375,12 +375,26 @@ static bool gemm_use_px256(int KH, int KW, int stride, int pad, int tconv, int O
 }
 
 // rows of the statistics partial buffer [rows][2][O] the forward kernel will write
+// stride-1 KxK convolutions wide enough for the 256x256 direct-to-LDS tile
+static bool gemm_use_glds_kxk(int dtype, const seg::ConvGemmArgs& a) {
+  return seg::g_gemm_px256 >= 2 && a.O >= 256 && a.M >= 4096 &&
+         seg::conv_gemm_glds_kxk_usable(dtype, a);
+}
+
 extern "C" int seg_conv_gemm_stat_rows(int dtype, int N, int Ho, int Wo, int C, int O, int KH,
                                        int KW, int stride, int pad, int dil, int tconv,
-                                       int has_bias) {
+                                       int has_bias, int pro_mode) {
   const long M = (long)N * Ho * Wo;
   if (seg::g_gemm_px256 && gemm_use_px256(KH, KW, stride, pad, tconv, O, M))
     return seg::px256_tiles_m(M);
+  {  // KxK on the direct-to-LDS pipeline (the predicate does not look at the input size)
+    seg::ConvGemmArgs probe = {};
+    probe.KH = KH; probe.KW = KW; probe.stride = stride; probe.pad = pad; probe.dil = dil;
+    probe.tconv = tconv; probe.out_s = 1; probe.C = C; probe.O = O; probe.ldx = 8; probe.ldy = 8;
+    probe.N = 1; probe.Hi = 1; probe.Wi = 1; probe.M = (int)M; probe.pro_mode = pro_mode;
+    probe.bias = has_bias ? reinterpret_cast<const float*>(&probe) : nullptr;
+    if (gemm_use_glds_kxk(dtype, probe)) return seg::px256_tiles_m(M);
+  }
   {  // the direct 3x3 kernel (stride 1, pad 1: the input has the output's size)
     seg::ConvGemmArgs probe = {};
     probe.KH = KH; probe.KW = KW; probe.stride = stride; probe.pad = pad; probe.dil = dil;
@@ -436,6 +450,8 @@ extern "C" int seg_conv_gemm_fwd(int dtype, const void* x, long ldx, int N, int 
   }
   if (g_conv3x3_direct && conv3x3_direct_usable(dtype, a))
     return launch_conv3x3_direct(a, (hipStream_t)stream);
+  if (out_s == 1 && gemm_use_glds_kxk(dtype, a))
+    return launch_conv_gemm_glds_kxk(a, (hipStream_t)stream);
   if (dtype == DT_BF16) return launch_conv_gemm_fwd<bf16_t>(a, (hipStream_t)stream);
   return launch_conv_gemm_fwd<float>(a, (hipStream_t)stream);
 }

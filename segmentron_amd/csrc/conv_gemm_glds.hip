@@ -10,7 +10,9 @@
 namespace seg {
 
 // EP: folded-BatchNorm backward correction in the store path; STATS: BatchNorm partial sums
-template <int VARIANT, bool EP, bool STATS>
+// KXK: stride-1 KxK convolution as an implicit GEMM (per-lane gather in the DMA source address,
+// gemm_glds.h GlConvA) — ResNet bottleneck / PSP-head 3x3s, C % 32 == 0
+template <int VARIANT, bool EP, bool STATS, bool KXK = false>
 __global__ __launch_bounds__(GL_THREADS, 2) void conv_gemm_glds_kernel(const ConvGemmArgs a) {
   typedef bf16_t T;
   constexpr int VEC = 8;
@@ -58,8 +60,14 @@ __global__ __launch_bounds__(GL_THREADS, 2) void conv_gemm_glds_kernel(const Con
     return;
   }
 #else
-  if (VARIANT >= 3) gl_mainloop_ring<0>(A, B, a.K, m0, n0, lds, acc);
-  else gl_mainloop<VARIANT>(A, B, a.K, m0, n0, lds, acc);
+  if (KXK) {
+    const GlConvA cg = {a.M, a.Hi, a.Wi, a.Ho, a.Wo, a.KW, a.pad, a.dil, a.C / 32};
+    gl_mainloop_ring<0, true>(A, B, a.K, m0, n0, lds, acc, &cg);
+  } else if (VARIANT >= 3) {
+    gl_mainloop_ring<0>(A, B, a.K, m0, n0, lds, acc);
+  } else {
+    gl_mainloop<VARIANT>(A, B, a.K, m0, n0, lds, acc);
+  }
 #endif
 
   // ---- epilogue, per wave and 32-pixel tile: channel groups -> LDS patch [32 px][64 ch] ->
@@ -220,6 +228,38 @@ static int launch_glds_variant(ConvGemmArgs a, hipStream_t stream) {
 
 int launch_conv_gemm_glds(ConvGemmArgs a, hipStream_t stream) {
   return launch_glds_variant<3>(a, stream);
+}
+
+// ---- stride-1 KxK on the same pipeline
+bool conv_gemm_glds_kxk_usable(int dtype, const ConvGemmArgs& a) {
+  return dtype == DT_BF16 && a.pro_mode == PRO_NONE && a.bias == nullptr && a.ep_x == nullptr &&
+         a.KH * a.KW > 1 && a.stride == 1 && a.tconv == 0 && a.out_s == 1 && (a.C % 32) == 0 &&
+         (a.ldx % 8) == 0 && (a.O % 8) == 0 && (a.ldy % 8) == 0 &&
+         (long)a.N * a.Hi * a.Wi < (1L << 31);
+}
+
+template <bool STATS>
+static int launch_glds_kxk_inst(const ConvGemmArgs& a, hipStream_t stream) {
+  static const int once = [] {
+    return (int)hipFuncSetAttribute(
+        reinterpret_cast<const void*>(&conv_gemm_glds_kernel<3, false, STATS, true>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, GL_LDS_BYTES);
+  }();
+  if (once != 0) {
+    set_error("conv_gemm_glds (KxK): cannot reserve %d bytes of LDS", GL_LDS_BYTES);
+    return 2;
+  }
+  const dim3 grid(a.tiles_m * a.tiles_n), block(GL_THREADS);
+  hipLaunchKernelGGL((conv_gemm_glds_kernel<3, false, STATS, true>), grid, block, GL_LDS_BYTES,
+                     stream, a);
+  return check_launch("conv_gemm_fwd (glds KxK)");
+}
+
+int launch_conv_gemm_glds_kxk(ConvGemmArgs a, hipStream_t stream) {
+  a.tiles_m = px256_tiles_m(a.M);
+  a.tiles_n = (a.O + GL_BN - 1) / GL_BN;
+  if (a.stat_partial != nullptr) return launch_glds_kxk_inst<true>(a, stream);
+  return launch_glds_kxk_inst<false>(a, stream);
 }
 
 #ifdef GL_LAB

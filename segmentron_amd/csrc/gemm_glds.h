@@ -245,11 +245,19 @@ __device__ __forceinline__ void gl_mainloop(const GemmOperand& A, const GemmOper
 // keeps the vmcnt arithmetic uniform; the caller's epilogue starts after vmcnt(0) + barrier.
 constexpr int GL_SLOT_BYTES = 32 * 1024, GL_SUB_BYTES = 16 * 1024;
 
+// Implicit-GEMM form of the A operand (KXK): row m = output pixel (n, ho, wo) of a stride-1 KxK
+// convolution over an NHWC tensor with C % 32 == 0, so that every 32-k slot lies inside ONE tap
+// (kh, kw): the per-lane DMA source of slot s is the input pixel (ho - pad + kh*dil,
+// wo - pad + kw*dil), channels cb*32 .. +31 — or the zero word outside the image.
+struct GlConvA {
+  int M, Hi, Wi, Ho, Wo, KW, pad, dil, cpt;  // cpt = C / 32: slots per tap
+};
+
 // ABL (tools/lab only): 1 = no DMA inside the loop, 2 = no MFMA (fragments xor-folded instead)
-template <int ABL = 0>
+template <int ABL = 0, bool KXK = false>
 __device__ __forceinline__ void gl_mainloop_ring(const GemmOperand& A, const GemmOperand& B, int K,
                                                  int m0, int n0, lds_byte_t* lds,
-                                                 f32x16 (&acc)[2][4]) {
+                                                 f32x16 (&acc)[2][4], const GlConvA* cg = nullptr) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
@@ -268,15 +276,45 @@ __device__ __forceinline__ void gl_mainloop_ring(const GemmOperand& A, const Gem
     inc[j] = aok ? 64 : 0;
     inc[2 + j] = bok ? 64 : 0;
   }
+  // KXK: this thread's two output pixels and the running tap of the slot being issued (slots are
+  // issued strictly in order)
+  int cpix[2] = {0, 0}, ch0[2] = {0, 0}, cw0[2] = {0, 0};
+  bool cval[2] = {false, false};
+  int tkh = 0, tkw = 0, tcb = 0;
+  if (KXK) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int m = m0 + (wave * 2 + j) * 16 + (lane >> 2);
+      cval[j] = m < cg->M;
+      const int mm = cval[j] ? m : 0;
+      const int wo = mm % cg->Wo, t = mm / cg->Wo;
+      const int ho = t % cg->Ho, n = t / cg->Ho;
+      cpix[j] = n * cg->Hi * cg->Wi;
+      ch0[j] = ho - cg->pad;
+      cw0[j] = wo - cg->pad;
+    }
+  }
   auto issue = [&](int slot) {
     lds_byte_t* base = lds + (slot & 3) * GL_SLOT_BYTES + (wave * 2) * 1024;
     const bool v = slot < nvalid;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const unsigned char* p = v ? src[j] : zero;
+      if (KXK && j < 2) {
+        const int hi = ch0[j] + tkh * cg->dil, wi = cw0[j] + tkw * cg->dil;
+        const bool ok = v && cval[j] && hi >= 0 && hi < cg->Hi && wi >= 0 && wi < cg->Wi;
+        p = ok ? A.base + (long)(cpix[j] + hi * cg->Wi + wi) * A.ld_bytes + tcb * 64 + kv * 16
+               : zero;
+      }
       src[j] += inc[j];
       lds_byte_t* dst = base + (j & 1) * 1024 + (j >> 1) * GL_SUB_BYTES;
       __builtin_amdgcn_global_load_lds((glb_byte_t*)p, dst, 16, 0, 0);
+    }
+    if (KXK) {  // (uniform) advance the tap: channel block fastest, then kw, then kh
+      if (++tcb == cg->cpt) {
+        tcb = 0;
+        if (++tkw == cg->KW) { tkw = 0; ++tkh; }
+      }
     }
   };
   const int nslot = (K + 31) >> 5;

@@ -105,6 +105,58 @@ __global__ __launch_bounds__(RS_THREADS) void bilinear_bwd_kernel(const ResizeAr
   }
 }
 
+// Same, for LARGE magnifications (PSP pyramid pooling: 1x1 .. 6x6 bins -> 129x257, every source
+// pixel collects from up to Ho*Wo / (Hi*Wi) outputs): with one thread per source vector the 1x1
+// bin ran 128 threads over 33 k outputs each — 17 ms, 30 % of the PSPNet train step.  Here a
+// BLOCK owns (source pixel, 8 channel vectors): 32 pixel lanes stride over the footprint, the
+// partial sums meet in LDS in a fixed order (deterministic).
+constexpr int RSW_CVB = 8, RSW_PL = RS_THREADS / RSW_CVB;
+template <typename T>
+__global__ __launch_bounds__(RS_THREADS) void bilinear_bwd_wide_kernel(const ResizeArgs a) {
+  constexpr int VEC = Vec<T>::N;
+  __shared__ float red[RSW_PL][RSW_CVB][VEC];
+  const T* __restrict__ GY = reinterpret_cast<const T*>(a.y);
+  T* __restrict__ GX = reinterpret_cast<T*>(const_cast<void*>(a.x));
+  const int cvb = (a.CV + RSW_CVB - 1) / RSW_CVB;
+  const int cx = threadIdx.x & (RSW_CVB - 1), pl = threadIdx.x / RSW_CVB;
+  long p = blockIdx.x / cvb;
+  const int cv = (int)(blockIdx.x - p * cvb) * RSW_CVB + cx;
+  const int wi = (int)(p % a.Wi); p /= a.Wi;
+  const int hi = (int)(p % a.Hi);
+  const int n = (int)(p / a.Hi);
+  const bool cok = cv < a.CV;
+  const int c0 = (cok ? cv : 0) * VEC;
+  int hlo, hhi, wlo, whi;
+  cand_range(a.sh, hi, a.Ho, a.align, hlo, hhi);
+  cand_range(a.sw, wi, a.Wo, a.align, wlo, whi);
+  const int nw = whi - wlo + 1, nf = (hhi - hlo + 1) * nw;
+  float acc[VEC];
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
+  for (int f = pl; f < nf; f += RSW_PL) {
+    const int r = f / nw;
+    const int ho = hlo + r, wo = wlo + (f - r * nw);
+    const float w = tap_weight(a.sh, ho, a.Hi, a.align, hi) * tap_weight(a.sw, wo, a.Wi, a.align, wi);
+    if (w == 0.f || !cok) continue;
+    float g[VEC];
+    Vec<T>::unpack(ldg16(GY + (((long)n * a.Ho + ho) * a.Wo + wo) * a.ldy + c0), g);
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) acc[k] = fmaf(w, g[k], acc[k]);
+  }
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) red[pl][cx][k] = acc[k];
+  __syncthreads();
+  if (pl == 0 && cok) {
+    float tot[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) tot[k] = 0.f;
+    for (int q = 0; q < RSW_PL; ++q)
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) tot[k] += red[q][cx][k];
+    stg16(GX + (((long)n * a.Hi + hi) * a.Wi + wi) * a.ldx + c0, Vec<T>::pack(tot));
+  }
+}
+
 // ---- logits: NHWC (T, C valid channels, row pitch ldx) -> NCHW fp32 at (Ho, Wo)
 template <typename T>
 __global__ __launch_bounds__(RS_THREADS) void upsample_to_nchw_kernel(const ResizeArgs a,
@@ -331,6 +383,18 @@ extern "C" int seg_bilinear_bwd(int dtype, void* gx, long ldgx, int N, int Hi, i
   if (fill_args(a, dtype, gx, ldgx, N, Hi, Wi, C, const_cast<void*>(gy), ldgy, Ho, Wo,
                 align_corners, true))
     return 1;
+  // large magnification (>= 64 outputs per source pixel): one block per source pixel
+  if ((long)Ho * Wo >= 64L * Hi * Wi) {
+    const long nblk = (long)N * Hi * Wi * ((a.CV + RSW_CVB - 1) / RSW_CVB);
+    SEG_REQUIRE(nblk < (1L << 31), "bilinear_bwd: too many blocks");
+    if (dtype == DT_BF16)
+      hipLaunchKernelGGL((bilinear_bwd_wide_kernel<bf16_t>), dim3((unsigned)nblk),
+                         dim3(RS_THREADS), 0, (hipStream_t)stream, a);
+    else
+      hipLaunchKernelGGL((bilinear_bwd_wide_kernel<float>), dim3((unsigned)nblk), dim3(RS_THREADS),
+                         0, (hipStream_t)stream, a);
+    return check_launch("bilinear_bwd (wide)");
+  }
   const int grid = rs_grid((long)N * Hi * Wi * a.CV);
   if (dtype == DT_BF16)
     hipLaunchKernelGGL((bilinear_bwd_kernel<bf16_t>), dim3(grid), dim3(RS_THREADS), 0,

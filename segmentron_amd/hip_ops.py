@@ -118,7 +118,7 @@ def conv_gemm(x, w_packed, O, KH, KW, stride, pad, dil, pro=None, bias=None, out
     partial = None
     if want_stats:
         tm = LIB.query("seg_conv_gemm_stat_rows", _DT[x.dtype], N, Ho, Wo, C, O, KH, KW, stride,
-                       pad, dil, 1 if tconv_out_hw is not None else 0, int(bias is not None))
+                       pad, dil, 1 if tconv_out_hw is not None else 0, int(bias is not None), mode)
         partial = torch.empty((tm, 2, O), dtype=torch.float32, device=x.device)
     assert w_packed.dtype == x.dtype and w_packed.is_contiguous()
     ep_x, ldep, ep_c0, ep_c1 = None, 0, None, None

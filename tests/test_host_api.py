@@ -246,14 +246,19 @@ def test_kernel_selection_queries_of_the_c_library():
     # xception conv2 [2,513,1025,32] -> 64, 3x3 s1 p1: bf16 = direct halo-tile kernel (one row per
     # persistent block, 512), fp32 = implicit GEMM's 256x64 tile (one row per 256 pixels)
     M = 2 * 513 * 1025
-    assert q("seg_conv_gemm_stat_rows", BF16, 2, 513, 1025, 32, 64, 3, 3, 1, 1, 1, 0, 0) == 512
-    assert q("seg_conv_gemm_stat_rows", F32, 2, 513, 1025, 32, 64, 3, 3, 1, 1, 1, 0, 0) == (M + 255) // 256
+    assert q("seg_conv_gemm_stat_rows", BF16, 2, 513, 1025, 32, 64, 3, 3, 1, 1, 1, 0, 0, 3) == 512
+    assert q("seg_conv_gemm_stat_rows", F32, 2, 513, 1025, 32, 64, 3, 3, 1, 1, 1, 0, 0, 3) == (M + 255) // 256
     # a bias keeps the conv on the implicit GEMM; dilation 2 likewise
-    assert q("seg_conv_gemm_stat_rows", BF16, 2, 513, 1025, 32, 64, 3, 3, 1, 1, 1, 0, 1) == (M + 255) // 256
-    assert q("seg_conv_gemm_stat_rows", BF16, 2, 513, 1025, 32, 64, 3, 3, 1, 2, 2, 0, 0) == (M + 255) // 256
+    assert q("seg_conv_gemm_stat_rows", BF16, 2, 513, 1025, 32, 64, 3, 3, 1, 1, 1, 0, 1, 0) == (M + 255) // 256
+    assert q("seg_conv_gemm_stat_rows", BF16, 2, 513, 1025, 32, 64, 3, 3, 1, 2, 2, 0, 0, 0) == (M + 255) // 256
     # small map: first-generation 128-pixel tiles; 1x1 with O >= 384: the 256-pixel-tile kernels
-    assert q("seg_conv_gemm_stat_rows", BF16, 2, 33, 65, 32, 64, 3, 3, 1, 1, 1, 0, 0) == (2 * 33 * 65 + 127) // 128
-    assert q("seg_conv_gemm_stat_rows", BF16, 2, 65, 129, 728, 728, 1, 1, 1, 0, 1, 0, 0) == (2 * 65 * 129 + 255) // 256
+    assert q("seg_conv_gemm_stat_rows", BF16, 2, 33, 65, 32, 64, 3, 3, 1, 1, 1, 0, 0, 0) == (2 * 33 * 65 + 127) // 128
+    assert q("seg_conv_gemm_stat_rows", BF16, 2, 65, 129, 728, 728, 1, 1, 1, 0, 1, 0, 0, 0) == (2 * 65 * 129 + 255) // 256
+    # ResNet layer3 3x3 (256 -> 256, dilation 2) without a prologue: the direct-to-LDS pipeline
+    # as an implicit GEMM (256-pixel tiles); with a pending BatchNorm/ReLU: first generation
+    Mr = 2 * 129 * 257
+    assert q("seg_conv_gemm_stat_rows", BF16, 2, 129, 257, 256, 256, 3, 3, 1, 2, 2, 0, 0, 0) == (Mr + 255) // 256
+    assert q("seg_conv_gemm_stat_rows", BF16, 2, 129, 257, 256, 256, 3, 3, 1, 2, 2, 0, 0, 3) == (Mr + 127) // 128
     # weight gradient: conv2 on the direct kernel (one partial per persistent block); plain 1x1
     # 728x728 on the direct-to-LDS kernel (~one block per CU: 36 tiles x 7 splits)
     assert q("seg_conv_gemm_wgrad_splits", BF16, 2, 513, 1025, 32, 64, 3, 3, 1, 1, 1, 3) == 512

@@ -73,6 +73,13 @@ CONV_CASES = [
     (1, 259, 261, 64, 32, 3, 1, 1, 1, 0, False, False),
     (2, 131, 259, 32, 32, 3, 1, 1, 1, 2, False, True),
     (2, 129, 257, 64, 32, 3, 1, 1, 1, 3, False, False),
+    # stride-1 KxK on the direct-to-LDS pipeline (bf16, no prologue, C % 32 == 0, O >= 256,
+    # >= 4096 pixels): ResNet layer3 / layer4 dilated 3x3, ragged O tile + slice in/out, a
+    # padding that shrinks the map (the data-gradient geometry of a padded conv)
+    (2, 65, 67, 256, 256, 3, 1, 2, 2, 0, False, False),
+    (1, 40, 110, 512, 512, 3, 1, 4, 4, 0, False, False),
+    (1, 70, 72, 320, 264, 3, 1, 1, 1, 0, False, True),
+    (1, 70, 72, 256, 256, 3, 1, 0, 1, 0, False, False),
 ]
 
 
@@ -105,9 +112,11 @@ def test_conv_gemm_fwd(case, dtype):
         M = N * ref.shape[2] * ref.shape[3]
         direct = k == 3 and stride == 1 and pad == 1 and dil == 1 and M >= 65536 and \
             (C, O) in ((32, 32), (32, 64), (64, 32))
-        if dtype == torch.bfloat16 and (direct or (k == 1 and stride == 1 and pad == 0
-                                                   and O >= 384 and M >= 4096)):
-            # the 256x128 and direct-3x3 kernels take the statistics of the values AS STORED
+        glds_kxk = k > 1 and stride == 1 and C % 32 == 0 and O >= 256 and M >= 4096 \
+            and mode == 0 and not bias
+        if dtype == torch.bfloat16 and (direct or glds_kxk or (k == 1 and stride == 1 and pad == 0
+                                                               and O >= 384 and M >= 4096)):
+            # the 256x128, direct-to-LDS and direct-3x3 kernels take the statistics of the values AS STORED
             # (bf16-rounded):
             # that is the tensor the consumer's normalisation is applied to
             nb = quant(nb.float(), dtype).double()
@@ -349,7 +358,11 @@ def test_bn_backward_matches_autograd(dtype, relu):
 RESIZE_CASES = [(5, 9, 17, 33, True), (17, 33, 65, 129, True), (9, 13, 20, 31, False),
                 (1, 1, 5, 9, True), (12, 10, 7, 5, True),
                 (2, 4, 16, 32, False), (4, 8, 16, 32, False), (8, 16, 16, 32, False),  # HRNet head
-                (3, 5, 40, 77, False), (12, 10, 7, 5, False)]
+                (3, 5, 40, 77, False), (12, 10, 7, 5, False),
+                # PSP pyramid bins -> feature map: >= 64 outputs per source pixel (block-cooperative
+                # backward kernel)
+                (2, 3, 40, 70, True), (6, 6, 65, 129, True), (3, 3, 49, 65, False),
+                (2, 2, 33, 65, True)]
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
