@@ -300,12 +300,14 @@ extern "C" int seg_conv_gemm_wgrad_splits(int dtype, int N, int Ho, int Wo, int 
   const long M = (long)N * Ho * Wo;
   const int K = KH * KW * C;
   const bool plain_1x1 = KH == 1 && KW == 1 && stride == 1 && pad == 0 && pro_mode == PRO_NONE;
-  if (plain_1x1 && g_wgrad_glds) {  // the call will run on conv_gemm_wgrad_glds.hip
+  if (g_wgrad_glds && pro_mode == PRO_NONE && stride == 1) {  // conv_gemm_wgrad_glds.hip
     WgradArgs probe = {};
-    probe.KH = probe.KW = 1; probe.stride = 1; probe.pro_mode = PRO_NONE;
-    probe.C = K; probe.O = O; probe.M = (int)M; probe.ldx = 8; probe.lddy = 8;
+    probe.KH = KH; probe.KW = KW; probe.stride = 1; probe.pad = pad; probe.dil = dil;
+    probe.pro_mode = PRO_NONE; probe.C = C; probe.O = O; probe.M = (int)M; probe.ldx = 8;
+    probe.lddy = 8; probe.N = 1; probe.Hi = 1; probe.Wi = 1; probe.Ho = Ho; probe.Wo = Wo;
     if (conv_wgrad_glds_usable(dtype, probe)) return conv_wgrad_glds_splits(M, O, K);
   }
+  (void)plain_1x1;
   if (g_wgrad_direct && conv3x3_wgrad_direct_usable(dtype, C, O, KH, KW, stride, pad, dil, M, 8, 8))
     return conv3x3_direct_blocks(N, Ho, Wo);  // one partial per persistent block
   const int tiles = ((O + BM - 1) / BM) * ((K + BN - 1) / BN);

@@ -53,6 +53,10 @@ __device__ __forceinline__ bf16x8 wg_join(u64_t lo, u64_t hi) {
   return __builtin_bit_cast(bf16x8, v);
 }
 
+// KXK: stride-1 KxK convolution with C % 128 == 0 — a 128-wide tile of the K = KH*KW*C axis
+// then lies inside ONE tap, and the x sub-tile of a slot is the same 64 output pixels shifted by
+// that tap (per-lane DMA source; the zero word outside the image).
+template <bool KXK>
 __global__ __launch_bounds__(WG_THREADS, 2) void conv_wgrad_glds_kernel(const WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   lds_byte_t* lds = (lds_byte_t*)smem_raw;
@@ -77,9 +81,19 @@ __global__ __launch_bounds__(WG_THREADS, 2) void conv_wgrad_glds_kernel(const Wg
   const unsigned char* zero = reinterpret_cast<const unsigned char*>(g_gl_zero);
   const int rr = lane >> 4;                          // row inside the chunk
   const int c16 = ((lane & 15) - 4 * rr) & 15;       // source piece of this lane's LDS position
-  const bool ch_dy = o0 + c16 * 8 < a.O, ch_x = c0 + c16 * 8 < a.C;
+  const bool ch_dy = o0 + c16 * 8 < a.O, ch_x = c0 + c16 * 8 < (KXK ? a.K : a.C);
   const unsigned char* src[4];
   int prow[2];
+  // KXK: tap of this K tile and the (n, ho, wo) of this thread's two pixel rows, advanced by
+  // 64 pixels per slot (Wo >= 64: at most one row wrap per step)
+  int kdh = 0, kdw = 0, kc0 = c0, pn[2] = {0, 0}, ph[2] = {0, 0}, pw[2] = {0, 0};
+  if (KXK) {
+    const int tap = c0 / a.C;
+    kc0 = c0 - tap * a.C;
+    const int kh = tap / a.KW;
+    kdh = kh * a.dil - a.pad;
+    kdw = (tap - kh * a.KW) * a.dil - a.pad;
+  }
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     prow[j] = p0 + (wave * 2 + j) * 4 + rr;          // pixel of slot 0; +64 per slot
@@ -87,6 +101,12 @@ __global__ __launch_bounds__(WG_THREADS, 2) void conv_wgrad_glds_kernel(const Wg
              ((long)prow[j] * a.lddy + o0 + c16 * 8) * 2;
     src[2 + j] = reinterpret_cast<const unsigned char*>(a.x) +
                  ((long)prow[j] * a.ldx + c0 + c16 * 8) * 2;
+    if (KXK) {
+      pw[j] = prow[j] % a.Wo;
+      const int t = prow[j] / a.Wo;
+      ph[j] = t % a.Ho;
+      pn[j] = t / a.Ho;
+    }
   }
   const long inc_dy = (long)WG_BK * a.lddy * 2, inc_x = (long)WG_BK * a.ldx * 2;
   auto issue = [&](int slot) {
@@ -96,6 +116,18 @@ __global__ __launch_bounds__(WG_THREADS, 2) void conv_wgrad_glds_kernel(const Wg
       const bool rok = prow[j] + slot * WG_BK < p1;
       const unsigned char* pd = (rok && ch_dy) ? src[j] : zero;
       const unsigned char* px = (rok && ch_x) ? src[2 + j] : zero;
+      if (KXK) {
+        const int hi = ph[j] + kdh, wi = pw[j] + kdw;
+        const bool ok = rok && ch_x && hi >= 0 && hi < a.Hi && wi >= 0 && wi < a.Wi;
+        px = ok ? reinterpret_cast<const unsigned char*>(a.x) +
+                      ((((long)pn[j] * a.Hi + hi) * a.Wi + wi) * a.ldx + kc0 + c16 * 8) * 2
+                : zero;
+        pw[j] += WG_BK;  // next slot: 64 pixels on
+        if (pw[j] >= a.Wo) {
+          pw[j] -= a.Wo;
+          if (++ph[j] == a.Ho) { ph[j] = 0; ++pn[j]; }
+        }
+      }
       src[j] += inc_dy;
       src[2 + j] += inc_x;
       __builtin_amdgcn_global_load_lds((glb_byte_t*)pd, base + j * 1024, 16, 0, 0);
@@ -191,9 +223,14 @@ __global__ __launch_bounds__(WG_THREADS, 2) void conv_wgrad_glds_kernel(const Wg
 }
 
 bool conv_wgrad_glds_usable(int dtype, const WgradArgs& a) {
-  return dtype == DT_BF16 && a.pro_mode == PRO_NONE && a.KH == 1 && a.KW == 1 && a.stride == 1 &&
-         a.pad == 0 && (a.C % 8) == 0 && (a.O % 8) == 0 && (a.ldx % 8) == 0 &&
-         (a.lddy % 8) == 0 && a.M >= 2048 && (long)a.O * a.C >= 128 * 128;
+  const bool common = dtype == DT_BF16 && a.pro_mode == PRO_NONE && a.stride == 1 &&
+                      (a.O % 8) == 0 && (a.ldx % 8) == 0 && (a.lddy % 8) == 0 && a.M >= 2048;
+  if (!common) return false;
+  if (a.KH == 1 && a.KW == 1)
+    return a.pad == 0 && (a.C % 8) == 0 && (long)a.O * a.C >= 128 * 128;
+  // KxK: a 128-wide K tile inside one tap, at most one row wrap per 64-pixel slot
+  return (a.C % 128) == 0 && a.Wo >= WG_BK && a.O >= 128 &&
+         (long)a.N * a.Hi * a.Wi < (1L << 31);
 }
 
 // splits so that tiles x splits ~ one block per CU in ONE round (up to 10 % over: a second,
@@ -214,15 +251,21 @@ int launch_conv_wgrad_glds(WgradArgs a, hipStream_t stream) {
   const int slots = (a.M + WG_BK - 1) / WG_BK;
   a.chunk = ((slots + a.splits - 1) / a.splits) * WG_BK;
   static const int once = [] {
-    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_glds_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, WG_LDS);
+    int rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_glds_kernel<false>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, WG_LDS);
+    rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_glds_kernel<true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, WG_LDS);
+    return rc;
   }();
   if (once != 0) {
     set_error("conv_wgrad_glds: cannot reserve %d bytes of LDS", WG_LDS);
     return 2;
   }
   const dim3 grid(a.tiles_o * a.tiles_k * a.splits), block(WG_THREADS);
-  hipLaunchKernelGGL(conv_wgrad_glds_kernel, grid, block, WG_LDS, stream, a);
+  if (a.KH * a.KW > 1)
+    hipLaunchKernelGGL(conv_wgrad_glds_kernel<true>, grid, block, WG_LDS, stream, a);
+  else
+    hipLaunchKernelGGL(conv_wgrad_glds_kernel<false>, grid, block, WG_LDS, stream, a);
   return check_launch("conv_gemm_wgrad (glds)");
 }
 

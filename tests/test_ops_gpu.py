@@ -158,6 +158,13 @@ WGRAD_CASES = [
     (1, 260, 257, 32, 64, 3, 1, 1, 1, 3),
     (2, 131, 259, 32, 32, 3, 1, 1, 1, 0),
     (2, 129, 263, 32, 64, 3, 1, 1, 1, 1),
+    # stride-1 KxK on the direct-to-LDS transpose-read kernel (bf16, no prologue, C % 128 == 0,
+    # output rows >= 64 pixels): dilated ResNet 3x3s, image-row wraps inside a slot, several
+    # splits; the last one (output rows of 62 pixels) stays on the first-generation kernel
+    (2, 40, 70, 256, 256, 3, 1, 2, 2, 0),
+    (1, 33, 129, 128, 384, 3, 1, 1, 1, 0),
+    (1, 70, 66, 256, 136, 3, 1, 4, 4, 0),
+    (2, 36, 64, 256, 128, 3, 1, 0, 1, 0),
 ]
 
 
