@@ -59,6 +59,34 @@ C3 = ["DATASET.NAME", "cityscape", "TRAIN.BATCH_SIZE", str(BATCH), "TRAIN.CROP_S
       "TEST.CROP_SIZE", "(1025, 2049)", "SOLVER.LR", "0.02", "MODEL.MODEL_NAME", "DeepLabV3_Plus",
       "MODEL.BACKBONE", "xception65", "MODEL.BN_EPS_FOR_ENCODER", "1e-3",
       "TRAIN.BACKBONE_PRETRAINED", "False"]
+_COMMON = ["DATASET.NAME", "cityscape", "TRAIN.BACKBONE_PRETRAINED", "False"]
+# `--config`: the default c3 is BASELINE.json's metric; c2 / c4 / c5 are its other GPU configs
+# (configs[1], [3], [4]) emitted in the same JSON schema so that they can be driver-timed too.
+# A "step" of an inference config is one forward pass over one batch (torch.no_grad, eval mode).
+CONFIGS = {
+    "c3": dict(over=C3, batch=BATCH, h=H, w=W, train=True, aux=False, oracle="deeplabv3_plus_xception65",
+               metric="images/sec fwd+bwd DeepLabv3+_xception65 @1025x2049",
+               workload="DeepLabv3+_xception65 train step (fwd + CE loss + bwd + SGD)",
+               tag="BASELINE.json configs[2]"),
+    "c4": dict(over=_COMMON + ["MODEL.MODEL_NAME", "PSPNet", "MODEL.BACKBONE", "resnet101",
+                               "MODEL.OUTPUT_STRIDE", "8", "SOLVER.AUX", "True", "SOLVER.LR", "0.01"],
+               batch=2, h=1025, w=2049, train=True, aux=True, oracle="pspnet_resnet", os=8,
+               metric="images/sec fwd+bwd PSPNet_resnet101 @1025x2049",
+               workload="PSPNet_resnet101 (OS8, aux head) train step (fwd + CE + 0.4 aux CE + bwd "
+                        "+ SGD)", tag="BASELINE.json configs[3]"),
+    "c2": dict(over=_COMMON + ["MODEL.MODEL_NAME", "DeepLabV3_Plus", "MODEL.BACKBONE", "mobilenet_v2",
+                               "MODEL.DEEPLABV3_PLUS.USE_ASPP", "False",
+                               "MODEL.DEEPLABV3_PLUS.ENABLE_DECODER", "False"],
+               batch=1, h=1024, w=2048, train=False, aux=False, oracle="deeplab_mobilenet", os=16,
+               metric="images/sec inference DeepLabv3_plus_mobilenetV2 @1024x2048",
+               workload="DeepLabv3+_mobilenet_v2 inference (the reference's "
+                        "cityscapes_deeplabv3_plus_mobilenet.yaml: USE_ASPP / ENABLE_DECODER False)",
+               tag="BASELINE.json configs[1]"),
+    "c5": dict(over=_COMMON, yaml="configs/cityscapes_hrnet_w18_small_v1.yaml", batch=16, h=1024,
+               w=2048, train=False, aux=False, oracle="hrnet_seg", os=16, momentum=0.01,
+               metric="images/sec inference HRNet_w18_small_v1 @1024x2048 batch 16",
+               workload="HRNet_w18_small_v1 inference", tag="BASELINE.json configs[4]"),
+}
 
 
 class GemmTimer:
@@ -118,35 +146,44 @@ def _cpu_model():
     return "unknown"
 
 
-def cpu_baseline(size):
+def cpu_baseline(size, conf="c3"):
     from oracle import synth, torch_ref
     import segmentron_amd
+    c = CONFIGS[conf]
     h, w = size
+    batch = c["batch"] if c["train"] else 1  # inference: per-image rate of the CPU path
     threads = min(32, os.cpu_count() or 1)  # oneDNN collapses when oversubscribed (256-core host)
     torch.set_num_threads(threads)
     model = segmentron_amd.get_segmentation_model()
     sd = synth.synth_like(model.state_dict(), seed=0)
-    x = synth.synth_images(BATCH, h, w, seed=0)
-    y = synth.synth_targets(BATCH, h, w, seed=0)
+    x = synth.synth_images(batch, h, w, seed=0)
+    y = synth.synth_targets(batch, h, w, seed=0)
     times = []
     for _ in range(3):  # 1 warm-up + 2 timed
-        osd = torch_ref.clone_state(sd, requires_grad=True)
-        net = torch_ref.OracleNet(osd, training=True, eps_encoder=1e-3)
+        osd = torch_ref.clone_state(sd, requires_grad=c["train"])
+        kw = dict(eps_encoder=1e-3) if conf == "c3" else dict(
+            output_stride=c["os"], aux=c["aux"], drop_p=0.0, momentum=c.get("momentum"))
+        net = torch_ref.OracleNet(osd, training=c["train"], **kw)
         t0 = time.perf_counter()
-        loss = torch_ref.mix_softmax_ce(net.deeplabv3_plus_xception65(x), y)
-        loss.backward()
+        if c["train"]:
+            loss = torch_ref.mix_softmax_ce(getattr(net, c["oracle"])(x), y)
+            loss.backward()
+        else:
+            with torch.no_grad():
+                loss = getattr(net, c["oracle"])(x)
         times.append(time.perf_counter() - t0)
         del osd, net, loss
     t = sum(times[1:]) / 2.0
-    ratio = (h * w) / float(H * W)
-    full = (h, w) == (H, W)
-    return {"value": BATCH * ratio / t, "unit": "images/sec" if full else
-            "images/sec (1025x2049-equivalent)", "cores": threads, "host_cores": os.cpu_count(),
+    ratio = (h * w) / float(c["h"] * c["w"])
+    full = (h, w) == (c["h"], c["w"])
+    return {"value": batch * ratio / t, "unit": "images/sec" if full else
+            "images/sec (%dx%d-equivalent)" % (c["h"], c["w"]), "cores": threads,
+            "host_cores": os.cpu_count(),
             "cpu_model": _cpu_model(), "torch": torch.__version__, "kind": "port",
-            "sample": "oracle (torch CPU fp32 restatement of the reference graph) train fwd+bwd, "
-                      "batch 2 @%dx%d, 1 warm-up + 2 timed (%.1f s, %.1f s)%s"
-                      % (h, w, times[1], times[2],
-                         "" if full else ", scaled by pixel ratio %.4f" % ratio)}
+            "sample": "oracle (torch CPU fp32 restatement of the reference graph) %s, "
+                      "batch %d @%dx%d, 1 warm-up + 2 timed (%.1f s, %.1f s)%s"
+                      % ("train fwd+bwd" if c["train"] else "eval forward", batch, h, w, times[1],
+                         times[2], "" if full else ", scaled by pixel ratio %.4f" % ratio)}
 
 
 def self_launch(args):
@@ -195,13 +232,25 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="c3", choices=sorted(CONFIGS),
+                    help="c3 = BASELINE.json's metric (default); c2 / c4 / c5 = its other configs")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--height", type=int, default=H)
-    ap.add_argument("--width", type=int, default=W)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--no-graph", action="store_true", help="eager launches (no HIP graph)")
-    ap.add_argument("--cpu-baseline-size", default="%dx%d" % (H, W))
+    ap.add_argument("--cpu-baseline-size", default=None)
     args = ap.parse_args()
+    conf = CONFIGS[args.config]
+    batch, train = conf["batch"], conf["train"]
+    if args.height is None:
+        args.height = conf["h"]
+    if args.width is None:
+        args.width = conf["w"]
+    if args.cpu_baseline_size is None:
+        # c4's CPU train step at 1025x2049 would take minutes: a bounded 513x1025 sample, scaled
+        args.cpu_baseline_size = "513x1025" if args.config == "c4" else \
+            "%dx%d" % (conf["h"], conf["w"])
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(self_launch(args))
@@ -228,36 +277,50 @@ def main():
     import segmentron_amd
     from segmentron_amd.config import cfg, reset_cfg
     reset_cfg()
-    cfg.update_from_list(C3)
-    cfg.PHASE = "train"
+    if conf.get("yaml"):
+        cfg.update_from_file(os.path.join(ROOT, conf["yaml"]))
+    cfg.update_from_list(conf["over"])
+    cfg.PHASE = "train" if train else "test"
     cfg.check_and_freeze()
     segmentron_amd.set_compute_dtype(args.dtype)
     torch.manual_seed(0)
     model = segmentron_amd.get_segmentation_model()
-    for _, m in model.encoder.named_modules():  # solver/optimizer.py:18-20
-        if isinstance(m, torch.nn.BatchNorm2d):
-            m.eps = cfg.MODEL.BN_EPS_FOR_ENCODER
-    model = model.to(dev).train()
-    if world > 1:
-        model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)  # tools/train.py:76
-        model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local],
-                                                          output_device=local)
-    params = [{"params": model.parameters(), "lr": cfg.SOLVER.LR}]
-    sgd = dict(lr=cfg.SOLVER.LR, momentum=cfg.SOLVER.MOMENTUM,
-               weight_decay=cfg.SOLVER.WEIGHT_DECAY)  # solver/optimizer.py:45-66
-    # the reference's optimizer (solver/optimizer.py:45-50) on the multi-tensor HIP kernel
-    from segmentron_amd.solver.optimizer import FusedSGD
-    opt = FusedSGD(params, **sgd)
+    if cfg.MODEL.BN_EPS_FOR_ENCODER and getattr(model, "encoder", None) is not None:
+        for _, m in model.encoder.named_modules():  # solver/optimizer.py:18-20
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.eps = cfg.MODEL.BN_EPS_FOR_ENCODER
+    model = model.to(dev).train(train)
+    opt = None
+    if train:
+        if world > 1:
+            model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)  # tools/train.py:76
+            model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local],
+                                                              output_device=local)
+        params = [{"params": model.parameters(), "lr": cfg.SOLVER.LR}]
+        sgd = dict(lr=cfg.SOLVER.LR, momentum=cfg.SOLVER.MOMENTUM,
+                   weight_decay=cfg.SOLVER.WEIGHT_DECAY)  # solver/optimizer.py:45-66
+        # the reference's optimizer (solver/optimizer.py:45-50) on the multi-tensor HIP kernel
+        from segmentron_amd.solver.optimizer import FusedSGD
+        opt = FusedSGD(params, **sgd)
 
     g = torch.Generator().manual_seed(rank)
-    images = torch.randn(BATCH, 3, args.height, args.width, generator=g).to(dev)
-    targets = torch.randint(0, 19, (BATCH, args.height, args.width), generator=g)
-    targets[torch.rand(BATCH, args.height, args.width, generator=g) < 0.05] = -1
+    images = torch.randn(batch, 3, args.height, args.width, generator=g).to(dev)
+    targets = torch.randint(0, 19, (batch, args.height, args.width), generator=g)
+    targets[torch.rand(batch, args.height, args.width, generator=g) < 0.05] = -1
     targets = targets.to(dev)
+    ce = torch.nn.functional.cross_entropy
+
+    def loss_fn(out, tgt):  # solver/loss.py:16-46 MixSoftmaxCrossEntropyLoss (aux weight 0.4)
+        loss = ce(out[0], tgt, ignore_index=-1)
+        for o in out[1:]:
+            loss = loss + cfg.SOLVER.AUX_WEIGHT * ce(o, tgt, ignore_index=-1)
+        return loss
 
     def step():
-        out = model(images)
-        loss = torch.nn.functional.cross_entropy(out[0], targets, ignore_index=-1)
+        if not train:
+            with torch.no_grad():
+                return model(images)[0]
+        loss = loss_fn(model(images), targets)
         opt.zero_grad(set_to_none=True)
         loss.backward()
         opt.step()
@@ -265,15 +328,17 @@ def main():
 
     timer = GemmTimer()
     # ---- launch path: one HIP graph of the whole step (single GPU), else eager
-    graph, graph_err, static_loss = None, None, None
-    use_graph = world == 1 and not args.no_graph and os.environ.get("SEG_BENCH_GRAPH", "1") != "0"
-    loss_fn = lambda out, tgt: torch.nn.functional.cross_entropy(out[0], tgt, ignore_index=-1)
+    graph, graph_err = None, None
+    use_graph = (world == 1 or not train) and not args.no_graph and \
+        os.environ.get("SEG_BENCH_GRAPH", "1") != "0"
     from segmentron_amd import functional as SF
     from segmentron_amd import graph as SG
     if use_graph:
         try:  # segmentron_amd/graph.py: eager warm-up on a side stream, then ONE capture
-            graph = SG.GraphedTrainStep(model, opt, images, targets, loss_fn)
-            static_loss = graph.loss
+            if train:
+                graph = SG.GraphedTrainStep(model, opt, images, targets, loss_fn)
+            else:
+                graph = SG.GraphedInference(model, images)
         except Exception as e:  # noqa: BLE001
             graph, graph_err = None, repr(e)[:300]
             sys.stderr.write("bench.py: HIP-graph capture failed, running eager: %s\n" % graph_err)
@@ -289,7 +354,8 @@ def main():
 
     def run_step():
         if graph is not None:
-            return graph()
+            out = graph()
+            return out if train else out[0]
         return step()
 
     # Device pre-conditioning (untimed, reported as "prewarm_steps"): a fresh box occasionally ran
@@ -323,7 +389,7 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
-    loss_value = float(loss.item())
+    loss_value = float(loss.item()) if train else float(loss.float().abs().mean().item())
     kernel_ms, n_kernels = (None, None)
     # per-launch HIP events of the dominant kernel: three EAGER steps (same kernels, same shapes)
     # AFTER the timed region — event pairs around every launch slow the launch-bound eager path
@@ -331,7 +397,8 @@ def main():
     # eager (N > 1) run either
     roofline_steps = 3
     if graph is not None:
-        graph.release()
+        if train:
+            graph.release()
         step()
     torch.cuda.synchronize()
     timer.active = True
@@ -367,19 +434,21 @@ def main():
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
-        value = world * BATCH * args.steps / elapsed
+        value = world * batch * args.steps / elapsed
         flops, secs, launches = timer.result()
         achieved = flops / secs / 1e12 if secs > 0 else 0.0
         traffic = traffic_src = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and args.config == "c3":
             tj = json.load(open(tpath))
-            traffic = tj.get("conv_gemm_px256_bytes_per_launch")
+            traffic = tj.get("conv_gemm_glds_bytes_per_launch",
+                             tj.get("conv_gemm_px256_bytes_per_launch"))
             traffic_src = tj.get("source")
         fa, sa, la = timer.result_all()
-        full = (args.height, args.width) == (H, W)
+        full = (args.height, args.width) == (conf["h"], conf["w"])
+        peak = MFMA_BF16_PEAK / 1e12 if args.dtype == "bf16" else 157.3
         line = {
-            "metric": "images/sec fwd+bwd DeepLabv3+_xception65 @1025x2049",
+            "metric": conf["metric"],
             "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "prewarm_steps": prewarm, "ms_per_step": ms,
             "higher_is_better": True, "scaling": "weak",
@@ -387,20 +456,19 @@ def main():
             "gpu_kernel_ms_per_step": kernel_ms, "kernels_per_step": n_kernels,
             "gpu_busy_frac": (kernel_ms / ms) if kernel_ms else None,
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "DeepLabv3+_xception65 train step (fwd + CE loss + bwd + SGD) "
-                                   "@%dx%d, batch %d/GPU (BASELINE.json configs[2])"
-                                   % (args.height, args.width, BATCH),
-                       "global_batch": world * BATCH, "bn": "SyncBN" if world > 1 else "BN",
-                       "parallelism": "dp%d" % world, "full_size": full,
-                       "loss": loss_value},
+            "config": {"workload": "%s @%dx%d, batch %d/GPU (%s)"
+                                   % (conf["workload"], args.height, args.width, batch, conf["tag"]),
+                       "global_batch": world * batch,
+                       "bn": ("SyncBN" if world > 1 else "BN") if train else "eval (running stats)",
+                       "parallelism": ("dp%d" % world) if train else ("replicas x%d" % world),
+                       "full_size": full, "loss" if train else "mean_abs_logit": loss_value},
             "model_flop_fraction_of_bf16_mfma_peak":
-                value / world * FLOP_FWD_BWD_PER_IMAGE / MFMA_BF16_PEAK if full else None,
+                value / world * FLOP_FWD_BWD_PER_IMAGE / MFMA_BF16_PEAK
+                if (full and args.config == "c3") else None,
             "roofline": {"bound": "mfma", "kernel": "conv_gemm_glds_kernel (bf16)" if args.dtype == "bf16" else
                          "conv_gemm_px256_kernel<fp32>",
-                         "achieved": achieved, "peak": MFMA_BF16_PEAK / 1e12 if
-                         args.dtype == "bf16" else 157.3, "unit": "TFLOP/s",
-                         "frac": achieved / (MFMA_BF16_PEAK / 1e12 if args.dtype == "bf16"
-                                             else 157.3),
+                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved / peak,
                          "traffic": traffic, "traffic_source": traffic_src,
                          "launches_per_step": launches / max(roofline_steps, 1),
                          "kernel_ms_per_step": secs * 1e3 / max(roofline_steps, 1),
@@ -416,7 +484,7 @@ def main():
             line["hip_graph_error"] = graph_err
         if not args.no_cpu_baseline and world == 1:
             ch, cw = (int(v) for v in args.cpu_baseline_size.lower().split("x"))
-            line["cpu_baseline"] = cpu_baseline((ch, cw))
+            line["cpu_baseline"] = cpu_baseline((ch, cw), args.config)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -243,20 +243,25 @@ def _fcn_resnet(self, x):
     return tuple(outs)
 
 
-def _pspnet_resnet(self, x):
-    """PSPNet.forward + _PSPHead + PyramidPooling — pspnet.py:28-58, module.py:82-97."""
-    size = x.shape[2:]
-    _, _, c3, c4 = _resnet(self, x)
+def _psp_head(self, c4, p="head"):
+    """_PSPHead + PyramidPooling — pspnet.py:44-58, module.py:82-97 (logits at c4 resolution)."""
     hw = c4.shape[2:]
     feats = [c4]
     for i, o in enumerate((1, 2, 3, 6)):
         f = F.adaptive_avg_pool2d(c4, o)
-        f = self.conv_bn_relu(f, "head.psp.convs.%d" % i)
+        f = self.conv_bn_relu(f, p + ".psp.convs.%d" % i)
         feats.append(F.interpolate(f, hw, mode="bilinear", align_corners=True))
     y = torch.cat(feats, dim=1)
-    y = F.relu(self.bn(self.conv(y, "head.block.0", 1, 1), "head.block.1"))
+    y = F.relu(self.bn(self.conv(y, p + ".block.0", 1, 1), p + ".block.1"))
     y = F.dropout(y, self.drop_p, self.training)
-    y = self.conv(y, "head.block.4")
+    return self.conv(y, p + ".block.4")
+
+
+def _pspnet_resnet(self, x):
+    """PSPNet.forward + _PSPHead + PyramidPooling — pspnet.py:28-58, module.py:82-97."""
+    size = x.shape[2:]
+    _, _, c3, c4 = _resnet(self, x)
+    y = _psp_head(self, c4, "head")
     outs = [F.interpolate(y, size, mode="bilinear", align_corners=True)]
     if self.aux:
         outs.append(F.interpolate(self.fcn_head(c3, "auxlayer"), size, mode="bilinear",

@@ -73,7 +73,9 @@ __global__ __launch_bounds__(CE_THREADS) void ce_fwd_kernel(const CeArgs a, doub
   for (long i = (long)blockIdx.x * CE_THREADS + threadIdx.x; i < total;
        i += (long)gridDim.x * CE_THREADS) {
     const long t = a.target[i];
-    if (t == a.ignore) continue;
+    // targets outside [0, C) that are not ignore_index (torch raises a device assert for them)
+    // are left out of the sum AND the count, like ignored pixels — never counted with z_t = 0
+    if (t == a.ignore || t < 0 || t >= a.C) continue;
     const int w = (int)(i % a.W);
     const long q = i / a.W;
     const int h = (int)(q % a.H), n = (int)(q / a.H);
@@ -186,7 +188,7 @@ __global__ __launch_bounds__(CE_BWD_THREADS) void ce_bwd_kernel(const CeArgs a, 
     const int h = hlo + hh, w = wlo + ww;
     const long t = a.target[((long)n * a.H + h) * a.W + w];
     float z[NC];
-    if (t != a.ignore) {
+    if (t != a.ignore && t >= 0 && t < a.C) {
       ce_logits<T, NC>(a, n, h, w, z);
       float m = z[0];
 #pragma unroll

@@ -115,12 +115,17 @@ class FusedSGD(optim.Optimizer):
                 if not (g0.is_cuda and g0.dtype == torch.float32):
                     raise RuntimeError("segmentron_amd SGD: gradients must be fp32 HIP tensors")
             K.sgd_multi_tensor(plan[2], gs, lr_dev, wd_dev, momentum, first)
+            # the kernel writes the parameters through raw pointers: tell autograd (and
+            # functional.cached_pack, which keys the packed weight copies on `_version`)
+            torch.autograd.graph.increment_version(ps)
         return loss
 
     def state_dict(self):
         sd = super().state_dict()
-        for st in sd["state"].values():  # the momentum-free scratch is not optimizer state
-            st.pop("_scratch", None)
+        # the momentum-free scratch is not optimizer state; the per-parameter dicts returned by
+        # Optimizer.state_dict() are the LIVE ones, so filter into copies
+        sd["state"] = {k: {n: v for n, v in st.items() if n != "_scratch"}
+                       for k, st in sd["state"].items()}
         return sd
 
 

@@ -30,6 +30,7 @@ class SegmentationMetric(object):
 
     def reset(self):
         self._cnt = None
+        self._cache = None
 
     def _counters(self, device):
         if self._cnt is None:
@@ -38,6 +39,7 @@ class SegmentationMetric(object):
 
     def update(self, preds, labels):
         from ..functional import LogitsView
+        self._cache = None
         if isinstance(preds, (list, tuple)):
             for p, l in zip(preds, labels):
                 self.update(p, l)
@@ -57,7 +59,15 @@ class SegmentationMetric(object):
                              self._counters(preds.device))
 
     def _totals(self):
-        """(correct, labelled, inter[nclass], union[nclass]) summed over ranks, on the host."""
+        """(correct, labelled, inter[nclass], union[nclass]) summed over ranks, on the host.
+
+        Distributed: the FIRST read after an update is a collective (one all_reduce of the
+        2 + 3*nclass counters) and must therefore happen on every rank — tools/train.py:196 and
+        tools/eval.py:73 call `get()` on all ranks.  The reduced totals are cached until the next
+        `update()` / `reset()`, so later rank-local reads (`total_*`, a rank-0-only `get()` for
+        logging) issue no further collective and cannot deadlock."""
+        if self._cache is not None:
+            return self._cache
         n = self.nclass
         if self._cnt is None:
             z = torch.zeros(n, dtype=torch.float64)
@@ -67,7 +77,8 @@ class SegmentationMetric(object):
             dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         tot = tot.cpu()
         inter, pred, lab = tot[2:2 + n], tot[2 + n:2 + 2 * n], tot[2 + 2 * n:]
-        return int(tot[0]), int(tot[1]), inter.double(), (pred + lab - inter).double()
+        self._cache = (int(tot[0]), int(tot[1]), inter.double(), (pred + lab - inter).double())
+        return self._cache
 
     # the reference's public attributes (score.py:76-80)
     @property

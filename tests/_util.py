@@ -45,3 +45,21 @@ def assert_close(got, ref, dtype, what="", scale=None, fac=1.0):
     assert err <= tol(dtype) * fac, "%s: max-normalised error %.3e > %.3e" % (what, err,
                                                                                 tol(dtype) * fac)
     return err
+
+
+def tie_tolerant_argmax_check(got, ref, what):
+    """`argmax masks identical` up to the oracle's own exact/near ties: a pixel may differ only
+    where the oracle's top-2 margin is within the observed numerical difference (two equally
+    valid fp32 evaluation orders of the same graph cannot agree there either)."""
+    err = (got - ref).abs().max().item()
+    a, b = got.argmax(1), ref.argmax(1)
+    diff = a != b
+    n_diff = int(diff.sum())
+    if n_diff:
+        top2 = ref.topk(2, dim=1).values
+        margin = (top2[:, 0] - top2[:, 1])[diff]
+        assert (margin <= 4 * err).all(), (
+            "%s: %d argmax mismatches with oracle margin up to %.3e > 4 x max-abs-diff %.3e"
+            % (what, n_diff, margin.max().item(), err))
+    assert n_diff <= 1e-4 * a.numel(), "%s: %d near-tie pixels" % (what, n_diff)
+    return n_diff

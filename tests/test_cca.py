@@ -97,3 +97,56 @@ def test_attention_rows_are_probabilities_and_map_transposes():
     lhs = (K.cca_map(att, b).double() * c.double()).sum()
     rhs = (b.double() * K.cca_map(att, c, transposed=True).double()).sum()
     assert abs(lhs.item() - rhs.item()) <= 1e-5 * abs(lhs.item())
+
+
+# ---------------------------------------------------------------- pinned to the reference's code
+def _ref_vectors():
+    import numpy as np
+    return np.load(os.path.join(ROOT, "tests", "golden", "cca_ref_vectors.npz"))
+
+
+def _check_against(ref_fns, shape, dtype, tol):
+    """oracle forward + torch autograd of the oracle == the reference kernels' forward and their
+    four hand-written backward kernels, on the inputs of oracle/gen_golden_cca.py."""
+    from oracle.gen_golden_cca import inputs
+    t, f, v, att, dwt, dout = inputs(shape, dtype)
+    weight, (dt_, df_), agg, (dw_, dg_) = ref_fns(t, f, v, att, dwt, dout)
+    scale = lambda x: max(x.abs().max().item(), 1e-30)
+    tq, fq = t.clone().requires_grad_(), f.clone().requires_grad_()
+    w = R.cca_weight(tq, fq)
+    assert (w.detach() - weight).abs().max().item() <= tol * scale(weight)
+    w.backward(dwt)      # ca_backward_kernel_t / _f  (ca_cuda.cu:38-94)
+    assert (tq.grad - dt_).abs().max().item() <= tol * scale(dt_)
+    assert (fq.grad - df_).abs().max().item() <= tol * scale(df_)
+    aq, vq = att.clone().requires_grad_(), v.clone().requires_grad_()
+    o = R.cca_map(aq, vq)
+    assert (o.detach() - agg).abs().max().item() <= tol * scale(agg)
+    o.backward(dout)     # ca_map_backward_kernel_w / _g  (ca_cuda.cu:121-177)
+    assert (aq.grad - dw_).abs().max().item() <= tol * scale(dw_)
+    assert (vq.grad - dg_).abs().max().item() <= tol * scale(dg_)
+
+
+@pytest.mark.parametrize("dtype,tag,tol", [(torch.float64, "f64", 1e-13), (torch.float32, "f32", 2e-6)])
+def test_oracle_matches_vectors_produced_by_the_compiled_reference_kernels(dtype, tag, tol):
+    """the oracle's criss-cross attention is pinned to numbers that the
+    reference's OWN kernel source produced (ca_cuda.cu compiled as host C++ by
+    oracle/cca_ref/build.sh; vectors by oracle/gen_golden_cca.py) — forward energies, the
+    aggregation, and the reference's four backward kernels vs torch autograd of the oracle."""
+    g = _ref_vectors()
+    for i, shape in enumerate(g["shapes"].tolist()):
+        get = lambda k: torch.from_numpy(g["%d_%s_%s" % (i, tag, k)])
+        _check_against(lambda *a: (get("weight"), (get("dt"), get("df")), get("agg"),
+                                   (get("dw"), get("dg"))), tuple(shape), dtype, tol)
+
+
+def test_oracle_matches_the_compiled_reference_kernels_live():
+    """Same comparison against oracle/_ref/libcca_ref.so itself on further shapes (skipped where
+    neither the built library nor the reference checkout to build it from exists)."""
+    from oracle import cca_ref
+    if not cca_ref.available():
+        pytest.skip("oracle/_ref/libcca_ref.so not built and no reference checkout here")
+    for shape in [(2, 5, 7, 9), (1, 3, 34, 5), (1, 2, 6, 37), (2, 4, 1, 1)]:
+        _check_against(lambda t, f, v, att, dwt, dout: (
+            cca_ref.ca_forward(t, f), cca_ref.ca_backward(dwt, t, f),
+            cca_ref.ca_map_forward(att, v), cca_ref.ca_map_backward(dout, att, v)),
+            shape, torch.float64, 1e-13)

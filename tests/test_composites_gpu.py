@@ -71,6 +71,7 @@ def _compare(name, dtype, got, ref64, emu, bars, ref32=None):
     backward chains amplify fp32 rounding to 1e-4..1e-3 in ANY evaluation order (the CPU fp32
     oracle's own dx sits 4e-4 from float64 on the 728-channel block)."""
     worst = 0.0
+    stats = {}
     # gradients that are identically zero in exact arithmetic (the bias of a BatchNorm / conv
     # in front of a training-mode BatchNorm) come out as 0 here and as 1e-13 noise in the
     # float64 oracle: measure every parameter gradient against max(its norm, 1e-6 x the largest
@@ -106,13 +107,22 @@ def _compare(name, dtype, got, ref64, emu, bars, ref32=None):
             e_k = emu[k] if k in emu else torch.zeros_like(ref64[k])
             ee = _l2(g, e_k, k)
             floor = _l2(e_k, ref64[k], k)
-            bar = bars[1] if k == "y" else bars[2]
+            # bars: output | data / weight gradients (dim >= 2) | BatchNorm gamma / beta and conv
+            # biases (1-d: residuals of cancelling sums, see _l2 above)
+            bar = bars[1] if k == "y" else (bars[3] if (k.startswith("dx") or ref64[k].dim() >= 2)
+                                            else bars[2])
+            cls = "y" if k == "y" else ("dx/dW" if (k.startswith("dx") or ref64[k].dim() >= 2)
+                                        else "gamma/beta")
+            stats[cls] = max(stats.get(cls, 0.0), ee)
             assert ee <= bar, ("%s %s bf16: L2-rel %.3e vs bf16 emulation > %.1e "
                                "(max-normalised %.3e; emulation itself is %.3e from fp64)"
                                % (name, k, ee, bar, _mx(g, e_k), floor))
             assert e64 <= 2.0 * floor + bar, (
                 "%s %s bf16: L2-rel %.3e vs fp64 oracle (emulation: %.3e)" % (name, k, e64, floor))
             worst = max(worst, ee)
+    if stats:
+        print("PARITY composite %s bf16 L2-rel vs emulation: %s" % (
+            name, ", ".join("%s %.2e" % kv for kv in sorted(stats.items()))))
     return worst
 
 
@@ -148,9 +158,15 @@ def _oracle_run(fn, inputs, dy, dtype_ref, dtype=None):
     return out
 
 
+# bf16 data / weight gradients vs the emulation: 3e-2 unless listed here with
+# the measured reason
+DXDW_BAR = {}
+
 CASES = ["sep_relu_first_728", "sep_relu_last_1536", "sep_stride2_256_728",
          "xception_middle_728", "xception_entry_conv_256_728", "xception_exit_1536_2048",
-         "inverted_residual_32", "aspp_2048", "deeplab_head"]
+         "inverted_residual_32", "aspp_2048", "deeplab_head",
+         # the block types of C1 / C4 / C5 at BASELINE-size feature maps
+         "bottleneck_dilated_2048", "psp_head_2048", "fcn_head_2048", "hr_module_4"]
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
@@ -164,7 +180,8 @@ def test_composite_teacher_forced(case, dtype, c3_cfg):
     segmentron_amd.set_compute_dtype(dtype)
     torch.manual_seed(0)
     N, H, W = 2, 65, 129       # C3's /16 feature map at 1025x2049: M = 16770 pixels
-    bars = (5e-4, 1e-2, 1.5e-1)
+    # fp32 | bf16 y | bf16 gamma / beta / bias | bf16 dx / dW
+    bars = (5e-4, 1e-2, 1.5e-1, DXDW_BAR.get(case, 3e-2))
 
     def act_in(shape, seed, relu_like=False):
         x = rnd(shape, seed) * 1.2 + 0.1
@@ -207,6 +224,51 @@ def test_composite_teacher_forced(case, dtype, c3_cfg):
         hip_fn = lambda a: F.materialize(mod(a)[0])
         ora = lambda net: (lambda x: net.aspp(x, PFX))
         emu = lambda net: (lambda x: r16(net.aspp(_A(x), PFX + ".").val()))
+    elif case == "bottleneck_dilated_2048":
+        # ResNet-101 layer4 block at OS8 (resnet.py:50-81): 2048 -> 512 -> 3x3 dil 4 -> 2048,
+        # identity skip, at C4's 1025x2049 / 8 map (conv2 on the direct-to-LDS KxK kernels)
+        from segmentron_amd.models.backbones.resnet import BottleneckV1b
+        mod, sd = _setup(BottleneckV1b(2048, 512, 1, 4, None, 4), 8)
+        inputs = [torch.relu(act_in((N, 2048, 65, 129), 7))]
+        hip_fn = lambda a: F.materialize(mod(a))
+        ora = lambda net: (lambda x: torch_ref._res_block(net, x, PFX, 1, 4, 4))
+        emu = lambda net: (lambda x: net.res_block(_A(x), PFX, 1, 4, 4).val())
+    elif case == "psp_head_2048":
+        # PyramidPooling + _PSPHead (pspnet.py:44-58, module.py:82-97) on a 2 x 2048 x 65 x 129 c4
+        from segmentron_amd.models.pspnet import _PSPHead
+        mod, sd = _setup(_PSPHead(19), 9)
+        mod.block[3].p = 0.0
+        inputs = [torch.relu(act_in((N, 2048, 65, 129), 8))]
+        hip_fn = lambda a: mod(a)
+        ora = lambda net: (lambda x: torch_ref._psp_head(net, x, PFX))
+        emu = lambda net: (lambda x: net.psp_head(_A(x), PFX))
+    elif case == "fcn_head_2048":
+        from segmentron_amd.modules import _FCNHead
+        mod, sd = _setup(_FCNHead(2048, 19), 10)
+        mod.block[3].p = 0.0
+        inputs = [torch.relu(act_in((N, 2048, 65, 129), 9))]
+        hip_fn = lambda a: mod(a)
+        ora = lambda net: (lambda x: net.fcn_head(x, PFX))
+        emu = lambda net: (lambda x: net.fcn_head(_A(x), PFX))
+    elif case == "hr_module_4":
+        # stage4 of hrnet_w18_small_v1 (4 branches 16/32/64/128, BASIC x 2) at C5's 1024x2048 / 4
+        # top resolution; the four fused outputs are compared as one concatenated vector each
+        from segmentron_amd.models.backbones import hrnet as HR
+        ch = [16, 32, 64, 128]
+        mod, sd = _setup(HR.HighResolutionModule(4, HR.BasicBlock, [2] * 4, list(ch), list(ch),
+                                                 "SUM", True), 11)
+        inputs = [torch.relu(act_in((N, c, 256 >> i, 512 >> i), 10 + i)) for i, c in enumerate(ch)]
+
+        def flat(ts):  # one NCHW "image" [N, sum_i C_i*H_i*W_i, 1, 1]
+            return torch.cat([t.reshape(t.shape[0], -1) for t in ts], 1)[:, :, None, None]
+
+        def hip_fn(*acts):
+            ys = mod(list(acts))
+            return torch.cat([F.materialize(y).permute(0, 3, 1, 2).reshape(N, -1) for y in ys],
+                             1)[:, None, None, :]
+        ora = lambda net: (lambda *xs: flat(torch_ref._hr_module(net, list(xs), PFX)))
+        emu = lambda net: (lambda *xs: flat([y.val() for y in
+                                             net.hr_module([_A(x) for x in xs], PFX)]))
     else:  # deeplab_head: ASPP + decoder + classifier at C3's c4 / c1 shapes (513x1025 input)
         mod, sd = _setup(_DeepLabHead(19, 256, 2048), 7)
         mod.aspp.dropout.p = 0.0

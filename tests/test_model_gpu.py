@@ -245,22 +245,7 @@ def test_full_size_properties_bf16():
 
 
 # ------------------------------------------------------------------ the metric's own shape
-def _tie_tolerant_argmax_check(got, ref, what):
-    """`argmax masks identical` up to the oracle's own exact/near ties: a pixel may differ only
-    where the oracle's top-2 margin is within the observed numerical difference (two equally
-    valid fp32 evaluation orders of the same graph cannot agree there either)."""
-    err = (got - ref).abs().max().item()
-    a, b = got.argmax(1), ref.argmax(1)
-    diff = a != b
-    n_diff = int(diff.sum())
-    if n_diff:
-        top2 = ref.topk(2, dim=1).values
-        margin = (top2[:, 0] - top2[:, 1])[diff]
-        assert (margin <= 4 * err).all(), (
-            "%s: %d argmax mismatches with oracle margin up to %.3e > 4 x max-abs-diff %.3e"
-            % (what, n_diff, margin.max().item(), err))
-    assert n_diff <= 1e-4 * a.numel(), "%s: %d near-tie pixels" % (what, n_diff)
-    return n_diff
+from _util import tie_tolerant_argmax_check as _tie_tolerant_argmax_check  # noqa: E402
 
 
 def test_eval_fp32_full_size_1025x2049_matches_oracle():

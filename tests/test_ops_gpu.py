@@ -191,6 +191,45 @@ def test_conv_gemm_wgrad(case, dtype):
     assert_close(got, w.grad, torch.float32, "dW", fac=20)
 
 
+# ------------------------------------------------------------------------------ PSP head
+def test_psp_head_geometry_on_the_direct_to_lds_kxk_kernels():
+    """pspnet.py:49 `_PSPHead.block[0]`: 3x3, 4096 -> 512 at the OS8 map of a 513 x 553 crop
+    (65 x 70 = 4550 pixels >= 4096): forward and data gradient on `conv_gemm_glds<KXK>` (K = 36864,
+    288 slots per tap sweep; dgrad = 512 -> 4096 with O = 4096), weight gradient on
+    `conv_wgrad_glds<KXK>` (C % 128 == 0, output rows of 70 >= 64 pixels) — the kernels
+    profiles/r02_infer.json's C4 numbers were measured on.  bf16 (the kernels' only dtype); the
+    CPU reference runs in fp32 (oneDNN; an fp64 conv of 171 GFLOP would take minutes)."""
+    dtype = torch.bfloat16
+    N, H, W, C, O = 1, 65, 70, 4096, 512
+    x = quant(rnd((N, C, H, W), 1), dtype)
+    w = quant(rnd((O, C, 3, 3), 2, (2.0 / (C * 9)) ** 0.5), dtype)
+    ref = TF.conv2d(x, w, None, 1, 1, 1)
+    xd = to_dev_nhwc(x, dtype)
+    wp = F().pack_conv_weight(w.to(DEV), C, dtype)
+    y, partial = K().conv_gemm(xd, wp, O, 3, 3, 1, 1, 1, None, None, None, want_stats=True)
+    e1 = assert_close(to_cpu_nchw(y), ref, dtype, "psp head fwd")
+    nb = quant(ref, dtype).double()
+    sums = K().colsum(partial.view(partial.shape[0], -1)).cpu()
+    assert_close(sums[:O], nb.sum((0, 2, 3)), torch.float32, "psp head sum",
+                 scale=nb.abs().sum((0, 2, 3)).max().item(), fac=5)
+    assert_close(sums[O:], (nb * nb).sum((0, 2, 3)), torch.float32, "psp head sumsq", fac=5)
+    # data gradient: dy [N, 512, H, W] -> dx [N, 4096, H, W] through the flipped / transposed pack
+    dy = quant(rnd((N, O, H, W), 3), dtype)
+    gref = TF.conv_transpose2d(dy, w, None, 1, 1)
+    wt = F().pack_conv_weight_dgrad(w.to(DEV), O, dtype)
+    dyd = to_dev_nhwc(dy, dtype)
+    g, _ = K().conv_gemm(dyd, wt, C, 3, 3, 1, 1, 1)
+    e2 = assert_close(to_cpu_nchw(g), gref, dtype, "psp head dgrad")
+    # weight gradient
+    wr = w.clone().requires_grad_()
+    TF.conv2d(x, wr, None, 1, 1, 1).backward(dy)
+    dW = K().conv_wgrad(xd, dyd, O, 3, 3, 1, 1, 1, None)
+    got = dW.view(O, 3, 3, C).permute(0, 3, 1, 2).cpu()
+    e3 = assert_close(got, wr.grad, torch.float32, "psp head dW", fac=20)
+    print("PARITY psp-head 3x3 4096->512 @65x70 bf16: fwd %.2e dgrad %.2e wgrad %.2e "
+          "(max-normalised)" % (e1, e2, e3))
+
+
 # ------------------------------------------------------------------------------ depthwise
 DW_CASES = [
     # N, H, W, C, stride, dil, mode
@@ -388,6 +427,25 @@ def test_bilinear_fwd_bwd(case, dtype):
     if Hi > 1:
         gx = K().bilinear_bwd(to_dev_nhwc(g, dtype, pitch=C + 8), (Hi, Wi), ac)
         assert_close(to_cpu_nchw(gx), xa.grad, dtype, "bilinear bwd")
+    else:
+        # 1x1 source (ASPP image pooling, PSP bin 1): the product path is the autograd function,
+        # whose backward is a per-image column sum + the pending BN/ReLU backward
+        xr = x.double().requires_grad_()
+        sr, tr = s.double().requires_grad_(), t.double().requires_grad_()
+        r2 = TF.interpolate(torch.relu(xr * sr.view(1, -1, 1, 1) + tr.view(1, -1, 1, 1)),
+                            size=(Ho, Wo), mode="bilinear", align_corners=ac)
+        r2.backward(g.double())
+        xd = to_dev_nhwc(x, dtype).requires_grad_()
+        gam, bet = s.to(DEV).requires_grad_(), t.to(DEV).requires_grad_()
+        bn = F().BNState(gam, bet, torch.zeros(C, device=DEV), torch.ones(C, device=DEV),
+                         pro[1], pro[2], N * Hi * Wi, False)
+        yf = F().bilinear(F().Act(xd, bn, True), (Ho, Wo), align_corners=ac)
+        assert_close(to_cpu_nchw(yf), ref.detach(), dtype, "bilinear fwd (autograd path)")
+        yf.backward(to_dev_nhwc(g, dtype))
+        assert_close(to_cpu_nchw(xd.grad), xr.grad, dtype, "bilinear 1x1-source bwd dx", fac=3)
+        # eval-mode BN (mean 0, invstd 1): dgamma = sum g' * x, dbeta = sum g'
+        assert_close(gam.grad.cpu(), sr.grad, torch.float32, "bilinear 1x1-source dgamma", fac=300 if dtype == torch.bfloat16 else 20)
+        assert_close(bet.grad.cpu(), tr.grad, torch.float32, "bilinear 1x1-source dbeta", fac=300 if dtype == torch.bfloat16 else 20)
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
