@@ -116,6 +116,17 @@ int seg_dwconv3x3_bwd_fused(int dtype, const void* dy, long lddy, const void* x,
                             int pro_mode, const float* pro_scale, const float* pro_shift, void* g,
                             long ldg, float* partial_w, float* partial_bn, int grid_y,
                             void* stream);
+/* The same with `res` ([N,H,W,C], pitch ldr, element type of g) ADDED to the masked data gradient
+ * in the store path: g = relu_mask(x) * dgrad + res — the second gradient of a forked activation
+ * (an Xception block input feeds the residual sum and the first separable conv,
+ * segmentron/models/backbones/xception.py:36-42), which autograd would add in a separate
+ * element-wise pass.  LDS-tiled kernel only: stride 1, dilation 1 (seg_..._add_ok(dil) != 0). */
+int seg_dwconv3x3_bwd_fused_add_ok(int dil);
+int seg_dwconv3x3_bwd_fused_add(int dtype, const void* dy, long lddy, const void* x, long ldx, int N,
+                                int H, int W, int C, const float* w9c, int w_layout, int pro_mode,
+                                const float* pro_scale, const float* pro_shift, const void* res,
+                                long ldr, void* g, long ldg, float* partial_w, float* partial_bn,
+                                int grid_y, void* stream);
 
 /* ---- nn.BatchNorm2d / nn.SyncBatchNorm (train + eval, forward + backward) -------------------
  * Replaces F.batch_norm behind every `bn*` module (segmentron/modules/basic.py:41,43,70;
@@ -169,6 +180,15 @@ int seg_bn_bwd_finalize(const double* sums, double count, const double* count_de
 int seg_bn_bwd_finalize_p(const float* partial, long R, double count, const float* mean,
                           const float* invstd, const float* gamma, float* dgamma, float* dbeta,
                           float* c0, float* c1, int C, double* ws, void* stream);
+/* Both reductions behind a fused depthwise backward in one launch: seg_bn_bwd_finalize_p on
+ * partial_bn [Rb][2][C] (Rb <= 1024) and seg_dwconv3x3_wgrad_finalize on partial_w [Rw][9][C]
+ * (replaces two launches per depthwise layer and step; the reference's counterpart is autograd's
+ * batch_norm_backward + the depthwise weight-gradient reduction inside cudnn/MIOpen,
+ * segmentron/modules/basic.py:38-44). */
+int seg_dw_bwd_finalize(const float* partial_bn, int Rb, double count, const float* mean,
+                        const float* invstd, const float* gamma, float* dgamma, float* dbeta,
+                        float* c0, float* c1, const float* partial_w, int Rw, float* dw_c9, int C,
+                        void* stream);
 int seg_bn_bwd_apply(int dtype, const void* g, long ldg, const void* x, long ldx, int mode,
                      const float* scale, const float* shift, const float* c0, const float* c1,
                      const float* chan_mul, long rows_per_n, const void* elem_mul, long ldm,

@@ -405,6 +405,8 @@ __device__ __forceinline__ void reduce_two_columns(const TIN* __restrict__ part,
   }
 }
 
+// (All per-channel parameters are requested BEFORE the partial-row reduction: these kernels are
+// pure latency — one dependent memory round trip instead of two or three: 5-6 us -> ~3 us.)
 template <typename TIN>
 __global__ __launch_bounds__(EW_THREADS) void bn_finalize_p_kernel(
     const TIN* __restrict__ part, int R, double count, const float* __restrict__ gamma,
@@ -414,24 +416,58 @@ __global__ __launch_bounds__(EW_THREADS) void bn_finalize_p_kernel(
   __shared__ double red[2][32][9];
   const int cx = threadIdx.x & 7, ry = threadIdx.x >> 3;
   const int c = blockIdx.x * 8 + cx;
+  const bool fin = ry == 0 && c < C;
+  float g = 1.f, b = 0.f, rm = 0.f, rv = 0.f, moff = 0.f;
+  if (fin) {
+    if (gamma) g = gamma[c];
+    if (beta) b = beta[c];
+    if (running_mean) { rm = running_mean[c]; rv = running_var[c]; }
+    if (mean_offset) moff = mean_offset[c];
+  }
   double sx, sxx;
   reduce_two_columns<TIN>(part, R, C, c, ry, cx, red, sx, sxx);
-  if (ry != 0 || c >= C) return;
+  if (!fin) return;
   const double mean = sx / count;
   double var = sxx / count - mean * mean;
   if (var < 0.0) var = 0.0;
   const double invstd = 1.0 / sqrt(var + (double)eps);
-  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
   mean_o[c] = (float)mean;
   invstd_o[c] = (float)invstd;
   scale_o[c] = (float)((double)g * invstd);
   shift_o[c] = (float)((double)b - mean * (double)g * invstd);
   if (running_mean) {
     const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-    const double off = mean_offset ? (double)mean_offset[c] : 0.0;
-    running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * (mean + off));
-    running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unbiased);
+    running_mean[c] = (float)((1.0 - momentum) * (double)rm + momentum * (mean + (double)moff));
+    running_var[c] = (float)((1.0 - momentum) * (double)rv + momentum * unbiased);
   }
+}
+
+template <typename TIN>
+__device__ __forceinline__ void bn_bwd_finalize_block(
+    const TIN* __restrict__ part, int R, double count, const float* __restrict__ mean,
+    const float* __restrict__ invstd, const float* __restrict__ gamma, float* dgamma, float* dbeta,
+    float* c0_o, float* c1_o, int C, int block, double (&red)[2][32][9]) {
+  const int cx = threadIdx.x & 7, ry = threadIdx.x >> 3;
+  const int c = block * 8 + cx;
+  const bool fin = ry == 0 && c < C;
+  float muf = 0.f, isf = 1.f, gf = 1.f;
+  if (fin) {
+    muf = mean[c];
+    isf = invstd[c];
+    if (gamma) gf = gamma[c];
+  }
+  double sg, sgx;
+  reduce_two_columns<TIN>(part, R, C, c, ry, cx, red, sg, sgx);
+  if (!fin) return;
+  const double mu = muf, is = isf;
+  const double dg = (sgx - mu * sg) * is;
+  const double s = (double)gf * is;
+  const double m1 = sg / count, m2 = dg / count;
+  const double c1 = s * m2 * is;
+  if (dgamma) dgamma[c] = (float)dg;
+  if (dbeta) dbeta[c] = (float)sg;
+  c1_o[c] = (float)c1;
+  c0_o[c] = (float)(s * m1 - c1 * mu);
 }
 
 template <typename TIN>
@@ -440,21 +476,40 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_finalize_p_kernel(
     const float* __restrict__ invstd, const float* __restrict__ gamma, float* dgamma, float* dbeta,
     float* c0_o, float* c1_o, int C) {
   __shared__ double red[2][32][9];
+  bn_bwd_finalize_block<TIN>(part, R, count, mean, invstd, gamma, dgamma, dbeta, c0_o, c1_o, C,
+                             blockIdx.x, red);
+}
+
+// The two reductions behind the fused depthwise backward in ONE launch (they were two: 65 + 78
+// launches of 4-5 us per C3 step): blocks [0, nb_bn) finish the BatchNorm backward of the
+// depthwise INPUT from its [Rb][2][C] partials, blocks [nb_bn, ..) sum the weight-gradient
+// partials [Rw][9][C] into torch's [C,1,3,3] layout (fixed order, fp64).
+__global__ __launch_bounds__(EW_THREADS) void dw_bwd_finalize_kernel(
+    const float* __restrict__ part_bn, int Rb, double count, const float* __restrict__ mean,
+    const float* __restrict__ invstd, const float* __restrict__ gamma, float* dgamma, float* dbeta,
+    float* c0_o, float* c1_o, int C, int nb_bn, const float* __restrict__ part_w, int Rw,
+    float* __restrict__ dw_out) {
+  __shared__ double red[2][32][9];
+  if ((int)blockIdx.x < nb_bn) {
+    bn_bwd_finalize_block<float>(part_bn, Rb, count, mean, invstd, gamma, dgamma, dbeta, c0_o,
+                                 c1_o, C, blockIdx.x, red);
+    return;
+  }
   const int cx = threadIdx.x & 7, ry = threadIdx.x >> 3;
-  const int c = blockIdx.x * 8 + cx;
-  double sg, sgx;
-  reduce_two_columns<TIN>(part, R, C, c, ry, cx, red, sg, sgx);
-  if (ry != 0 || c >= C) return;
-  const double mu = mean[c], is = invstd[c];
-  const double dg = (sgx - mu * sg) * is;
-  const double g = gamma ? (double)gamma[c] : 1.0;
-  const double s = g * is;
-  const double m1 = sg / count, m2 = dg / count;
-  const double c1 = s * m2 * is;
-  if (dgamma) dgamma[c] = (float)dg;
-  if (dbeta) dbeta[c] = (float)sg;
-  c1_o[c] = (float)c1;
-  c0_o[c] = (float)(s * m1 - c1 * mu);
+  const int col = ((int)blockIdx.x - nb_bn) * 8 + cx;  // column of the [9*C] row: tap * C + c
+  const int L = 9 * C;
+  double acc = 0.0;
+  if (col < L)
+    for (int r = ry; r < Rw; r += 32) acc += (double)part_w[(long)r * L + col];
+  red[0][ry][cx] = acc;
+  __syncthreads();
+  if (ry == 0 && col < L) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) t += red[0][k][cx];
+    const int tap = col / C, c = col - tap * C;
+    dw_out[c * 9 + tap] = (float)t;
+  }
 }
 
 static int pick_cvb_log2_ew(int CV) {
@@ -691,4 +746,18 @@ extern "C" int seg_bn_bwd_finalize_p(const float* partial, long R, double count,
                        count, mean, invstd, gamma, dgamma, dbeta, c0, c1, C);
   }
   return check_launch("bn_bwd_finalize_p");
+}
+
+extern "C" int seg_dw_bwd_finalize(const float* partial_bn, int Rb, double count, const float* mean,
+                                   const float* invstd, const float* gamma, float* dgamma,
+                                   float* dbeta, float* c0, float* c1, const float* partial_w,
+                                   int Rw, float* dw_c9, int C, void* stream) {
+  using namespace seg;
+  SEG_REQUIRE(count >= 1.0 && C >= 1 && Rb >= 1 && Rw >= 1 && Rb <= 1024,
+              "dw_bwd_finalize: bad count/C/rows");
+  const int nb_bn = (C + 7) / 8;
+  hipLaunchKernelGGL(dw_bwd_finalize_kernel, dim3(nb_bn + (9 * C + 7) / 8), dim3(EW_THREADS), 0,
+                     (hipStream_t)stream, partial_bn, Rb, count, mean, invstd, gamma, dgamma, dbeta,
+                     c0, c1, C, nb_bn, partial_w, Rw, dw_c9);
+  return check_launch("dw_bwd_finalize");
 }

@@ -575,6 +575,31 @@ extern "C" int seg_dwconv3x3_wgrad(int dtype, const void* x, long ldx, int N, in
 // Fused stride-1 backward: g = relu_mask(x) * dgrad(dy), partial_w [grid_y][9][C],
 // partial_bn [grid_y][2][C] = (sum g, sum g*x_raw) (nullable).  x is the forward input (raw tensor
 // + prologue), w9c the forward taps (not reversed).
+// The same with a tensor `res` ([N,H,W,C], pitch ldr, element type of g) added to the masked data
+// gradient in the store path: g = relu_mask(x) * dgrad + res.  LDS-tiled kernel only (stride 1,
+// dilation 1) — the caller falls back to a separate add otherwise (seg_dwconv3x3_bwd_fused_add_ok).
+extern "C" int seg_dwconv3x3_bwd_fused_add_ok(int dil) { return dil == 1 ? 1 : 0; }
+
+extern "C" int seg_dwconv3x3_bwd_fused_add(int dtype, const void* dy, long lddy, const void* x,
+                                           long ldx, int N, int H, int W, int C, const float* w9c,
+                                           int w_layout, int pro_mode, const float* pro_scale,
+                                           const float* pro_shift, const void* res, long ldr,
+                                           void* g, long ldg, float* partial_w, float* partial_bn,
+                                           int grid_y, void* stream) {
+  using namespace seg;
+  SEG_REQUIRE(dtype == DT_F32 || dtype == DT_BF16, "dwconv3x3_bwd_fused_add: bad dtype %d", dtype);
+  const int tvec = dtype == DT_BF16 ? 8 : 4;
+  SEG_REQUIRE(C % tvec == 0 && ldx % tvec == 0 && lddy % tvec == 0 && ldg % tvec == 0 &&
+                  ldr % 4 == 0 && res != nullptr,
+              "dwconv3x3_bwd_fused_add: C/ld must be multiples of %d, res non-null", tvec);
+  SEG_REQUIRE(((pro_mode & PRO_AFFINE) == 0) || (pro_scale && pro_shift),
+              "dwconv3x3_bwd_fused_add: affine prologue without scale/shift");
+  SEG_REQUIRE(grid_y >= 1 && partial_w != nullptr, "dwconv3x3_bwd_fused_add: bad grid/partials");
+  return launch_dw_bwd_tiled(dtype, dy, lddy, x, ldx, N, H, W, C, w9c, w_layout, 1, pro_mode,
+                             pro_scale, pro_shift, g, ldg, partial_w, partial_bn, grid_y,
+                             (hipStream_t)stream, res, ldr);
+}
+
 extern "C" int seg_dwconv3x3_bwd_fused(int dtype, const void* dy, long lddy, const void* x,
                                        long ldx, int N, int H, int W, int C, const float* w9c,
                                        int w_layout, int dil, int pro_mode, const float* pro_scale,

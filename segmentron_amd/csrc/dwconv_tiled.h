@@ -12,7 +12,8 @@ int launch_dw_tiled(int dtype, const void* x, long ldx, int N, int H, int W, int
 int launch_dw_bwd_tiled(int dtype, const void* dy, long lddy, const void* x, long ldx, int N, int H,
                         int W, int C, const float* w, int w_layout, int dil, int pro_mode,
                         const float* sc, const float* sh, void* g, long ldg, float* partial_w,
-                        float* partial_bn, int grid_y, hipStream_t st);
+                        float* partial_bn, int grid_y, hipStream_t st,
+                        const void* res = nullptr, long ldr = 0);
 int launch_dw_wgrad_finalize(const float* partial, int R, int C, float* out, hipStream_t st);
 int launch_dw_wgrad_tiled(int dtype, const void* x, long ldx, int N, int H, int W, int C,
                           const void* dy, long lddy, int dil, int pro_mode, const float* sc,

@@ -36,6 +36,8 @@ struct DwTiledArgs {
   const float* sc; const float* sh;
   float* partial;      // fwd: [gridDim.y][2][C] statistics or null; wgrad: [gridDim.y][9][C]
   float* partial_bn;   // fused backward: [gridDim.y][2][C] or null
+  const void* res;     // fused backward: tensor ADDED to the masked data gradient before the
+  long ldr;            // store (the other gradient of a forked activation) or null
   long ldx, ldy, lddy;
   int N, H, W, C, CV, pro_mode, tiles_h, tiles_w, ntiles;
 };
@@ -405,7 +407,10 @@ __global__ __launch_bounds__(LT_THREADS, 2) void dwconv_wgrad_tiled_kernel(const
 // of the staged taps holds w[8 - r] (flipped), and the value read at tile offset (kh, kw) pairs
 // with tap 8 - r of the weight gradient.  Replaces dgrad + wgrad + bn_bwd_reduce (three passes
 // over two tensors each).
-template <typename T, int DIL>
+// RES: the second gradient of a forked activation (an Xception block input feeds the residual
+// sum AND the first separable conv, xception.py:40-42) is added in the store path — the
+// element-wise add autograd would launch for it (2 reads + 1 write of the tensor) is gone.
+template <typename T, int DIL, bool RES = false>
 __global__ __launch_bounds__(LT_THREADS, DW_BWD_OCC) void dwconv_bwd_tiled_kernel(const DwTiledArgs a) {
   // 4 channels per thread in both element types (8-byte bf16 vectors): this kernel carries nine
   // tap accumulators per channel on top of the data-gradient accumulators
@@ -516,6 +521,16 @@ __global__ __launch_bounds__(LT_THREADS, DW_BWD_OCC) void dwconv_bwd_tiled_kerne
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int i = 0; i < VEC; ++i) accg[j][i] = 0.f;
+    raw_t rres[4];
+    if (RES) {  // in flight during the tap loop
+      const T* __restrict__ R = reinterpret_cast<const T*>(a.res);
+      const int hoc = min(ho, a.H - 1), cvc = min(cv, a.CV - 1);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int wo = min(w0 + strip * 4 + j, a.W - 1);
+        rres[j] = V::load_raw(R + (((long)n * a.H + hoc) * a.W + wo) * a.ldr + cvc * VEC);
+      }
+    }
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh) {
       float wv[3][VEC];
@@ -560,7 +575,15 @@ __global__ __launch_bounds__(LT_THREADS, DW_BWD_OCC) void dwconv_bwd_tiled_kerne
             accg[j][i] = on ? accg[j][i] : 0.f;
           }
         }
-        V::store(GO + (((long)n * a.H + ho) * a.W + wo) * a.ldy + cv * VEC, accg[j]);
+        if (RES) {
+          float rr[VEC], o[VEC];
+          V::unpack_raw(rres[j], rr);
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) o[i] = accg[j][i] + rr[i];
+          V::store(GO + (((long)n * a.H + ho) * a.W + wo) * a.ldy + cv * VEC, o);
+        } else {
+          V::store(GO + (((long)n * a.H + ho) * a.W + wo) * a.ldy + cv * VEC, accg[j]);
+        }
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
           s1[i] += accg[j][i];
@@ -704,7 +727,7 @@ int launch_dw_tiled(int dtype, const void* x, long ldx, int N, int H, int W, int
   tiled_geom(a, dtype, N, H, W, C);
   a.w_layout = w_layout;
   a.x = x; a.w = w; a.y = y; a.dy = nullptr; a.sc = sc; a.sh = sh; a.partial = stat_partial;
-  a.partial_bn = nullptr;
+  a.partial_bn = nullptr; a.res = nullptr; a.ldr = 0;
   a.ldx = ldx; a.ldy = ldy; a.lddy = 0; a.pro_mode = pro_mode;
   const dim3 grid((a.CV + LT_CVB - 1) / LT_CVB, grid_y);
 #define SEG_LT(TT, DD) \
@@ -723,7 +746,7 @@ int launch_dw_wgrad_tiled(int dtype, const void* x, long ldx, int N, int H, int 
   tiled_geom(a, dtype, N, H, W, C);
   a.w_layout = 0;
   a.x = x; a.w = nullptr; a.y = nullptr; a.dy = dy; a.sc = sc; a.sh = sh; a.partial = partial;
-  a.partial_bn = nullptr;
+  a.partial_bn = nullptr; a.res = nullptr; a.ldr = 0;
   a.ldx = ldx; a.ldy = 0; a.lddy = lddy; a.pro_mode = pro_mode;
   const dim3 grid((a.CV + LT_CVB - 1) / LT_CVB, grid_y);
 #define SEG_LT(TT, DD) \
@@ -739,20 +762,23 @@ int launch_dw_wgrad_tiled(int dtype, const void* x, long ldx, int N, int H, int 
 int launch_dw_bwd_tiled(int dtype, const void* dy, long lddy, const void* x, long ldx, int N, int H,
                         int W, int C, const float* w, int w_layout, int dil, int pro_mode,
                         const float* sc, const float* sh, void* g, long ldg, float* partial_w,
-                        float* partial_bn, int grid_y, hipStream_t st) {
+                        float* partial_bn, int grid_y, hipStream_t st, const void* res, long ldr) {
   DwTiledArgs a;
   tiled_geom(a, dtype, N, H, W, C);
   a.CV = C / 4;               // HVec: 4 channels per thread in both element types
   a.w_layout = w_layout ^ 2;  // taps staged flipped (bit 1 toggles the caller's orientation)
   a.x = x; a.w = w; a.y = g; a.dy = dy; a.sc = sc; a.sh = sh;
   a.partial = partial_w; a.partial_bn = partial_bn;
+  a.res = res; a.ldr = ldr;
   a.ldx = ldx; a.ldy = ldg; a.lddy = lddy; a.pro_mode = pro_mode;
   const dim3 grid((a.CV + LT_CVB - 1) / LT_CVB, grid_y);
-#define SEG_LT(TT, DD) \
-  hipLaunchKernelGGL((dwconv_bwd_tiled_kernel<TT, DD>), grid, dim3(LT_THREADS), \
+#define SEG_LT(TT, DD, RR) \
+  hipLaunchKernelGGL((dwconv_bwd_tiled_kernel<TT, DD, RR>), grid, dim3(LT_THREADS), \
                      tiled_lds<DD>(dtype, true), st, a)
-  if (dtype == DT_BF16) { if (dil == 1) SEG_LT(bf16_t, 1); else SEG_LT(bf16_t, 2); }
-  else { if (dil == 1) SEG_LT(float, 1); else SEG_LT(float, 2); }
+  if (res != nullptr) {  // (dilation 1 only: dw_bwd_tiled_res_supported)
+    if (dtype == DT_BF16) SEG_LT(bf16_t, 1, true); else SEG_LT(float, 1, true);
+  } else if (dtype == DT_BF16) { if (dil == 1) SEG_LT(bf16_t, 1, false); else SEG_LT(bf16_t, 2, false); }
+  else { if (dil == 1) SEG_LT(float, 1, false); else SEG_LT(float, 2, false); }
 #undef SEG_LT
   return check_launch("dwconv3x3_bwd_fused (tiled)");
 }

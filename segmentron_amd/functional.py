@@ -70,6 +70,25 @@ class Act:
 _sync_group = parallel.sync_group
 
 
+class GradFork:
+    """Hand-off of one gradient between the two consumers of a forked plain activation.
+
+    An Xception block input feeds the residual sum (identity path) AND the first separable conv
+    (xception.py:36-42); autograd would add the two gradients with an element-wise kernel
+    (2 reads + 1 write of the tensor, 25 launches per C3 step).  The identity consumer's backward
+    (`_ApplyFn`) parks ITS gradient here and reports none; the depthwise backward of the other
+    consumer (`_DwFn`), which autograd can only run later (its output feeds the sum), adds the
+    parked tensor in its store path and returns the total."""
+    __slots__ = ("g",)
+
+    def __init__(self):
+        self.g = None
+
+    def take(self):
+        g, self.g = self.g, None
+        return g
+
+
 def finish_bn(bn, partial, count, mean_offset=None):
     """Turn conv-epilogue partials into a BNState (and update running stats like torch does).
     bn: nn.BatchNorm2d / nn.SyncBatchNorm module — eps / momentum / training read NOW."""
@@ -233,6 +252,7 @@ class ConvSpec:
         self.out, self.want_stats = out, want_stats
         self.partial = None
         self.drop_bias = False
+        self.fork = None
 
 
 class _ConvFn(torch.autograd.Function):
@@ -398,12 +418,22 @@ class _DwFn(torch.autograd.Function):
             # (LDS-tiled for dil <= 2; the strip version only pays on large tensors; stride 2 on
             # its own kernel, csrc/dwconv_s2.hip)
             bn = s.bn_in
+            # single-process BatchNorm on the input: the weight-gradient partials and the
+            # BatchNorm-backward partials are reduced by ONE launch (K.dw_bwd_finalize)
+            both = bn is not None and bn.group is None and (strided or tiled)
             if strided:
                 g, dW, pb = K.dwconv_bwd_fused_s2(x, dy, weight.detach().contiguous(), s.pro,
-                                                  want_bn=bn is not None)
+                                                  want_bn=bn is not None, raw_dw=both)
             elif tiled:
+                res = None
+                if bn is None and s.fork is not None and s.fork.g is not None \
+                        and K.dwconv_bwd_fused_add_ok(x, s.dil):
+                    res = s.fork.take()  # the identity path's gradient rides in the store
+                    if res.dtype != x.dtype or tuple(res.shape) != tuple(x.shape):
+                        s.fork.g, res = res, None
                 g, dW, pb = K.dwconv_bwd_fused(x, dy, weight.detach(), s.dil, s.pro,
-                                               want_bn=bn is not None, torch_layout=True)
+                                               want_bn=bn is not None, torch_layout=True,
+                                               raw_dw=both, res=res)
             else:
                 w9c = cached_pack(weight, "dw", lambda: pack_dw_weight(weight))
                 g, dW9c, pb = K.dwconv_bwd_fused(x, dy, w9c, s.dil, s.pro, want_bn=bn is not None)
@@ -411,7 +441,14 @@ class _DwFn(torch.autograd.Function):
             if bn is None:
                 dx = g  # plain / ReLU input: the masked gradient is final
             else:
-                if bn.group is None:
+                if both and pb.shape[0] <= 1024:
+                    dgamma, dbeta, c0, c1, dW = K.dw_bwd_finalize(pb, dW, bn.count, bn.mean,
+                                                                  bn.invstd, bn.gamma)
+                elif both:
+                    dW = K.dw_wgrad_finalize(dW, C)
+                    dgamma, dbeta, c0, c1 = K.bn_bwd_finalize_p(pb, bn.count, bn.mean, bn.invstd,
+                                                                bn.gamma)
+                elif bn.group is None:
                     dgamma, dbeta, c0, c1 = K.bn_bwd_finalize_p(pb, bn.count, bn.mean, bn.invstd,
                                                                 bn.gamma)
                 else:
@@ -439,12 +476,16 @@ class _DwFn(torch.autograd.Function):
                     w = cached_pack(weight, "dw", lambda: pack_dw_weight(weight))
                 g = K.dwconv_dgrad(dy, w, s.stride, s.dil, (x.shape[1], x.shape[2]))
                 dx, dgamma, dbeta = bn_input_backward(g, x, s.bn_in, s.relu, inplace=True)
+        if s.fork is not None and s.fork.g is not None and dx is not None:
+            dx = dx + s.fork.take()  # (a path whose kernel cannot add it in its store)
         return dx, dgamma, dbeta, dW, None
 
 
 class ApplySpec:
-    def __init__(self, a, r=None, chan_mul=None, post_relu=False, out=None, elem_mul=None):
+    def __init__(self, a, r=None, chan_mul=None, post_relu=False, out=None, elem_mul=None,
+                 fork=None):
         self.elem_mul = elem_mul
+        self.fork = fork
         self.bn_x, self.relu_x, self.pro_x = a.bn, a.relu, a.pro
         if r is not None:
             self.bn_r, self.relu_r, self.pro_r = r.bn, r.relu, r.pro
@@ -480,7 +521,10 @@ class _ApplyFn(torch.autograd.Function):
                                          elem_mul=s.elem_mul)
         dr = dgr = dbr = None
         if ctx.has_r and ctx.needs_input_grad[3]:
-            dr, dgr, dbr = bn_input_backward(g, r, s.bn_r, s.relu_r, None, inplace=False)
+            if s.fork is not None and s.bn_r is None and not s.relu_r:
+                s.fork.g = g  # plain identity path: handed to the fork's other consumer
+            else:
+                dr, dgr, dbr = bn_input_backward(g, r, s.bn_r, s.relu_r, None, inplace=False)
         return dx, dgx, dbx, dr, dgr, dbr, None
 
 
@@ -827,9 +871,10 @@ def conv_bn(act, conv, bn=None, out=None):
     return Act(y, finish_bn(bn, spec.partial, N * Ho * Wo, offset))
 
 
-def dwconv_bn(act, conv, bn, out=None):
+def dwconv_bn(act, conv, bn, out=None, fork=None):
     spec = ConvSpec(act, conv.stride[0], conv.padding[0], conv.dilation[0], out,
                     want_stats=bn.training or bn.running_mean is None)
+    spec.fork = fork
     assert conv.padding[0] == conv.dilation[0] and conv.kernel_size[0] == 3
     g, b = act.params
     y = _DwFn.apply(act.t, g, b, conv.weight, spec)
@@ -838,13 +883,14 @@ def dwconv_bn(act, conv, bn, out=None):
 
 
 def materialize(act, residual=None, chan_mul=None, post_relu=False, out=None, elem_mul=None,
-                force=False):
+                force=False, fork=None):
     """-> plain NHWC tensor = act(x)*chan_mul*elem_mul (+ act(residual)).  `force` copies even a
-    plain tensor (into `out`)."""
+    plain tensor (into `out`).  `fork`: see GradFork (the residual is a forked plain activation
+    whose other consumer adds this pass's gradient in its own store path)."""
     if act.bn is None and not act.relu and residual is None and chan_mul is None and out is None \
             and not post_relu and elem_mul is None and not force:
         return act.t
-    spec = ApplySpec(act, residual, chan_mul, post_relu, out, elem_mul)
+    spec = ApplySpec(act, residual, chan_mul, post_relu, out, elem_mul, fork)
     gx, bx = act.params
     if residual is None:
         return _ApplyFn.apply(act.t, gx, bx, None, None, None, spec)

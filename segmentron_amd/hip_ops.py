@@ -219,7 +219,33 @@ def dwconv_dgrad(dy, w9c, stride, dil, in_hw, flipped=True):
     return dx
 
 
-def dwconv_bwd_fused(x, dy, w, dil, pro=None, want_bn=False, torch_layout=False):
+def dw_wgrad_finalize(pw, C):
+    """weight-gradient partials [R, 9C] -> dW [C,1,3,3]."""
+    dW = torch.empty((C, 1, 3, 3), dtype=torch.float32, device=pw.device)
+    LIB.call("seg_dwconv3x3_wgrad_finalize", _p(pw), pw.shape[0], C, _p(dW), _stream())
+    return dW
+
+
+def dw_bwd_finalize(pb, pw, count, mean, invstd, gamma):
+    """Both reductions behind a fused depthwise backward in one launch: BatchNorm-backward
+    partials pb [Rb, 2C] -> (dgamma, dbeta, c0, c1) and weight-gradient partials pw [Rw, 9C] ->
+    dW [C,1,3,3]."""
+    C = mean.numel()
+    out = torch.empty((4, C), dtype=torch.float32, device=mean.device)
+    dW = torch.empty((C, 1, 3, 3), dtype=torch.float32, device=mean.device)
+    LIB.call("seg_dw_bwd_finalize", _p(pb), pb.shape[0], float(count), _p(mean), _p(invstd),
+             _p(gamma), _p(out[0]), _p(out[1]), _p(out[2]), _p(out[3]), _p(pw), pw.shape[0],
+             _p(dW), C, _stream())
+    return out[0], out[1], out[2], out[3], dW
+
+
+def dwconv_bwd_fused_add_ok(x, dil):
+    """Can the fused depthwise backward add a second gradient in its store path?"""
+    return bool(LIB.query("seg_dwconv3x3_bwd_fused_add_ok", int(dil)))
+
+
+def dwconv_bwd_fused(x, dy, w, dil, pro=None, want_bn=False, torch_layout=False, raw_dw=False,
+                     res=None):
     """stride-1 depthwise backward in one pass: returns (g masked by the prologue's ReLU,
     dW fp32 [9, C] (or [C,1,3,3] with torch_layout), bn_partial fp32 [gy, 2C] | None).
     w: tap-major [9, C] or (dil <= 2) the [C,1,3,3] parameter itself."""
@@ -234,8 +260,16 @@ def dwconv_bwd_fused(x, dy, w, dil, pro=None, want_bn=False, torch_layout=False)
     gy = LIB.query("seg_dwconv_grid_y", _DT[x.dtype], C, N, H, W, 1, dil, 1)
     pw = torch.empty((gy, 9 * C), dtype=torch.float32, device=x.device)
     pb = torch.empty((gy, 2 * C), dtype=torch.float32, device=x.device) if want_bn else None
-    LIB.call("seg_dwconv3x3_bwd_fused", _DT[x.dtype], _p(dy), lddy, _p(x), ldx, N, H, W, C,
-             _p(w), layout, dil, mode, _p(ps), _p(pt), _p(g), C, _p(pw), _p(pb), gy, _stream())
+    if res is not None:  # g = masked dgrad + res (the other gradient of a forked activation)
+        assert dil == 1 and tuple(res.shape) == (N, H, W, C) and res.dtype == x.dtype
+        LIB.call("seg_dwconv3x3_bwd_fused_add", _DT[x.dtype], _p(dy), lddy, _p(x), ldx, N, H, W,
+                 C, _p(w), layout, mode, _p(ps), _p(pt), _p(res), nhwc(res)[4], _p(g), C, _p(pw),
+                 _p(pb), gy, _stream())
+    else:
+        LIB.call("seg_dwconv3x3_bwd_fused", _DT[x.dtype], _p(dy), lddy, _p(x), ldx, N, H, W, C,
+                 _p(w), layout, dil, mode, _p(ps), _p(pt), _p(g), C, _p(pw), _p(pb), gy, _stream())
+    if raw_dw:  # the caller reduces pw together with pb (dw_bwd_finalize)
+        return g, pw, pb
     if torch_layout:
         dW = torch.empty((C, 1, 3, 3), dtype=torch.float32, device=x.device)
         LIB.call("seg_dwconv3x3_wgrad_finalize", _p(pw), gy, C, _p(dW), _stream())
@@ -243,7 +277,7 @@ def dwconv_bwd_fused(x, dy, w, dil, pro=None, want_bn=False, torch_layout=False)
     return g, colsum(pw, f64=False).view(9, C), pb
 
 
-def dwconv_bwd_fused_s2(x, dy, w, pro=None, want_bn=False):
+def dwconv_bwd_fused_s2(x, dy, w, pro=None, want_bn=False, raw_dw=False):
     """stride-2 (pad 1, dil 1) depthwise backward in one pass over dy and x: returns (g masked by
     the prologue's ReLU, dW fp32 [C,1,3,3], bn_partial fp32 [gy, 2C] | None).  w: the [C,1,3,3]
     parameter."""
@@ -257,6 +291,8 @@ def dwconv_bwd_fused_s2(x, dy, w, pro=None, want_bn=False):
     pb = torch.empty((gy, 2 * C), dtype=torch.float32, device=x.device) if want_bn else None
     LIB.call("seg_dwconv3x3_s2_bwd_fused", _DT[x.dtype], _p(dy), lddy, _p(x), ldx, N, H, W, C,
              _p(w), mode, _p(ps), _p(pt), _p(g), C, _p(pw), _p(pb), gy, _stream())
+    if raw_dw:
+        return g, pw, pb
     dW = torch.empty((C, 1, 3, 3), dtype=torch.float32, device=x.device)
     LIB.call("seg_dwconv3x3_wgrad_finalize", _p(pw), gy, C, _p(dW), _stream())
     return g, dW, pb

@@ -1,5 +1,6 @@
 """Xception65 backbone — module tree / state_dict of
 segmentron/models/backbones/xception.py:10-165, forward on HIP kernels."""
+import torch
 import torch.nn as nn
 
 from ... import functional as F
@@ -37,14 +38,21 @@ class XceptionBlock(nn.Module):
         self.last_inp_channels = c[3]
 
     def forward(self, inputs):
-        sc1 = self.sep_conv1(inputs)
+        # "sum" blocks: `inputs` (a plain tensor) feeds the residual sum and sep_conv1 — the
+        # identity path's gradient is handed to sep_conv1's depthwise backward, which adds it in
+        # its store path (functional.GradFork) instead of autograd's element-wise add
+        fork = None
+        if (self.skip_connection_type == "sum" and self.relu_first and inputs.bn is None
+                and not inputs.relu and torch.is_grad_enabled() and inputs.t.requires_grad):
+            fork = F.GradFork()
+        sc1 = self.sep_conv1(inputs, fork=fork) if fork is not None else self.sep_conv1(inputs)
         sc2 = self.sep_conv2(sc1)
         residual = self.sep_conv3(sc2)
         if self.skip_connection_type == "conv":
             shortcut = F.conv_bn(inputs, self.conv, self.bn)
             outputs = F.Act(F.materialize(residual, residual=shortcut))
         elif self.skip_connection_type == "sum":
-            outputs = F.Act(F.materialize(residual, residual=inputs))
+            outputs = F.Act(F.materialize(residual, residual=inputs, fork=fork))
         else:
             outputs = residual
         return (outputs, sc2) if self.low_feat else outputs

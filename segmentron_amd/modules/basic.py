@@ -36,11 +36,12 @@ class SeparableConv2d(nn.Module):
             layers.append(("relu2", nn.ReLU(inplace=True)))
         self.block = nn.Sequential(OrderedDict(layers))
 
-    def forward(self, act):
+    def forward(self, act, fork=None):
         b = self.block
         if self.relu_first:
-            d = F.dwconv_bn(act.with_relu(), b.depthwise, b.bn_depth)
+            d = F.dwconv_bn(act.with_relu(), b.depthwise, b.bn_depth, fork=fork)
             return F.conv_bn(d, b.pointwise, b.bn_point)
+        assert fork is None
         d = F.dwconv_bn(act, b.depthwise, b.bn_depth)
         d.relu = True
         p = F.conv_bn(d, b.pointwise, b.bn_point)

@@ -71,7 +71,7 @@ def _compare(name, dtype, got, ref64, emu, bars, ref32=None):
     backward chains amplify fp32 rounding to 1e-4..1e-3 in ANY evaluation order (the CPU fp32
     oracle's own dx sits 4e-4 from float64 on the 728-channel block)."""
     worst = 0.0
-    stats = {}
+    stats, fails = {}, []
     # gradients that are identically zero in exact arithmetic (the bias of a BatchNorm / conv
     # in front of a training-mode BatchNorm) come out as 0 here and as 1e-13 noise in the
     # float64 oracle: measure every parameter gradient against max(its norm, 1e-6 x the largest
@@ -86,6 +86,10 @@ def _compare(name, dtype, got, ref64, emu, bars, ref32=None):
             # almost invariant to gamma (exactly for beta = 0: relu(g*x) = g*relu(x) and the next
             # BN divides the scale out again), so dgamma is the tiny residual of a cancelling
             # sum — measure both gradients of a layer against the larger of their two norms
+            pat = SIBLINGS.get(name, {}).get(key)
+            if pat is not None:
+                den = max([den] + [ref64[pat % i].double().norm().item() for i in range(8)
+                                   if (pat % i) in ref64])
             for a_, b_ in ((".weight", ".bias"), (".bias", ".weight")):
                 sib = key[:-len(a_)] + b_ if key.endswith(a_) else None
                 if sib in ref64 and ref64[sib].dim() == 1 and ref64[key].dim() == 1:
@@ -114,15 +118,18 @@ def _compare(name, dtype, got, ref64, emu, bars, ref32=None):
             cls = "y" if k == "y" else ("dx/dW" if (k.startswith("dx") or ref64[k].dim() >= 2)
                                         else "gamma/beta")
             stats[cls] = max(stats.get(cls, 0.0), ee)
-            assert ee <= bar, ("%s %s bf16: L2-rel %.3e vs bf16 emulation > %.1e "
-                               "(max-normalised %.3e; emulation itself is %.3e from fp64)"
-                               % (name, k, ee, bar, _mx(g, e_k), floor))
-            assert e64 <= 2.0 * floor + bar, (
-                "%s %s bf16: L2-rel %.3e vs fp64 oracle (emulation: %.3e)" % (name, k, e64, floor))
+            if ee > bar:
+                fails.append("%s %s bf16: L2-rel %.3e vs bf16 emulation > %.1e (max-normalised "
+                             "%.3e; emulation itself is %.3e from fp64)"
+                             % (name, k, ee, bar, _mx(g, e_k), floor))
+            if e64 > 2.0 * floor + bar:
+                fails.append("%s %s bf16: L2-rel %.3e vs fp64 oracle (emulation: %.3e)"
+                             % (name, k, e64, floor))
             worst = max(worst, ee)
     if stats:
         print("PARITY composite %s bf16 L2-rel vs emulation: %s" % (
             name, ", ".join("%s %.2e" % kv for kv in sorted(stats.items()))))
+    assert not fails, "\n".join(fails)
     return worst
 
 
@@ -160,7 +167,20 @@ def _oracle_run(fn, inputs, dy, dtype_ref, dtype=None):
 
 # bf16 data / weight gradients vs the emulation: 3e-2 unless listed here with
 # the measured reason
-DXDW_BAR = {}
+DXDW_BAR = {
+    # three stacked separable convs (ReLU after each BN) resp. ASPP + decoder + classifier: every
+    # intermediate gradient is stored in bf16 and passes 6-9 train-mode BatchNorm backwards; the
+    # emulation's backward is exact arithmetic.  Measured r03: dx 3.7e-2 / 5.1e-2, every dW below
+    # 3e-2 / 5.6e-2 (profiles/r03_parity.txt)
+    "xception_exit_1536_2048": 5e-2,
+    "deeplab_head": 7e-2,
+}
+# Gradients that are residuals of an (almost) exact cancellation and are therefore measured
+# against the norm of their siblings: PSP's bin-1 branch normalises N*1*1 = 2 samples per channel
+# in training mode — BatchNorm of two samples is +-gamma/sqrt(1 + eps/var) + beta whatever the
+# convolution computed, so d loss / d conv weight is ~0 up to the eps term (the emulation itself
+# sits 0.39 from the fp64 oracle there).
+SIBLINGS = {"psp_head_2048": {"d:psp.convs.0.conv.weight": "d:psp.convs.%d.conv.weight"}}
 
 CASES = ["sep_relu_first_728", "sep_relu_last_1536", "sep_stride2_256_728",
          "xception_middle_728", "xception_entry_conv_256_728", "xception_exit_1536_2048",
@@ -262,10 +282,19 @@ def test_composite_teacher_forced(case, dtype, c3_cfg):
         def flat(ts):  # one NCHW "image" [N, sum_i C_i*H_i*W_i, 1, 1]
             return torch.cat([t.reshape(t.shape[0], -1) for t in ts], 1)[:, :, None, None]
 
+        class _DenseGrad(torch.autograd.Function):  # the kernels take dense NHWC gradients
+            @staticmethod
+            def forward(ctx, t):
+                return t.view_as(t)
+
+            @staticmethod
+            def backward(ctx, g):
+                return g.contiguous()
+
         def hip_fn(*acts):
             ys = mod(list(acts))
-            return torch.cat([F.materialize(y).permute(0, 3, 1, 2).reshape(N, -1) for y in ys],
-                             1)[:, None, None, :]
+            return torch.cat([_DenseGrad.apply(F.materialize(y)).permute(0, 3, 1, 2).reshape(N, -1)
+                              for y in ys], 1)[:, None, None, :]
         ora = lambda net: (lambda *xs: flat(torch_ref._hr_module(net, list(xs), PFX)))
         emu = lambda net: (lambda *xs: flat([y.val() for y in
                                              net.hr_module([_A(x) for x in xs], PFX)]))
