@@ -118,6 +118,10 @@ def _compare(name, dtype, got, ref64, emu, bars, ref32=None):
             cls = "y" if k == "y" else ("dx/dW" if (k.startswith("dx") or ref64[k].dim() >= 2)
                                         else "gamma/beta")
             stats[cls] = max(stats.get(cls, 0.0), ee)
+            if SIBLINGS.get(name, {}).get(k) is not None:
+                # ill-conditioned by construction: its own sensitivity to bf16 rounding (the
+                # emulation's distance to fp64, same normalisation) sets the bar
+                bar = max(bar, 2.0 * floor + bars[3])
             if ee > bar:
                 fails.append("%s %s bf16: L2-rel %.3e vs bf16 emulation > %.1e (max-normalised "
                              "%.3e; emulation itself is %.3e from fp64)"
@@ -174,12 +178,17 @@ DXDW_BAR = {
     # 3e-2 / 5.6e-2 (profiles/r03_parity.txt)
     "xception_exit_1536_2048": 5e-2,
     "deeplab_head": 7e-2,
+    # two BasicBlocks per branch + the cross-resolution fuse: 16-channel tensors at 256x512, four
+    # bf16-stored gradient hops per weight; measured 3.4e-2 on branches.0.0.conv2.weight
+    "hr_module_4": 5e-2,
 }
 # Gradients that are residuals of an (almost) exact cancellation and are therefore measured
 # against the norm of their siblings: PSP's bin-1 branch normalises N*1*1 = 2 samples per channel
 # in training mode — BatchNorm of two samples is +-gamma/sqrt(1 + eps/var) + beta whatever the
-# convolution computed, so d loss / d conv weight is ~0 up to the eps term (the emulation itself
-# sits 0.39 from the fp64 oracle there).
+# convolution computed, so d loss / d conv weight carries the factor eps / (delta^2 + eps) with
+# delta the difference of two bf16-rounded pooled responses: one flipped rounding of a pooled
+# input moves it by tens of percent (the emulation itself sits 0.39 from the fp64 oracle there by
+# its own norm, 0.11 by its siblings').  Bar for it: 2 x that floor + the dx/dW bar.
 SIBLINGS = {"psp_head_2048": {"d:psp.convs.0.conv.weight": "d:psp.convs.%d.conv.weight"}}
 
 CASES = ["sep_relu_first_728", "sep_relu_last_1536", "sep_stride2_256_728",
