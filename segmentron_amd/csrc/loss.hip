@@ -53,15 +53,52 @@ __device__ __forceinline__ void ce_logits(const CeArgs& a, int n, int h, int w, 
   taps(a.sh, h, a.Hi, a.align, h0, h1, lh);
   taps(a.sw, w, a.Wi, a.align, w0, w1, lw);
   const long base = (long)n * a.Hi * a.Wi;
-  float f00[NC], f01[NC], f10[NC], f11[NC];
-  ce_load_pixel<T, NC>(X + (base + (long)h0 * a.Wi + w0) * a.ld, a.ld, f00);
-  ce_load_pixel<T, NC>(X + (base + (long)h0 * a.Wi + w1) * a.ld, a.ld, f01);
-  ce_load_pixel<T, NC>(X + (base + (long)h1 * a.Wi + w0) * a.ld, a.ld, f10);
-  ce_load_pixel<T, NC>(X + (base + (long)h1 * a.Wi + w1) * a.ld, a.ld, f11);
+  // the four taps stay PACKED until they are combined, one channel vector at a time: 4 * NC
+  // unpacked floats alive at once (96 registers for 24 classes) cost the backward kernel its
+  // occupancy; all loads are still issued before the first use
+  constexpr int VEC = Vec<T>::N, NV = NC / VEC;
+  const T* __restrict__ p00 = X + (base + (long)h0 * a.Wi + w0) * a.ld;
+  const T* __restrict__ p01 = X + (base + (long)h0 * a.Wi + w1) * a.ld;
+  const T* __restrict__ p10 = X + (base + (long)h1 * a.Wi + w0) * a.ld;
+  const T* __restrict__ p11 = X + (base + (long)h1 * a.Wi + w1) * a.ld;
   const float h0l = 1.f - lh, w0l = 1.f - lw;
+  // one vector ahead: the next vector's four loads are in flight while this one is combined
+  uint4 q00 = ldg16(p00), q01 = ldg16(p01), q10 = ldg16(p10), q11 = ldg16(p11);
 #pragma unroll
-  for (int c = 0; c < NC; ++c)
-    z[c] = h0l * (w0l * f00[c] + lw * f01[c]) + lh * (w0l * f10[c] + lw * f11[c]);
+  for (int v = 0; v < NV; ++v) {
+    const uint4 c00 = q00, c01 = q01, c10 = q10, c11 = q11;
+    if (v + 1 < NV) {
+      const int off = ((v + 1) * VEC < a.ld) ? (v + 1) * VEC : 0;  // beyond the pitch: masked below
+      q00 = ldg16(p00 + off); q01 = ldg16(p01 + off);
+      q10 = ldg16(p10 + off); q11 = ldg16(p11 + off);
+    }
+    const bool in = v * VEC < a.ld;
+    if constexpr (sizeof(T) == 2) {
+      // bf16: two channels per dword, combined pair by pair (8 temporaries instead of 32)
+      const unsigned d00[4] = {c00.x, c00.y, c00.z, c00.w}, d01[4] = {c01.x, c01.y, c01.z, c01.w};
+      const unsigned d10[4] = {c10.x, c10.y, c10.z, c10.w}, d11[4] = {c11.x, c11.y, c11.z, c11.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float a0 = __uint_as_float(d00[k] << 16), a1 = __uint_as_float(d00[k] & 0xFFFF0000u);
+        const float b0 = __uint_as_float(d01[k] << 16), b1 = __uint_as_float(d01[k] & 0xFFFF0000u);
+        const float e0 = __uint_as_float(d10[k] << 16), e1 = __uint_as_float(d10[k] & 0xFFFF0000u);
+        const float g0 = __uint_as_float(d11[k] << 16), g1 = __uint_as_float(d11[k] & 0xFFFF0000u);
+        const float t0 = h0l * (w0l * a0 + lw * b0) + lh * (w0l * e0 + lw * g0);
+        const float t1 = h0l * (w0l * a1 + lw * b1) + lh * (w0l * e1 + lw * g1);
+        z[v * VEC + 2 * k] = in ? t0 : 0.f;
+        z[v * VEC + 2 * k + 1] = in ? t1 : 0.f;
+      }
+    } else {
+      float f00[VEC], f01[VEC], f10[VEC], f11[VEC];
+      Vec<T>::unpack(c00, f00); Vec<T>::unpack(c01, f01);
+      Vec<T>::unpack(c10, f10); Vec<T>::unpack(c11, f11);
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) {
+        const float t = h0l * (w0l * f00[k] + lw * f01[k]) + lh * (w0l * f10[k] + lw * f11[k]);
+        z[v * VEC + k] = in ? t : 0.f;
+      }
+    }
+  }
 }
 
 // forward: partial[block] = (sum of -log p_target over the block's valid pixels, valid count)
@@ -132,17 +169,22 @@ __global__ void ce_finalize_kernel(const double* partial, int nblocks, float* ou
   }
 }
 
-// backward: one block per LOW-resolution tile of LT x LT pixels.  Phase 1: the block evaluates
-// dz = (softmax - onehot) for every output pixel that touches its tile (redundantly with the
-// neighbouring tiles at the borders) into LDS; phase 2: every (pixel, channel) of the tile
-// gathers its sum over those outputs in a fixed order — separably: first along w, then along h.
+// backward: one block per LOW-resolution tile of LT x LT pixels.  The output rows that touch the
+// tile are processed in CHUNKS of CH rows.  Per chunk — phase 1: dz = (softmax - onehot) of the
+// chunk's output pixels (redundantly with the neighbouring tiles at the borders) into LDS;
+// phase 2a: reduced along w with the tile columns' interpolation weights; phase 2b: every
+// (pixel, channel) of the tile adds its weighted rows of the chunk to a register accumulator, in
+// ascending row order — the same fixed summation order as a whole-footprint gather.
 // LT = low-res tile edge, HT_MAX = most output rows / columns that can touch LT low-res rows at
-// up to 4.1x upsampling: (LT + 1.5) * 4.1 + 5.  LDS: NC * HT_MAX * (HT_MAX + LT) floats.
+// up to 4.1x upsampling: (LT + 1.5) * 4.1 + 5.  LDS: NC * CH * (HT_MAX + LT) floats — the first
+// version staged the whole NC x HT_MAX x HT_MAX footprint (137 KiB: ONE 512-thread block per CU,
+// 7396 blocks in 29 rounds of 17 us = 0.5 ms per C3 step, the largest single kernel of the step);
+// with 12-row chunks three blocks share a CU and overlap each other's load / LDS phases.
 constexpr int CE_BWD_THREADS = 512;
-template <typename T, int NC, int LT, int HT_MAX>
-__global__ __launch_bounds__(CE_BWD_THREADS) void ce_bwd_kernel(const CeArgs a, const float* gscale,
-                                                                const float* gout, void* dlo,
-                                                                long lddlo) {
+template <typename T, int NC, int LT, int HT_MAX, int CH>
+__global__ __launch_bounds__(CE_BWD_THREADS, 4) void ce_bwd_kernel(const CeArgs a, const float* gscale,
+                                                                   const float* gout, void* dlo,
+                                                                   long lddlo) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_ce[];
   const int tiles_w = (a.Wi + LT - 1) / LT, tiles_h = (a.Hi + LT - 1) / LT;
   const int tw = blockIdx.x % tiles_w, th = (blockIdx.x / tiles_w) % tiles_h;
@@ -156,9 +198,9 @@ __global__ __launch_bounds__(CE_BWD_THREADS) void ce_bwd_kernel(const CeArgs a, 
   cand_range(a.sw, j0, a.W, a.align, wlo, t1);
   cand_range(a.sw, j1, a.W, a.align, t0, whi);
   const int nh = hhi - hlo + 1, nw = whi - wlo + 1;  // <= HT_MAX (checked on the host)
-  float* dz = reinterpret_cast<float*>(smem_ce);                  // [NC][nh][nw]
-  float* tmp = dz + (long)NC * HT_MAX * HT_MAX;                   // [NC][nh][LT]
-  float* wth = tmp + (long)NC * HT_MAX * LT;                      // [HT_MAX][LT] row weights
+  float* dz = reinterpret_cast<float*>(smem_ce);                  // [NC][CH][HT_MAX]
+  float* tmp = dz + (long)NC * CH * HT_MAX;                       // [NC][CH][LT]
+  float* wth = tmp + (long)NC * CH * LT;                          // [HT_MAX][LT] row weights
   float* wtw = wth + HT_MAX * LT;                                 // [HT_MAX][LT] column weights
   int* rng = reinterpret_cast<int*>(wtw + HT_MAX * LT);           // [2][LT][2] candidate ranges
   const float g = gout[0] * gscale[1];  // dLoss * (1 / valid count)
@@ -182,80 +224,106 @@ __global__ __launch_bounds__(CE_BWD_THREADS) void ce_bwd_kernel(const CeArgs a, 
     rng[(which * LT + ii) * 2] = clo;
     rng[(which * LT + ii) * 2 + 1] = chi;
   }
-  // ---- phase 1
-  for (int p = threadIdx.x; p < nh * nw; p += CE_BWD_THREADS) {
-    const int hh = p / nw, ww = p - hh * nw;
-    const int h = hlo + hh, w = wlo + ww;
-    const long t = a.target[((long)n * a.H + h) * a.W + w];
-    float z[NC];
-    if (t != a.ignore && t >= 0 && t < a.C) {
-      ce_logits<T, NC>(a, n, h, w, z);
-      float m = z[0];
-#pragma unroll
-      for (int c = 1; c < NC; ++c) m = (c < a.C) ? fmaxf(m, z[c]) : m;
-      float s = 0.f;
-#pragma unroll
-      for (int c = 0; c < NC; ++c) {
-        z[c] = (c < a.C) ? expf(z[c] - m) : 0.f;
-        s += z[c];
-      }
-      const float inv = 1.f / s;
-#pragma unroll
-      for (int c = 0; c < NC; ++c) z[c] = (z[c] * inv - (c == (int)t ? 1.f : 0.f)) * g;
-    } else {
-#pragma unroll
-      for (int c = 0; c < NC; ++c) z[c] = 0.f;
-    }
-#pragma unroll
-    for (int c = 0; c < NC; ++c) dz[((long)c * HT_MAX + hh) * HT_MAX + ww] = z[c];
-  }
-  __syncthreads();
-  // ---- phase 2a: along w.  tmp[c][hh][jj] = sum_ww wtw[ww][jj] * dz[c][hh][ww]
   const int lw_n = j1 - j0 + 1, lh_n = i1 - i0 + 1;
-  for (int p = threadIdx.x; p < a.C * nh * LT; p += CE_BWD_THREADS) {
-    const int jj = p % LT, hh = (p / LT) % nh, c = p / (LT * nh);
-    float acc = 0.f;
-    if (jj < lw_n) {
-      const int clo = rng[(LT + jj) * 2], chi = rng[(LT + jj) * 2 + 1];
-      const float* row = dz + ((long)c * HT_MAX + hh) * HT_MAX;
-      for (int ww = clo; ww <= chi; ++ww) acc = fmaf(wtw[ww * LT + jj], row[ww], acc);
+  // this thread's (tile pixel, channel) items of phase 2b: p = (ii * LT + jj) * lddlo + c
+  constexpr int MAXI = (LT * LT * 32 + CE_BWD_THREADS - 1) / CE_BWD_THREADS;
+  const int ld = (int)lddlo, nitems = LT * LT * ld;
+  float acc[MAXI];
+#pragma unroll
+  for (int k = 0; k < MAXI; ++k) acc[k] = 0.f;
+
+  for (int r0 = 0; r0 < nh; r0 += CH) {
+    const int rows = min(CH, nh - r0);
+    // ---- phase 1: the chunk's output pixels (at most one per thread: rows * nw <= 432)
+#pragma unroll 1
+    for (int p = threadIdx.x; p < rows * nw; p += CE_BWD_THREADS) {
+      const int hh = p / nw, ww = p - hh * nw;
+      const int h = hlo + r0 + hh, w = wlo + ww;
+      const long t = a.target[((long)n * a.H + h) * a.W + w];
+      float z[NC];
+      if (t != a.ignore && t >= 0 && t < a.C) {
+        ce_logits<T, NC>(a, n, h, w, z);
+        float m = z[0];
+#pragma unroll
+        for (int c = 1; c < NC; ++c) m = (c < a.C) ? fmaxf(m, z[c]) : m;
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          z[c] = (c < a.C) ? expf(z[c] - m) : 0.f;
+          s += z[c];
+        }
+        const float inv = 1.f / s;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) z[c] = (z[c] * inv - (c == (int)t ? 1.f : 0.f)) * g;
+      } else {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) z[c] = 0.f;
+      }
+#pragma unroll
+      for (int c = 0; c < NC; ++c) dz[((long)c * CH + hh) * HT_MAX + ww] = z[c];
     }
-    tmp[((long)c * HT_MAX + hh) * LT + jj] = acc;
+    __syncthreads();  // (also orders the weight tables / the previous chunk's phase 2b)
+    // ---- phase 2a: along w.  tmp[c][hh][jj] = sum_ww wtw[ww][jj] * dz[c][hh][ww]
+    for (int p = threadIdx.x; p < a.C * rows * LT; p += CE_BWD_THREADS) {
+      const int jj = p % LT, hh = (p / LT) % rows, c = p / (LT * rows);
+      float v = 0.f;
+      if (jj < lw_n) {
+        const int clo = rng[(LT + jj) * 2], chi = rng[(LT + jj) * 2 + 1];
+        const float* row = dz + ((long)c * CH + hh) * HT_MAX;
+        for (int ww = clo; ww <= chi; ++ww) v = fmaf(wtw[ww * LT + jj], row[ww], v);
+      }
+      tmp[((long)c * CH + hh) * LT + jj] = v;
+    }
+    __syncthreads();
+    // ---- phase 2b: along h, this chunk's rows (ascending: the whole sum runs in row order)
+#pragma unroll
+    for (int k = 0; k < MAXI; ++k) {
+      const int p = threadIdx.x + k * CE_BWD_THREADS;
+      if (p < nitems) {
+        const int c = p % ld, jj = (p / ld) % LT, ii = p / (ld * LT);
+        if (c < a.C && ii < lh_n && jj < lw_n) {
+          const int clo = max(rng[ii * 2], r0), chi = min(rng[ii * 2 + 1], r0 + rows - 1);
+          float v = acc[k];
+          for (int hh = clo; hh <= chi; ++hh)
+            v = fmaf(wth[hh * LT + ii], tmp[((long)c * CH + (hh - r0)) * LT + jj], v);
+          acc[k] = v;
+        }
+      }
+    }
   }
-  __syncthreads();
-  // ---- phase 2b: along h, and store (channels >= C are written as zero padding)
+  // ---- store (channels >= C are written as zero padding)
   T* __restrict__ D = reinterpret_cast<T*>(dlo);
-  for (int p = threadIdx.x; p < lh_n * lw_n * (int)lddlo; p += CE_BWD_THREADS) {
-    const int c = p % (int)lddlo, jj = (p / (int)lddlo) % lw_n, ii = p / ((int)lddlo * lw_n);
-    float acc = 0.f;
-    if (c < a.C) {
-      const int clo = rng[ii * 2], chi = rng[ii * 2 + 1];
-      for (int hh = clo; hh <= chi; ++hh)
-        acc = fmaf(wth[hh * LT + ii], tmp[((long)c * HT_MAX + hh) * LT + jj], acc);
+#pragma unroll
+  for (int k = 0; k < MAXI; ++k) {
+    const int p = threadIdx.x + k * CE_BWD_THREADS;
+    if (p < nitems) {
+      const int c = p % ld, jj = (p / ld) % LT, ii = p / (ld * LT);
+      if (ii < lh_n && jj < lw_n)
+        Vec<T>::store1(D + (((long)n * a.Hi + i0 + ii) * a.Wi + j0 + jj) * lddlo + c, acc[k]);
     }
-    Vec<T>::store1(D + (((long)n * a.Hi + i0 + ii) * a.Wi + j0 + jj) * lddlo + c, acc);
   }
 }
 
-template <int NC, int LT, int HT_MAX> constexpr size_t ce_bwd_lds() {
-  return ((size_t)NC * HT_MAX * HT_MAX + (size_t)NC * HT_MAX * LT + 2 * (size_t)HT_MAX * LT) *
+template <int NC, int LT, int HT_MAX, int CH> constexpr size_t ce_bwd_lds() {
+  return ((size_t)NC * CH * HT_MAX + (size_t)NC * CH * LT + 2 * (size_t)HT_MAX * LT) *
              sizeof(float) + 4 * (size_t)LT * sizeof(int);
 }
-// <= 24 classes: 6 x 6 tiles (137 KiB of LDS); <= 32 classes: 4 x 4 tiles (112 KiB)
-constexpr int CE_LT24 = 6, CE_HT24 = 36, CE_LT32 = 4, CE_HT32 = 28;
-static_assert(ce_bwd_lds<24, CE_LT24, CE_HT24>() <= 160 * 1024, "LDS budget");
-static_assert(ce_bwd_lds<32, CE_LT32, CE_HT32>() <= 160 * 1024, "LDS budget");
+// <= 24 classes: 6 x 6 tiles, 12-row chunks (49 KiB of LDS); <= 32 classes: 4 x 4 tiles, 10-row
+// chunks (41 KiB): three blocks per CU
+constexpr int CE_LT24 = 6, CE_HT24 = 36, CE_CH24 = 12, CE_LT32 = 4, CE_HT32 = 28, CE_CH32 = 10;
+static_assert(ce_bwd_lds<24, CE_LT24, CE_HT24, CE_CH24>() <= 53 * 1024, "LDS budget (3 blocks/CU)");
+static_assert(ce_bwd_lds<32, CE_LT32, CE_HT32, CE_CH32>() <= 53 * 1024, "LDS budget (3 blocks/CU)");
 
-template <typename T, int NC, int LT, int HT>
+template <typename T, int NC, int LT, int HT, int CH>
 static int launch_ce_bwd(int blocks, hipStream_t st, const CeArgs& a, const float* loss_out,
                          const float* grad_out, void* dlo, long lddlo) {
-  constexpr size_t lds = ce_bwd_lds<NC, LT, HT>();
+  constexpr size_t lds = ce_bwd_lds<NC, LT, HT, CH>();
   static const int once = (int)hipFuncSetAttribute(
-      reinterpret_cast<const void*>(&ce_bwd_kernel<T, NC, LT, HT>),
+      reinterpret_cast<const void*>(&ce_bwd_kernel<T, NC, LT, HT, CH>),
       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   SEG_REQUIRE(once == 0, "upsample_ce_bwd: cannot reserve %d bytes of LDS", (int)lds);
-  hipLaunchKernelGGL((ce_bwd_kernel<T, NC, LT, HT>), dim3(blocks), dim3(CE_BWD_THREADS), lds, st, a,
-                     loss_out, grad_out, dlo, lddlo);
+  hipLaunchKernelGGL((ce_bwd_kernel<T, NC, LT, HT, CH>), dim3(blocks), dim3(CE_BWD_THREADS), lds, st,
+                     a, loss_out, grad_out, dlo, lddlo);
   return 0;
 }
 
@@ -319,11 +387,11 @@ extern "C" int seg_upsample_ce_bwd(int dtype, const void* lo, long ld, int N, in
   const int blocks = N * ((Hi + lt - 1) / lt) * ((Wi + lt - 1) / lt);
   int rc;
   if (dtype == DT_BF16) {
-    rc = nc == 24 ? launch_ce_bwd<bf16_t, 24, CE_LT24, CE_HT24>(blocks, st, a, loss_out, grad_out, dlo, lddlo)
-                  : launch_ce_bwd<bf16_t, 32, CE_LT32, CE_HT32>(blocks, st, a, loss_out, grad_out, dlo, lddlo);
+    rc = nc == 24 ? launch_ce_bwd<bf16_t, 24, CE_LT24, CE_HT24, CE_CH24>(blocks, st, a, loss_out, grad_out, dlo, lddlo)
+                  : launch_ce_bwd<bf16_t, 32, CE_LT32, CE_HT32, CE_CH32>(blocks, st, a, loss_out, grad_out, dlo, lddlo);
   } else {
-    rc = nc == 24 ? launch_ce_bwd<float, 24, CE_LT24, CE_HT24>(blocks, st, a, loss_out, grad_out, dlo, lddlo)
-                  : launch_ce_bwd<float, 32, CE_LT32, CE_HT32>(blocks, st, a, loss_out, grad_out, dlo, lddlo);
+    rc = nc == 24 ? launch_ce_bwd<float, 24, CE_LT24, CE_HT24, CE_CH24>(blocks, st, a, loss_out, grad_out, dlo, lddlo)
+                  : launch_ce_bwd<float, 32, CE_LT32, CE_HT32, CE_CH32>(blocks, st, a, loss_out, grad_out, dlo, lddlo);
   }
   if (rc) return rc;
   return check_launch("upsample_ce_bwd");

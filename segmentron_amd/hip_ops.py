@@ -461,8 +461,14 @@ def fold_bwd_reduce(w2d, dwp, scale, shift, db=None):
     O, C = w2d.shape
     S = 1 if tuple(dwp.shape) == (O, C) else dwp.shape[0]
     assert dwp.numel() == S * O * C and dwp.is_contiguous()
-    dW = torch.empty((O, C), dtype=torch.float32, device=w2d.device)
     R = LIB.query("seg_fold_bwd_rows", O)
+    if S > 8 and R == 1:
+        # a narrow conv on a huge map (decoder c1_block: 256 -> 48 on 263 k pixels, 256 pixel
+        # splits): the fold reduction would walk all S partials with ONE row group of blocks
+        # (184 us for 12.6 MB) — sum the splits with the wide column-sum kernel first
+        dwp = colsum(dwp.view(S, O * C), f64=False).view(O, C)
+        S = 1
+    dW = torch.empty((O, C), dtype=torch.float32, device=w2d.device)
     dsdt = torch.empty((R, 2 * C), dtype=torch.float32, device=w2d.device)
     LIB.call("seg_fold_bwd_reduce", _p(w2d), _p(dwp), S, _p(scale), _p(shift), _p(db), _p(dW),
              _p(dsdt), O, C, _stream())

@@ -86,6 +86,17 @@ def main():
     mean, invstd = rn(C) * 0.1, torch.rand(C, device=DEV) + 0.5
     ops["dw_bwd_finalize"] = lambda: K.dw_bwd_finalize(pb_, pw_, float(M), mean, invstd, bnw)
     ops["bn_bwd_finalize_p"] = lambda: K.bn_bwd_finalize_p(pb_, float(M), mean, invstd, bnw)
+    # what does one extra tiny launch cost inside a graph?  (pair - single)
+    def pair():
+        K.conv_gemm(x, wpw, C, 1, 1, 1, 0, 1, None, None, None, True)
+        K.bn_finalize_p(part, float(M), bnw, bnb, 1e-3, 0.1, rm, rv)
+    ops["gemm_fwd+fin"] = pair
+
+    def triple():
+        K.conv_gemm(x, wpw, C, 1, 1, 1, 0, 1, None, None, None, True)
+        K.bn_finalize_p(part, float(M), bnw, bnb, 1e-3, 0.1, rm, rv)
+        K.fold_weights(wf, sc, sh, dt, want_transpose=True)
+    ops["gemm_fwd+fin+fold"] = triple
     which = args.ops or list(ops)
     for name in which:
         us = timeit(ops[name], args.iters)
