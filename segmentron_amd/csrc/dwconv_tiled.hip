@@ -51,6 +51,12 @@ template <int DIL> struct TileGeom {
 };
 
 // ---- global -> registers (all loads of the tile issued back to back)
+// The address arithmetic of the six loads used to cost ~150 VALU instructions per tile and
+// thread (division by the tile width, two clamps, 64-bit multiplies per load) — as much as a
+// third of the multiply-accumulate work of the tile: these kernels are instruction-bound, not
+// bandwidth-bound (7.6 M wave-instructions for 12.2 M outputs).  Tiles whose halo lies inside
+// the image (block-uniform test) take the short path: pixel offsets relative to the tile origin
+// are per-thread constants.
 template <typename T, typename V, int DIL>
 __device__ __forceinline__ void tile_issue(const DwTiledArgs& a, const T* __restrict__ X, int n,
                                            int h0, int w0, int cv,
@@ -60,6 +66,20 @@ __device__ __forceinline__ void tile_issue(const DwTiledArgs& a, const T* __rest
   constexpr int VEC = V::N;
   okmask = 0;
   const int cvc = min(cv, a.CV - 1);
+  const bool inside = h0 >= DIL && h0 + LT_TH + DIL <= a.H && w0 >= DIL && w0 + LT_TW + DIL <= a.W;
+  if (inside) {
+    const int origin = (n * a.H + h0 - DIL) * a.W + (w0 - DIL);  // (N*H*W < 2^31: checked on the host)
+    const T* __restrict__ base = X + cvc * VEC;
+#pragma unroll
+    for (int u = 0; u < G::PER; ++u) {
+      const int p = (threadIdx.x >> 3) + u * (LT_THREADS / LT_CVB);
+      const int pc = p < G::NPIX ? p : G::NPIX - 1;
+      const int r = pc / G::IW, c = pc - r * G::IW;
+      okmask |= (p < G::NPIX && cv < a.CV) ? (1u << u) : 0u;
+      raw[u] = V::load_raw(base + (long)(origin + r * a.W + c) * a.ldx);
+    }
+    return;
+  }
 #pragma unroll
   for (int u = 0; u < G::PER; ++u) {
     const int p = (threadIdx.x >> 3) + u * (LT_THREADS / LT_CVB);
@@ -72,17 +92,20 @@ __device__ __forceinline__ void tile_issue(const DwTiledArgs& a, const T* __rest
   }
 }
 
-// ---- registers -> LDS: activation once per element, zero padding outside the image
-template <typename T, typename V, int DIL>
+// ---- registers -> LDS: activation once per element, zero padding outside the image.
+// MODE >= 0: the prologue mode as a compile-time constant (no per-vector branches; MODE 0 stores
+// the raw vector); MODE < 0: a.pro_mode at run time.
+template <typename T, typename V, int DIL, int MODE = -1>
 __device__ __forceinline__ void tile_commit(const DwTiledArgs& a,
                                             typename V::raw_t* __restrict__ tile,
                                             const typename V::raw_t (&raw)[TileGeom<DIL>::PER],
                                             unsigned okmask, const float4* __restrict__ psm) {
   using G = TileGeom<DIL>;
   constexpr int VEC = V::N, WQ = VEC / 4;
+  const int mode = MODE >= 0 ? MODE : a.pro_mode;
   const int cx = threadIdx.x & (LT_CVB - 1);
   float sc[VEC], sh[VEC];
-  if (a.pro_mode & PRO_AFFINE) {
+  if (mode & PRO_AFFINE) {
 #pragma unroll
     for (int q = 0; q < WQ; ++q) {
       const float4 s4 = psm[(9 * LT_CVB + cx) * WQ + q], t4 = psm[(10 * LT_CVB + cx) * WQ + q];
@@ -95,21 +118,24 @@ __device__ __forceinline__ void tile_commit(const DwTiledArgs& a,
     const int p = (threadIdx.x >> 3) + u * (LT_THREADS / LT_CVB);
     if (p < G::NPIX) {
       const int r = p / G::IW, c = p - r * G::IW;
-      float f[VEC];
-      V::unpack_raw(raw[u], f);
-      if (a.pro_mode & PRO_AFFINE) {
+      typename V::raw_t v = raw[u];
+      if (mode != PRO_NONE) {
+        float f[VEC];
+        V::unpack_raw(raw[u], f);
+        if (mode & PRO_AFFINE) {
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) f[i] = fmaf(f[i], sc[i], sh[i]);
-      }
-      if (a.pro_mode & PRO_RELU) {
+          for (int i = 0; i < VEC; ++i) f[i] = fmaf(f[i], sc[i], sh[i]);
+        }
+        if (mode & PRO_RELU) {
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) f[i] = fmaxf(f[i], 0.f);
-      }
-      if (a.pro_mode & PRO_CLAMP6) {
+          for (int i = 0; i < VEC; ++i) f[i] = fmaxf(f[i], 0.f);
+        }
+        if (mode & PRO_CLAMP6) {
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) f[i] = fminf(f[i], 6.f);
+          for (int i = 0; i < VEC; ++i) f[i] = fminf(f[i], 6.f);
+        }
+        v = V::pack_raw(f);
       }
-      typename V::raw_t v = V::pack_raw(f);
       if (!((okmask >> u) & 1u)) v = V::zero_raw();
       tile[(r * G::IWP + c) * LT_CVB + cx] = v;
     }
@@ -173,7 +199,7 @@ __device__ __forceinline__ LtBlock lt_block() {
   return b;
 }
 
-template <typename T, int DIL>
+template <typename T, int DIL, int MODE = -1>
 __global__ __launch_bounds__(LT_THREADS, sizeof(T) == 2 ? 3 : 4) void dwconv_tiled_kernel(const DwTiledArgs a) {
   using G = TileGeom<DIL>;
   constexpr int VEC = Vec<T>::N, WQ = VEC / 4;
@@ -213,7 +239,7 @@ __global__ __launch_bounds__(LT_THREADS, sizeof(T) == 2 ? 3 : 4) void dwconv_til
       tile_issue<T, Vec<T>, DIL>(a, X, nn, nh0, nw0, cv, raw, okmask);
     }
     __syncthreads();  // every thread is done reading the previous tile
-    tile_commit<T, Vec<T>, DIL>(a, tile, raw, okmask, wsm);
+    tile_commit<T, Vec<T>, DIL, MODE>(a, tile, raw, okmask, wsm);
     const int n = nn, h0 = nh0, w0 = nw0;
     t += gridDim.y;
     if (PIPE && t < a.ntiles) {
@@ -479,7 +505,7 @@ __global__ __launch_bounds__(LT_THREADS, DW_BWD_OCC) void dwconv_bwd_tiled_kerne
       issue_x(nn, nh0, nw0, xnext);
     }
     __syncthreads();
-    tile_commit<T, V, DIL>(plain, tile, raw, okmask, psm);
+    tile_commit<T, V, DIL, PRO_NONE>(plain, tile, raw, okmask, psm);
     const int n = nn, h0 = nh0, w0 = nw0;
     raw_t xraw[4];
 #pragma unroll
@@ -730,11 +756,23 @@ int launch_dw_tiled(int dtype, const void* x, long ldx, int N, int H, int W, int
   a.partial_bn = nullptr; a.res = nullptr; a.ldr = 0;
   a.ldx = ldx; a.ldy = ldy; a.lddy = 0; a.pro_mode = pro_mode;
   const dim3 grid((a.CV + LT_CVB - 1) / LT_CVB, grid_y);
-#define SEG_LT(TT, DD) \
-  hipLaunchKernelGGL((dwconv_tiled_kernel<TT, DD>), grid, dim3(LT_THREADS), \
+#define SEG_LT(TT, DD, MM) \
+  hipLaunchKernelGGL((dwconv_tiled_kernel<TT, DD, MM>), grid, dim3(LT_THREADS), \
                      tiled_lds<DD>(dtype, true), st, a)
-  if (dtype == DT_BF16) { if (dil == 1) SEG_LT(bf16_t, 1); else SEG_LT(bf16_t, 2); }
-  else { if (dil == 1) SEG_LT(float, 1); else SEG_LT(float, 2); }
+  if (dtype == DT_BF16 && dil == 1) {
+    // the prologue modes of the networks as compile-time constants (no per-vector branches)
+    switch (pro_mode) {
+      case PRO_NONE: SEG_LT(bf16_t, 1, PRO_NONE); break;
+      case PRO_RELU: SEG_LT(bf16_t, 1, PRO_RELU); break;
+      case PRO_AFFINE: SEG_LT(bf16_t, 1, PRO_AFFINE); break;
+      case PRO_AFFINE_RELU: SEG_LT(bf16_t, 1, PRO_AFFINE_RELU); break;
+      default: SEG_LT(bf16_t, 1, -1); break;
+    }
+  } else if (dtype == DT_BF16) {
+    SEG_LT(bf16_t, 2, -1);
+  } else {
+    if (dil == 1) SEG_LT(float, 1, -1); else SEG_LT(float, 2, -1);
+  }
 #undef SEG_LT
   return check_launch("dwconv3x3 (tiled)");
 }

@@ -111,8 +111,9 @@ __global__ __launch_bounds__(CE_THREADS) void ce_fwd_kernel(const CeArgs a, doub
        i += (long)gridDim.x * CE_THREADS) {
     const long t = a.target[i];
     // targets outside [0, C) that are not ignore_index (torch raises a device assert for them)
-    // are left out of the sum AND the count, like ignored pixels — never counted with z_t = 0
-    if (t == a.ignore || t < 0 || t >= a.C) continue;
+    // are left out of the sum AND the count, like ignored pixels — never counted with z_t = 0.
+    // (No branch on the target: its load and the logit taps go out together.)
+    const bool valid = !(t == a.ignore || t < 0 || t >= a.C);
     const int w = (int)(i % a.W);
     const long q = i / a.W;
     const int h = (int)(q % a.H), n = (int)(q / a.H);
@@ -127,8 +128,10 @@ __global__ __launch_bounds__(CE_THREADS) void ce_fwd_kernel(const CeArgs a, doub
       if (c < a.C) s += expf(z[c] - m);
       if (c == (int)t) zt = z[c];
     }
-    lsum += (double)(logf(s) + m - zt);
-    lcnt += 1.0;
+    if (valid) {
+      lsum += (double)(logf(s) + m - zt);
+      lcnt += 1.0;
+    }
   }
   // block reduction in a fixed order (wave butterfly, then the waves in index order)
 #pragma unroll
@@ -239,26 +242,25 @@ __global__ __launch_bounds__(CE_BWD_THREADS, 4) void ce_bwd_kernel(const CeArgs 
     for (int p = threadIdx.x; p < rows * nw; p += CE_BWD_THREADS) {
       const int hh = p / nw, ww = p - hh * nw;
       const int h = hlo + r0 + hh, w = wlo + ww;
+      // the target and the four logit taps are requested together (the softmax of an ignored
+      // pixel — 5 % of Cityscapes-like labels — is computed and discarded: a branch on the
+      // target would put a second, dependent memory round trip behind the first)
       const long t = a.target[((long)n * a.H + h) * a.W + w];
       float z[NC];
-      if (t != a.ignore && t >= 0 && t < a.C) {
-        ce_logits<T, NC>(a, n, h, w, z);
-        float m = z[0];
+      ce_logits<T, NC>(a, n, h, w, z);
+      const bool valid = t != a.ignore && t >= 0 && t < a.C;
+      float m = z[0];
 #pragma unroll
-        for (int c = 1; c < NC; ++c) m = (c < a.C) ? fmaxf(m, z[c]) : m;
-        float s = 0.f;
+      for (int c = 1; c < NC; ++c) m = (c < a.C) ? fmaxf(m, z[c]) : m;
+      float s = 0.f;
 #pragma unroll
-        for (int c = 0; c < NC; ++c) {
-          z[c] = (c < a.C) ? expf(z[c] - m) : 0.f;
-          s += z[c];
-        }
-        const float inv = 1.f / s;
-#pragma unroll
-        for (int c = 0; c < NC; ++c) z[c] = (z[c] * inv - (c == (int)t ? 1.f : 0.f)) * g;
-      } else {
-#pragma unroll
-        for (int c = 0; c < NC; ++c) z[c] = 0.f;
+      for (int c = 0; c < NC; ++c) {
+        z[c] = (c < a.C) ? expf(z[c] - m) : 0.f;
+        s += z[c];
       }
+      const float inv = valid ? g / s : 0.f, hot = valid ? g : 0.f;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) z[c] = z[c] * inv - (c == (int)t ? hot : 0.f);
 #pragma unroll
       for (int c = 0; c < NC; ++c) dz[((long)c * CH + hh) * HT_MAX + ww] = z[c];
     }

@@ -118,7 +118,7 @@ def _compare(name, dtype, got, ref64, emu, bars, ref32=None):
             cls = "y" if k == "y" else ("dx/dW" if (k.startswith("dx") or ref64[k].dim() >= 2)
                                         else "gamma/beta")
             stats[cls] = max(stats.get(cls, 0.0), ee)
-            if SIBLINGS.get(name, {}).get(k) is not None:
+            if SIBLINGS.get(name, {}).get(k) is not None or k in SENSITIVE.get(name, ()):
                 # ill-conditioned by construction: its own sensitivity to bf16 rounding (the
                 # emulation's distance to fp64, same normalisation) sets the bar
                 bar = max(bar, 2.0 * floor + bars[3])
@@ -190,6 +190,11 @@ DXDW_BAR = {
 # input moves it by tens of percent (the emulation itself sits 0.39 from the fp64 oracle there by
 # its own norm, 0.11 by its siblings').  Bar for it: 2 x that floor + the dx/dW bar.
 SIBLINGS = {"psp_head_2048": {"d:psp.convs.0.conv.weight": "d:psp.convs.%d.conv.weight"}}
+# The other pyramid branches normalise N*o*o = 8 / 18 / 72 samples per channel: the same
+# mechanism, weaker (the bf16 emulation sits 0.27 / 0.24 from the fp64 oracle on bins 2 and 3;
+# measured HIP-vs-emulation 0.16 / 0.10).  Same sensitivity-based bar, by their own norms.
+SENSITIVE = {"psp_head_2048": ("d:psp.convs.1.conv.weight", "d:psp.convs.2.conv.weight",
+                               "d:psp.convs.3.conv.weight")}
 
 CASES = ["sep_relu_first_728", "sep_relu_last_1536", "sep_stride2_256_728",
          "xception_middle_728", "xception_entry_conv_256_728", "xception_exit_1536_2048",
