@@ -18,9 +18,7 @@
  *     0 none, 1 relu(x), 2 x*scale[c]+shift[c], 3 relu(x*scale[c]+shift[c]); +4 = ReLU6 clamp
  *     (5 = relu6(x), 7 = relu6(x*scale[c]+shift[c]))
  *   - `stream` is a hipStream_t; all launches are asynchronous on it; no host synchronisation,
- *     no allocation; re-entrant and graph-capturable.  The only process-wide state are three
- *     kernel-SELECTION knobs for A/B measurements (seg_conv_gemm_config, seg_conv_gemm_px256,
- *     seg_conv_gemm_wgrad_config): they pick between implementations with identical results
+ *     no allocation; re-entrant and graph-capturable; no process-wide state.
  *   - return value 0 = ok; otherwise seg_last_error() (thread-local) describes the failure.
  *     Never aborts.
  */
@@ -55,9 +53,6 @@ int seg_conv_gemm_fwd(int dtype, const void* x, long ldx, int N, int Hi, int Wi,
                       int out_s, float* stat_partial, const void* ep_x, long ldep,
                       const float* ep_c0, const float* ep_c1, int tconv, void* stream);
 int seg_conv_gemm_tiles_m(int N, int Ho, int Wo);
-/* tuning knob (not a correctness switch): LDS pipeline variant of the GEMM kernels; returns the
- * previous value, negative = query only. */
-int seg_conv_gemm_config(int double_buffer);
 
 /* Weight gradient of the same convolution (autograd's conv2d backward wrt weight):
  * partial[s][o][k] for s < splits (fp32); sum over s with seg_colsum gives dW[O][KH*KW*C].
@@ -69,18 +64,11 @@ int seg_conv_gemm_wgrad(int dtype, const void* x, long ldx, int N, int Hi, int W
 /* rows of the [rows][2][O] statistics buffer seg_conv_gemm_fwd writes for this geometry */
 int seg_conv_gemm_stat_rows(int dtype, int N, int Ho, int Wo, int C, int O, int KH, int KW,
                             int stride, int pad, int dil, int tconv, int has_bias, int pro_mode);
-/* tuning knob: 2 (default) = 1x1 stride-1 convs on the direct-to-LDS 256x256 bf16 kernel where
- * it applies (no prologue / bias, O % 8 == 0) else the 256x128-tile kernel; 1 = 256x128 only;
- * 0 = first-generation 128x128 kernel; +4 = keep 3x3 stride-1 bf16 convolutions with C, O in
- * {32, 64} at >= 65536 pixels on the implicit GEMM instead of the direct halo-tile kernel;
- * returns the previous value, negative = query only */
-int seg_conv_gemm_px256(int enable);
 /* splits to allocate `partial` for (same geometry arguments as the seg_conv_gemm_wgrad call:
  * plain 1x1 convolutions run on the direct-to-LDS kernel, which wants ~one block per CU; the
  * 3x3 stride-1 stems with 32 input channels on persistent blocks, one partial each) */
 int seg_conv_gemm_wgrad_splits(int dtype, int N, int Ho, int Wo, int C, int O, int KH, int KW,
                                int stride, int pad, int dil, int pro_mode);
-int seg_conv_gemm_wgrad_config(int double_buffer);
 
 /* ---- nn.Conv2d, groups=C, 3x3, padding=dilation (depthwise) --------------------------------
  * Replaces segmentron/modules/basic.py:38-40 (SeparableConv2d.depthwise), :152-153.

@@ -23,7 +23,7 @@ namespace seg {
 // FAST : 1x1, stride 1, no padding — the 96 %-of-FLOPs case: operand rows are addressed by
 //        pointers set up once and advanced by a constant per K-slab (no per-slab index math).
 // DBUF : two LDS stages, one barrier per slab (2 blocks/CU) vs one stage, two barriers per slab
-//        (3 blocks/CU).  The variant is chosen by the host (seg_conv_gemm_config).
+//        (3 blocks/CU).  The single-stage variant is the one launched (measured faster on every C3 shape).
 // WIDE : block tile 256 pixels x 64 output channels (waves 4x1) instead of 128 x 128 (2x2): KxK
 //        convolutions with O <= 64 at large spatial sizes (network stems, the ResNet layer1
 //        3x3s) would otherwise spend half of their MFMAs and B staging on zero columns.
@@ -315,10 +315,10 @@ __global__ __launch_bounds__(GEMM_THREADS, (DBUF || !FAST) ? 2 : 3) void conv_ge
 // 1x1 stride-1 convs: 0 = first-generation 128x128 kernel, 1 = 256x128 kernel
 // (conv_gemm_px256.hip), 2 = direct-to-LDS 256x256 kernel where it applies (conv_gemm_glds.hip:
 // bf16, no prologue), 256x128 otherwise
-static int g_gemm_px256 = 2;
-static int g_conv3x3_direct = 1;  // bit 2 of seg_conv_gemm_px256's argument CLEARS it (A/B runs)
-static int g_gemm_dbuf = 0;  // single LDS stage, 3 blocks/CU: measured faster on every C3 shape
-                             // (gpurun_out/gemm_bench2: 709 vs 622 TF on 1536->2048 @65x129)
+// (fixed selection; the A/B history is in profiles/r01..r02: single LDS stage, 3 blocks/CU,
+// measured faster than two stages on every C3 shape — 709 vs 622 TF on 1536->2048 @65x129)
+constexpr int g_gemm_px256 = 2;
+constexpr bool g_conv3x3_direct = true;
 
 // The 256 x 64 tile of the general path: few output channels, many pixels.
 static bool gemm_use_wide(int KH, int KW, int stride, int pad, int tconv, int O, long M) {
@@ -333,36 +333,14 @@ static int launch_conv_gemm_fwd(const ConvGemmArgs& a, hipStream_t stream) {
   if (gemm_use_wide(a.KH, a.KW, a.stride, a.pad, a.tconv, a.O, a.M)) {
     hipLaunchKernelGGL((conv_gemm_fwd_kernel<T, false, false, true>), grid, block, 0, stream, a);
   } else if (fast) {
-    if (g_gemm_dbuf) hipLaunchKernelGGL((conv_gemm_fwd_kernel<T, true, true>), grid, block, 0, stream, a);
-    else hipLaunchKernelGGL((conv_gemm_fwd_kernel<T, true, false>), grid, block, 0, stream, a);
+    hipLaunchKernelGGL((conv_gemm_fwd_kernel<T, true, false>), grid, block, 0, stream, a);
   } else {
-    if (g_gemm_dbuf) hipLaunchKernelGGL((conv_gemm_fwd_kernel<T, false, true>), grid, block, 0, stream, a);
-    else hipLaunchKernelGGL((conv_gemm_fwd_kernel<T, false, false>), grid, block, 0, stream, a);
+    hipLaunchKernelGGL((conv_gemm_fwd_kernel<T, false, false>), grid, block, 0, stream, a);
   }
   return check_launch("conv_gemm_fwd");
 }
 
 }  // namespace seg
-
-// Process-wide tuning knob: 1 = two LDS stages / one barrier per slab, 0 = one stage (more
-// resident blocks).  Returns the previous value; a negative argument only queries.
-extern "C" int seg_conv_gemm_config(int double_buffer) {
-  const int prev = seg::g_gemm_dbuf;
-  if (double_buffer >= 0) seg::g_gemm_dbuf = double_buffer ? 1 : 0;
-  return prev;
-}
-
-// 2 (default): 1x1 / stride-1 convolutions run on the direct-to-LDS 256x256 kernel where it
-// applies and on the 256x128-tile kernel otherwise; 1: 256x128 only; 0: first-generation
-// 128x128 kernel everywhere.  Returns the previous value; a negative argument only queries.
-extern "C" int seg_conv_gemm_px256(int enable) {
-  const int prev = seg::g_gemm_px256 | (seg::g_conv3x3_direct ? 0 : 4);
-  if (enable >= 0) {
-    seg::g_gemm_px256 = (enable & 3) > 2 ? 2 : (enable & 3);
-    seg::g_conv3x3_direct = (enable & 4) ? 0 : 1;
-  }
-  return prev;
-}
 
 // The 256x128 kernel pays off where an output row is wide enough to amortise its longer
 // per-block pipeline (tools/gemm_bench.py, bf16 TFLOP/s, 128x128 -> 256x128: 728->728 @65x129

@@ -12,7 +12,7 @@ namespace seg {
 // EP: folded-BatchNorm backward correction in the store path; STATS: BatchNorm partial sums
 // KXK: stride-1 KxK convolution as an implicit GEMM (per-lane gather in the DMA source address,
 // gemm_glds.h GlConvA) — ResNet bottleneck / PSP-head 3x3s, C % 32 == 0
-template <int VARIANT, bool EP, bool STATS, bool KXK = false>
+template <bool EP, bool STATS, bool KXK = false>
 __global__ __launch_bounds__(GL_THREADS, 2) void conv_gemm_glds_kernel(const ConvGemmArgs a) {
   typedef bf16_t T;
   constexpr int VEC = 8;
@@ -34,41 +34,14 @@ __global__ __launch_bounds__(GL_THREADS, 2) void conv_gemm_glds_kernel(const Con
   B.ld_bytes = (long)a.K * 2;
   B.rows = a.O;
 
-  f32x16 acc[2][4];
-  if (VARIANT != 3 && VARIANT != 4) {  // (the ring variant starts from a zero accumulator INPUT)
-#pragma unroll
-    for (int jn = 0; jn < 2; ++jn)
-#pragma unroll
-      for (int im = 0; im < 4; ++im)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[jn][im][e] = 0.f;
-  }
+  f32x16 acc[2][4];  // (the ring starts from a constant-zero accumulator INPUT)
 
-#ifdef GL_LAB  // ablation knobs of tools/lab/gemm_lab (never compiled into the library)
-  const int lab = a.dil;
-  if (VARIANT >= 3) gl_mainloop_ring<VARIANT - 3>(A, B, (lab == 102) ? 64 : a.K, m0, n0, lds, acc);
-  else gl_mainloop<VARIANT>(A, B, (lab == 102) ? 64 : a.K, m0, n0, lds, acc);
-  if (lab == 101) {  // no epilogue: keep the accumulators alive with one conditional store
-    float t = 0.f;
-#pragma unroll
-    for (int jn = 0; jn < 2; ++jn)
-#pragma unroll
-      for (int im = 0; im < 4; ++im)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) t += acc[jn][im][e];
-    if (t == 12345.678f) reinterpret_cast<float*>(a.y)[tid] = t;
-    return;
-  }
-#else
   if (KXK) {
     const GlConvA cg = {a.M, a.Hi, a.Wi, a.Ho, a.Wo, a.KW, a.pad, a.dil, a.C / 32};
-    gl_mainloop_ring<0, true>(A, B, a.K, m0, n0, lds, acc, &cg);
-  } else if (VARIANT >= 3) {
-    gl_mainloop_ring<0>(A, B, a.K, m0, n0, lds, acc);
+    gl_mainloop_ring<true>(A, B, a.K, m0, n0, lds, acc, &cg);
   } else {
-    gl_mainloop<VARIANT>(A, B, a.K, m0, n0, lds, acc);
+    gl_mainloop_ring<false>(A, B, a.K, m0, n0, lds, acc);
   }
-#endif
 
   // ---- epilogue, per wave and 32-pixel tile: channel groups -> LDS patch [32 px][64 ch] ->
   // 16-byte NHWC vectors (+ statistics, + folded-BatchNorm correction) -> global
@@ -142,19 +115,7 @@ __global__ __launch_bounds__(GL_THREADS, 2) void conv_gemm_glds_kernel(const Con
         val[q] = Vec<T>::pack(f);
       }
       // (O % 8 == 0 on this kernel — conv_gemm_glds_usable: a vector is inside or outside)
-      if (p < a.M && o < a.O) {
-#ifdef GL_LAB
-        if (lab == 104) {  // no store at all
-          if (val[q].x == 0x12345678u) stg16(Y + (long)p * a.ldy + o, val[q]);
-        } else
-#endif
-        stg16(Y + (long)p * a.ldy + o, val[q]);
-      }
-#ifdef GL_LAB
-      if (lab == 106) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (lab == 107) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-      if (lab == 108 && q == NQ - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
+      if (p < a.M && o < a.O) stg16(Y + (long)p * a.ldy + o, val[q]);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -197,11 +158,11 @@ bool conv_gemm_glds_usable(int dtype, const ConvGemmArgs& a) {
          (a.ldy % 8) == 0;
 }
 
-template <int VARIANT, bool EP, bool STATS>
+template <bool EP, bool STATS>
 static int launch_glds_inst(const ConvGemmArgs& a, hipStream_t stream) {
   static const int once = [] {
     return (int)hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&conv_gemm_glds_kernel<VARIANT, EP, STATS>),
+        reinterpret_cast<const void*>(&conv_gemm_glds_kernel<EP, STATS>),
         hipFuncAttributeMaxDynamicSharedMemorySize, GL_LDS_BYTES);
   }();
   if (once != 0) {
@@ -209,25 +170,20 @@ static int launch_glds_inst(const ConvGemmArgs& a, hipStream_t stream) {
     return 2;
   }
   const dim3 grid(a.tiles_m * a.tiles_n), block(GL_THREADS);
-  hipLaunchKernelGGL((conv_gemm_glds_kernel<VARIANT, EP, STATS>), grid, block, GL_LDS_BYTES,
+  hipLaunchKernelGGL((conv_gemm_glds_kernel<EP, STATS>), grid, block, GL_LDS_BYTES,
                      stream, a);
   return check_launch("conv_gemm_fwd (glds)");
 }
 
-template <int VARIANT>
-static int launch_glds_variant(ConvGemmArgs a, hipStream_t stream) {
+int launch_conv_gemm_glds(ConvGemmArgs a, hipStream_t stream) {
   a.tiles_m = px256_tiles_m(a.M);  // 256-pixel tiles: same statistics rows as the px256 kernel
   a.tiles_n = (a.O + GL_BN - 1) / GL_BN;
   // (forward convs take statistics, data gradients the folded-BN correction; never both)
   if (a.ep_x != nullptr && a.stat_partial != nullptr)
-    return launch_glds_inst<VARIANT, true, true>(a, stream);
-  if (a.ep_x != nullptr) return launch_glds_inst<VARIANT, true, false>(a, stream);
-  if (a.stat_partial != nullptr) return launch_glds_inst<VARIANT, false, true>(a, stream);
-  return launch_glds_inst<VARIANT, false, false>(a, stream);
-}
-
-int launch_conv_gemm_glds(ConvGemmArgs a, hipStream_t stream) {
-  return launch_glds_variant<3>(a, stream);
+    return launch_glds_inst<true, true>(a, stream);
+  if (a.ep_x != nullptr) return launch_glds_inst<true, false>(a, stream);
+  if (a.stat_partial != nullptr) return launch_glds_inst<false, true>(a, stream);
+  return launch_glds_inst<false, false>(a, stream);
 }
 
 // ---- stride-1 KxK on the same pipeline
@@ -242,7 +198,7 @@ template <bool STATS>
 static int launch_glds_kxk_inst(const ConvGemmArgs& a, hipStream_t stream) {
   static const int once = [] {
     return (int)hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&conv_gemm_glds_kernel<3, false, STATS, true>),
+        reinterpret_cast<const void*>(&conv_gemm_glds_kernel<false, STATS, true>),
         hipFuncAttributeMaxDynamicSharedMemorySize, GL_LDS_BYTES);
   }();
   if (once != 0) {
@@ -250,7 +206,7 @@ static int launch_glds_kxk_inst(const ConvGemmArgs& a, hipStream_t stream) {
     return 2;
   }
   const dim3 grid(a.tiles_m * a.tiles_n), block(GL_THREADS);
-  hipLaunchKernelGGL((conv_gemm_glds_kernel<3, false, STATS, true>), grid, block, GL_LDS_BYTES,
+  hipLaunchKernelGGL((conv_gemm_glds_kernel<false, STATS, true>), grid, block, GL_LDS_BYTES,
                      stream, a);
   return check_launch("conv_gemm_fwd (glds KxK)");
 }
@@ -262,15 +218,5 @@ int launch_conv_gemm_glds_kxk(ConvGemmArgs a, hipStream_t stream) {
   return launch_glds_kxk_inst<false>(a, stream);
 }
 
-#ifdef GL_LAB
-int launch_conv_gemm_glds_variant(ConvGemmArgs a, hipStream_t stream, int variant) {
-  return variant == 0 ? launch_glds_variant<0>(a, stream)
-                      : variant == 2 ? launch_glds_variant<2>(a, stream)
-                      : variant == 3 ? launch_glds_variant<3>(a, stream)
-                      : variant == 4 ? launch_glds_variant<4>(a, stream)
-                      : variant == 5 ? launch_glds_variant<5>(a, stream)
-                                     : launch_glds_variant<1>(a, stream);
-}
-#endif
 
 }  // namespace seg

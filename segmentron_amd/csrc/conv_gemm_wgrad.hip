@@ -276,21 +276,12 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void conv_gemm_wgrad_kernel(
 }  // namespace seg
 
 namespace seg {
-static int g_wgrad_dbuf = 0;  // see conv_gemm_fwd.hip: single stage measured faster
-static int g_wgrad_glds = 1;  // plain 1x1 bf16 weight gradients on conv_gemm_wgrad_glds.hip
-static int g_wgrad_direct = 1;  // 3x3 stride-1 stems (C = 32) on conv3x3_direct.hip
-}
-// tuning knob for the weight-gradient kernel, same semantics as seg_conv_gemm_config
-// bit 0: two LDS stages in the first-generation kernel; bit 1 CLEAR (default): plain 1x1 bf16
-// weight gradients run on the direct-to-LDS transpose-read kernel, SET: first generation only
-extern "C" int seg_conv_gemm_wgrad_config(int double_buffer) {
-  const int prev = seg::g_wgrad_dbuf | (seg::g_wgrad_glds ? 0 : 2) | (seg::g_wgrad_direct ? 0 : 4);
-  if (double_buffer >= 0) {
-    seg::g_wgrad_dbuf = double_buffer & 1;
-    seg::g_wgrad_glds = (double_buffer & 2) ? 0 : 1;
-    seg::g_wgrad_direct = (double_buffer & 4) ? 0 : 1;
-  }
-  return prev;
+// kernel selection (fixed; the A/B history is in profiles/r01..r02): single LDS stage in the
+// first-generation kernel (3 blocks/CU measured faster than two stages on every C3 shape),
+// plain 1x1 / stride-1 KxK bf16 weight gradients on the direct-to-LDS transpose-read kernel,
+// the 3x3 stride-1 stems (C = 32) on the direct halo-tile kernel
+constexpr bool g_wgrad_glds = true;
+constexpr bool g_wgrad_direct = true;
 }
 
 extern "C" int seg_conv_gemm_wgrad_splits(int dtype, int N, int Ho, int Wo, int C, int O, int KH,
@@ -311,13 +302,9 @@ extern "C" int seg_conv_gemm_wgrad_splits(int dtype, int N, int Ho, int Wo, int 
   if (g_wgrad_direct && conv3x3_wgrad_direct_usable(dtype, C, O, KH, KW, stride, pad, dil, M, 8, 8))
     return conv3x3_direct_blocks(N, Ho, Wo);  // one partial per persistent block
   const int tiles = ((O + BM - 1) / BM) * ((K + BN - 1) / BN);
-  static const int target = [] {
-    const char* e = getenv("SEG_WGRAD_BLOCKS");  // experiment knob: total blocks aimed for
-    return e ? atoi(e) : 0;
-  }();
   // 512 blocks in total: 2 per CU.  (768 = all 3 resident blocks per CU measured 0.3-0.4 ms/step
   // slower on C3: a third more split partials to write and to reduce for the same GEMM.)
-  long want = (target > 0 ? target : 512) / tiles;
+  long want = 512 / tiles;
   long maxs = (M + 8 * bkp - 1) / (8 * bkp);       // at least 8 slabs per split
   if (maxs < 1) maxs = 1;
   if (want > maxs) want = maxs;
@@ -360,12 +347,7 @@ extern "C" int seg_conv_gemm_wgrad(int dtype, const void* x, long ldx, int N, in
   const int grid = a.tiles_o * a.tiles_k * splits;
   hipStream_t st = (hipStream_t)stream;
   const dim3 g(grid), b(GEMM_THREADS);
-  if (dtype == DT_BF16) {
-    if (g_wgrad_dbuf) hipLaunchKernelGGL((conv_gemm_wgrad_kernel<bf16_t, true>), g, b, 0, st, a);
-    else hipLaunchKernelGGL((conv_gemm_wgrad_kernel<bf16_t, false>), g, b, 0, st, a);
-  } else {
-    if (g_wgrad_dbuf) hipLaunchKernelGGL((conv_gemm_wgrad_kernel<float, true>), g, b, 0, st, a);
-    else hipLaunchKernelGGL((conv_gemm_wgrad_kernel<float, false>), g, b, 0, st, a);
-  }
+  if (dtype == DT_BF16) hipLaunchKernelGGL((conv_gemm_wgrad_kernel<bf16_t, false>), g, b, 0, st, a);
+  else hipLaunchKernelGGL((conv_gemm_wgrad_kernel<float, false>), g, b, 0, st, a);
   return check_launch("conv_gemm_wgrad");
 }

@@ -22,11 +22,7 @@
 
 namespace seg {
 
-// SEG_DW_ROW=0 (environment, A/B runs): wide-dilation layers back on the strip kernels
-static const int g_dw_row = [] {
-  const char* e = getenv("SEG_DW_ROW");
-  return e ? atoi(e) : 1;
-}();
+constexpr bool g_dw_row = true;  // wide dilations on the row-chain kernels (dwconv_row.hip)
 
 constexpr int DW_TW = 4;
 constexpr int DW_THREADS = 256;

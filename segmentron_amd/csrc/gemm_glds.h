@@ -1,6 +1,6 @@
 // Third-generation MFMA GEMM core for gfx950: direct-to-LDS staging (global_load_lds, 16 B per
-// lane), XOR-swizzled lane-linear LDS image, two LDS stages with the NEXT K tile's DMA kept in
-// flight across the barriers (counted s_waitcnt vmcnt, raw s_barrier), 256 x 256 block tile,
+// lane), XOR-swizzled lane-linear LDS image, a RING of four 32-k slots with three slots' DMA kept
+// in flight across the barriers (counted s_waitcnt vmcnt, raw s_barrier), 256 x 256 block tile,
 // eight waves as 2 (row halves) x 4 (column quarters), 128 x 64 per wave = 4 x 2 MFMA 32x32x16
 // tiles (128 fp32 accumulators).
 //
@@ -9,15 +9,10 @@
 //
 // Used by the 1x1 / stride-1 convolution forward + data gradient (conv_gemm_glds.hip: A = pixels,
 // B = packed weights) — the operands that need no element-wise prologue, which is what the BN
-// fold (fold.hip) leaves for 63 of the 79 GEMM-shaped convolutions of DeepLabv3+/xception65.
-//
-// LDS image of one operand tile (256 rows x 64 k = 128 B per row): byte offset of 16-byte vector
-// kv (0..7) of row r is  r*128 + ((kv ^ ((r >> 1) & 7)) << 4).  A wave-wide global_load_lds
-// writes 64 lanes x 16 B = 1 KiB = 8 consecutive rows; lane i lands on row 8c + (i >> 3),
-// physical slot i & 7, so the swizzle is applied to the lane's SOURCE address (the hardware
-// adds lane*16 to a wave-uniform LDS base).  ds_read_b128 fragment reads (lane l: row l & 31 of
-// a 32-row group, k half l >> 5) then touch 16 distinct 16-byte slots per 16-lane service
-// group: conflict-free (MI355X_MICROARCH.md, LDS table).
+// fold (fold.hip) leaves for 63 of the 79 GEMM-shaped convolutions of DeepLabv3+/xception65 —
+// and, with the per-lane DMA source gathered per tap, by the stride-1 KxK convolutions.
+// (The two-stage 64-k predecessors of the ring and their ablation hooks — profiles/r02_gemm_lab.md
+// — were removed in r03.)
 //
 // Tails: rows >= M / N and k >= K are fetched from a 16-byte zero word (per-lane source
 // address), so no operand padding is required and nothing is read out of bounds.
@@ -27,11 +22,9 @@
 
 namespace seg {
 
-constexpr int GL_BM = 256, GL_BN = 256, GL_BK = 64;
+constexpr int GL_BM = 256, GL_BN = 256;
 constexpr int GL_THREADS = 512;
-constexpr int GL_TILE_BYTES = 256 * 128;                 // one operand tile in LDS (32 KiB)
-constexpr int GL_STAGE_BYTES = 2 * GL_TILE_BYTES;        // A + B
-constexpr int GL_LDS_BYTES = 2 * GL_STAGE_BYTES;         // two stages: 128 KiB
+constexpr int GL_LDS_BYTES = 128 * 1024;                 // four ring slots of 32 KiB
 
 typedef __attribute__((address_space(3))) unsigned char lds_byte_t;
 typedef __attribute__((address_space(1))) const unsigned char glb_byte_t;
@@ -42,106 +35,19 @@ struct GemmOperand {
   int rows;                   // valid rows
 };
 
-// Per-thread source offsets of the 4 + 4 DMA pieces this thread issues for every K tile.
-struct GlStager {
-  long a_off[4], b_off[4];   // byte offset of (row, kv) from the operand base, or -1 (zero word)
-  int kv[4];                 // logical k-vector of piece j (same for A and B)
-};
-
-__device__ __forceinline__ void gl_stager_init(GlStager& s, const GemmOperand& A,
-                                               const GemmOperand& B, int m0, int n0, int wave,
-                                               int lane) {
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int chunk = wave * 4 + j;            // 32 chunks of 8 rows per operand tile
-    const int r = chunk * 8 + (lane >> 3);     // tile row
-    const int kvl = (lane & 7) ^ ((r >> 1) & 7);
-    s.kv[j] = kvl;
-    s.a_off[j] = (m0 + r < A.rows) ? (long)(m0 + r) * A.ld_bytes + kvl * 16 : -1;
-    s.b_off[j] = (n0 + r < B.rows) ? (long)(n0 + r) * B.ld_bytes + kvl * 16 : -1;
-  }
-}
-
 // 16 bytes of zeros in global memory: the DMA source of every out-of-range vector
 __device__ __attribute__((aligned(16))) const unsigned int g_gl_zero[4] = {0u, 0u, 0u, 0u};
 
-// Issue the DMA of K tile `kt` into LDS stage `stage` (8 global_load_lds per thread).
-__device__ __forceinline__ void gl_issue_tile(const GlStager& s, const GemmOperand& A,
-                                              const GemmOperand& B, int kt, int K,
-                                              lds_byte_t* lds, int stage, int wave) {
-  const unsigned char* zero = reinterpret_cast<const unsigned char*>(g_gl_zero);
-  const long kb = (long)kt * (GL_BK * 2);
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const bool kok = kt * GL_BK + s.kv[j] * 8 < K;
-    const unsigned char* pa = (kok && s.a_off[j] >= 0) ? A.base + s.a_off[j] + kb : zero;
-    const unsigned char* pb = (kok && s.b_off[j] >= 0) ? B.base + s.b_off[j] + kb : zero;
-    lds_byte_t* la = lds + stage * GL_STAGE_BYTES + (wave * 4 + j) * 1024;
-    lds_byte_t* lb = la + GL_TILE_BYTES;
-    __builtin_amdgcn_global_load_lds((glb_byte_t*)pa, la, 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((glb_byte_t*)pb, lb, 16, 0, 0);
-  }
-}
-
 #define GL_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
-#define GL_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
-
-// One K tile of MFMAs for this wave: acc[jn][im] += A(rows wm*128 + im*32 ..) x B(rows wn*64 +
-// jn*32 ..)^T.  MFMA "A" operand = the B-matrix rows (output columns n), MFMA "B" operand = the
-// A-matrix rows (output rows m): a lane's 16 accumulators of a tile are 4 groups of 4
-// CONSECUTIVE n for ONE m (C layout: col = lane & 31 -> m, row -> n).
-__device__ __forceinline__ void gl_mma_tile(const lds_byte_t* stA, const lds_byte_t* stB, int wm,
-                                            int wn, int lane, f32x16 (&acc)[2][4]) {
-  const int r32 = lane & 31, h = lane >> 5, x = (lane >> 1) & 7;
-  // (rows of a 32-row group start at a multiple of 32, so (row >> 1) & 7 == (lane >> 1) & 7)
-  const lds_byte_t* pa = stA + (wm * 128 + r32) * 128;
-  const lds_byte_t* pb = stB + (wn * 64 + r32) * 128;
-  int ko[4];
-#pragma unroll
-  for (int s = 0; s < 4; ++s) ko[s] = ((2 * s + h) ^ x) << 4;
-  typedef const __attribute__((address_space(3))) bf16x8 lds_frag_t;
-  bf16x8 nf[2][2], mf[2][4];
-  auto frags = [&](int s, int set) {
-    nf[set][0] = *(lds_frag_t*)(pb + ko[s]);
-    nf[set][1] = *(lds_frag_t*)(pb + 32 * 128 + ko[s]);
-#pragma unroll
-    for (int im = 0; im < 4; ++im) mf[set][im] = *(lds_frag_t*)(pa + im * 32 * 128 + ko[s]);
-  };
-  frags(0, 0);
-#pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    if (s + 1 < 4) frags(s + 1, (s + 1) & 1);
-    __builtin_amdgcn_sched_barrier(0);  // next step's reads stay above this step's MFMAs
-#pragma unroll
-    for (int im = 0; im < 4; ++im) {
-      acc[0][im] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(nf[s & 1][0], mf[s & 1][im],
-                                                           acc[0][im], 0, 0, 0);
-      acc[1][im] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(nf[s & 1][1], mf[s & 1][im],
-                                                           acc[1][im], 0, 0, 0);
-    }
-  }
-}
 
 // Fragment registers of one k-step (16 k): 2 column-block fragments, 4 row-block fragments.
 struct GlFrags { bf16x8 n[2], m[4]; };
 typedef const __attribute__((address_space(3))) bf16x8 gl_lds_frag_t;
 
-__device__ __forceinline__ void gl_read_frags(GlFrags& f, const lds_byte_t* pa, const lds_byte_t* pb,
-                                              int ko) {
-  f.n[0] = *(gl_lds_frag_t*)(pb + ko);
-  f.n[1] = *(gl_lds_frag_t*)(pb + 32 * 128 + ko);
-#pragma unroll
-  for (int im = 0; im < 4; ++im) f.m[im] = *(gl_lds_frag_t*)(pa + im * 32 * 128 + ko);
-}
-
 // MFMAs of row blocks [IM0, IM1) of one k-step.  ZERO: the accumulator input is the constant 0
 // (first k-step of a tile: saves zero-filling 128 registers before the loop).
-#ifndef GL_SETPRIO
-#define GL_SETPRIO 0
-#endif
 template <int IM0, int IM1, bool ZERO = false>
 __device__ __forceinline__ void gl_mma_part(const GlFrags& f, f32x16 (&acc)[2][4]) {
-  if (GL_SETPRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
   for (int im = IM0; im < IM1; ++im) {
     const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -150,97 +56,20 @@ __device__ __forceinline__ void gl_mma_part(const GlFrags& f, f32x16 (&acc)[2][4
     acc[1][im] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.n[1], f.m[im], ZERO ? z : acc[1][im],
                                                          0, 0, 0);
   }
-  if (GL_SETPRIO) __builtin_amdgcn_s_setprio(0);
 }
 __device__ __forceinline__ void gl_mma_step(const GlFrags& f, f32x16 (&acc)[2][4]) {
   gl_mma_part<0, 4>(f, acc);
 }
 
-// The whole K loop.  On return every wave has passed a barrier after its last LDS read, so the
-// caller may reuse the LDS for its epilogue.
-//
-// VARIANT 0 (first version, kept for A/B in tools/lab): per K tile  wait -> barrier -> 4 k-steps
-// -> barrier -> issue; every wave reads / multiplies / issues in lockstep, so the matrix pipe
-// idles during the first fragment reads and the DMA issue block of every tile.
-//
-// VARIANT 1: ONE barrier per K tile, placed where "every wave has issued AND received its last
-// fragment read of tile k" and "every wave's DMA of tile k+1 has landed" coincide — after the
-// k-step-3 fragments are in registers.  Behind that barrier the wave re-fills stage k&1 with
-// tile k+2 and requests the first fragments of tile k+1, and only then runs the 8 MFMAs of
-// k-step 3: the barrier skew, the DMA issue block and the LDS latency of the next tile's first
-// fragments all sit under matrix work, and the MFMA stream never drains between tiles.
-template <int VARIANT>
-__device__ __forceinline__ void gl_mainloop(const GemmOperand& A, const GemmOperand& B, int K,
-                                            int m0, int n0, lds_byte_t* lds,
-                                            f32x16 (&acc)[2][4]) {
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
-  GlStager st;
-  gl_stager_init(st, A, B, m0, n0, wave, lane);
-  const int nk = (K + GL_BK - 1) / GL_BK;
-  gl_issue_tile(st, A, B, 0, K, lds, 0, wave);
-  if (nk > 1) gl_issue_tile(st, A, B, 1, K, lds, 1, wave);
-  if (VARIANT == 0) {
-    for (int kt = 0; kt < nk; ++kt) {
-      // my pieces of tile kt have landed (tile kt+1's eight may still be in flight) ...
-      if (kt + 1 < nk) GL_WAIT_VM(8); else GL_WAIT_VM(0);
-      __builtin_amdgcn_s_barrier();  // ... and so have everybody else's
-      const lds_byte_t* sA = lds + (kt & 1) * GL_STAGE_BYTES;
-      gl_mma_tile(sA, sA + GL_TILE_BYTES, wm, wn, lane, acc);
-      GL_WAIT_LGKM0();
-      __builtin_amdgcn_s_barrier();  // every wave is done reading stage kt & 1
-      if (kt + 2 < nk) gl_issue_tile(st, A, B, kt + 2, K, lds, kt & 1, wave);
-    }
-    return;
-  }
-  const int r32 = lane & 31, h = lane >> 5, x = (lane >> 1) & 7;
-  const int rowA = (wm * 128 + r32) * 128, rowB = GL_TILE_BYTES + (wn * 64 + r32) * 128;
-  int ko[4];
-#pragma unroll
-  for (int s = 0; s < 4; ++s) ko[s] = ((2 * s + h) ^ x) << 4;
-  GlFrags f0, f1;
-  if (nk > 1) GL_WAIT_VM(8); else GL_WAIT_VM(0);
-  __builtin_amdgcn_s_barrier();
-  gl_read_frags(f0, lds + rowA, lds + rowB, ko[0]);
-  for (int kt = 0; kt < nk; ++kt) {
-    const lds_byte_t* pa = lds + (kt & 1) * GL_STAGE_BYTES + rowA;
-    const lds_byte_t* pb = lds + (kt & 1) * GL_STAGE_BYTES + rowB;
-    gl_read_frags(f1, pa, pb, ko[1]);
-    __builtin_amdgcn_sched_barrier(0);
-    gl_mma_step(f0, acc);
-    __builtin_amdgcn_sched_barrier(0);
-    gl_read_frags(f0, pa, pb, ko[2]);
-    __builtin_amdgcn_sched_barrier(0);
-    gl_mma_step(f1, acc);
-    __builtin_amdgcn_sched_barrier(0);
-    gl_read_frags(f1, pa, pb, ko[3]);
-    __builtin_amdgcn_sched_barrier(0);
-    gl_mma_step(f0, acc);
-    __builtin_amdgcn_sched_barrier(0);
-    // last fragment read of this tile has returned; my DMA of tile kt+1 has landed
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (VARIANT != 2 && kt + 2 < nk) gl_issue_tile(st, A, B, kt + 2, K, lds, kt & 1, wave);
-    if (kt + 1 < nk) {
-      const lds_byte_t* qa = lds + ((kt + 1) & 1) * GL_STAGE_BYTES;
-      gl_read_frags(f0, qa + rowA, qa + rowB, ko[0]);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    gl_mma_step(f1, acc);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-}
-
 // ---------------------------------------------------------------------------------------------
-// Ring variant (VARIANT 3): the DMA round trip under full load (~2 us: 198 CUs pulling 64 KB per
+// The ring: the DMA round trip under full load (~2 us: 198 CUs pulling 64 KB per
 // K tile from L2) is longer than one K tile of MFMAs, so two 64-k stages leave the waves parked
 // in s_waitcnt vmcnt (tools/lab ablation: 1.58 us per K tile with the in-loop DMA, 1.16 without).
 // Here the 128 KiB hold FOUR slots of 32 k (A [256][64 B] + B [256][64 B] = 32 KiB each), slot
 // j+4 is issued as soon as slot j has been read, and up to three slots (96 KiB per CU) are in
 // flight while one is multiplied.  Slot image: row pitch 64 B, vector kv (0..3) of row r at
 // r*64 + ((kv ^ ((r >> 2) & 3)) << 4) — conflict-free for the ds_read_b128 fragment pattern.
-// One barrier per slot, placed as in VARIANT 1 (after the slot's last fragment read returned).
+// One barrier per slot, placed after the slot's last fragment read has returned.
 // Slots past the end of K are issued as all-zero DMAs (every lane fetches the zero word), which
 // keeps the vmcnt arithmetic uniform; the caller's epilogue starts after vmcnt(0) + barrier.
 constexpr int GL_SLOT_BYTES = 32 * 1024, GL_SUB_BYTES = 16 * 1024;
@@ -253,8 +82,7 @@ struct GlConvA {
   int M, Hi, Wi, Ho, Wo, KW, pad, dil, cpt;  // cpt = C / 32: slots per tap
 };
 
-// ABL (tools/lab only): 1 = no DMA inside the loop, 2 = no MFMA (fragments xor-folded instead)
-template <int ABL = 0, bool KXK = false>
+template <bool KXK = false>
 __device__ __forceinline__ void gl_mainloop_ring(const GemmOperand& A, const GemmOperand& B, int K,
                                                  int m0, int n0, lds_byte_t* lds,
                                                  f32x16 (&acc)[2][4], const GlConvA* cg = nullptr) {
@@ -331,13 +159,6 @@ __device__ __forceinline__ void gl_mainloop_ring(const GemmOperand& A, const Gem
     for (int im = 0; im < 4; ++im) f.m[im] = *(gl_lds_frag_t*)(s + rowA + im * 32 * 64 + ko);
   };
   GlFrags f0, f1;
-  auto fold = [&](const GlFrags& f) {  // ablation: consume the fragments without the matrix pipe
-    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-    u32x4 t = __builtin_bit_cast(u32x4, f.n[0]) ^ __builtin_bit_cast(u32x4, f.n[1]);
-#pragma unroll
-    for (int im = 0; im < 4; ++im) t ^= __builtin_bit_cast(u32x4, f.m[im]);
-    acc[0][0][0] += __uint_as_float(t.x ^ t.y ^ t.z ^ t.w);
-  };
   GL_WAIT_VM(12);
   __builtin_amdgcn_s_barrier();
   read(f0, 0, ko0);
@@ -346,15 +167,11 @@ __device__ __forceinline__ void gl_mainloop_ring(const GemmOperand& A, const Gem
   // MFMA that consumes f0, so nothing newer may be in flight at that point.
   auto slot_body = [&](int j, auto first) {
     constexpr bool FIRST = decltype(first)::value;
-    if (ABL == 2) {
-      fold(f0);
-    } else {
-      gl_mma_part<0, 1, FIRST>(f0, acc);
-    }
+    gl_mma_part<0, 1, FIRST>(f0, acc);
     __builtin_amdgcn_sched_barrier(0);
     read(f1, j, ko1);
     __builtin_amdgcn_sched_barrier(0);
-    if (ABL != 2) gl_mma_part<1, 4, FIRST>(f0, acc);
+    gl_mma_part<1, 4, FIRST>(f0, acc);
     __builtin_amdgcn_sched_barrier(0);
     // my reads of slot j have returned; my DMA of slot j+1 has landed (j+2, j+3 in flight).
     // f1 is passed THROUGH the asm: hipcc then sees it as produced here and does not put its
@@ -366,10 +183,10 @@ __device__ __forceinline__ void gl_mainloop_ring(const GemmOperand& A, const Gem
                  :
                  : "memory");
     __builtin_amdgcn_s_barrier();
-    if (ABL != 1) issue(j + 4);
+    issue(j + 4);
     read(f0, j + 1, ko0);
     __builtin_amdgcn_sched_barrier(0);
-    if (ABL == 2) fold(f1); else gl_mma_step(f1, acc);
+    gl_mma_step(f1, acc);
     __builtin_amdgcn_sched_barrier(0);
   };
   slot_body(0, std::true_type{});

@@ -12,15 +12,6 @@ PRO_NONE, PRO_RELU, PRO_AFFINE, PRO_AFFINE_RELU = 0, 1, 2, 3
 _DT = {torch.float32: 0, torch.bfloat16: 1}
 
 
-def gemm_config(fwd_double_buffer=None, wgrad_double_buffer=None):
-    """Tuning knobs of the MFMA GEMM kernels (LDS pipeline variant); returns current values."""
-    if fwd_double_buffer is not None:
-        LIB.query("seg_conv_gemm_config", int(fwd_double_buffer))
-    if wgrad_double_buffer is not None:
-        LIB.query("seg_conv_gemm_wgrad_config", int(wgrad_double_buffer))
-    return LIB.query("seg_conv_gemm_config", -1), LIB.query("seg_conv_gemm_wgrad_config", -1)
-
-
 def vec_of(dtype):
     return 8 if dtype == torch.bfloat16 else 4
 

@@ -37,12 +37,8 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--only", type=int, default=-1)
     ap.add_argument("--wgrad", action="store_true")
-    ap.add_argument("--dbuf", type=int, default=-1, help="GEMM LDS pipeline variant (0/1)")
     args = ap.parse_args()
     from segmentron_amd._lib import LIB
-    if args.dbuf >= 0:
-        LIB.query("seg_conv_gemm_config", args.dbuf)
-        LIB.query("seg_conv_gemm_wgrad_config", args.dbuf)
     dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     out = []
     for i, (name, N, H, W, C, O) in enumerate(SHAPES):
@@ -54,7 +50,7 @@ def main():
         s = torch.rand(C, device="cuda") + 0.5
         t = torch.randn(C, device="cuda") * 0.1
         flop = 2.0 * N * H * W * C * O
-        r = {"shape": name, "GFLOP": flop / 1e9, "dbuf": LIB.query("seg_conv_gemm_config", -1)}
+        r = {"shape": name, "GFLOP": flop / 1e9}
         r["fwd_plain_TF"] = flop / timeit(lambda: K.conv_gemm(x, w, O, 1, 1, 1, 0, 1), args.iters) / 1e12
         r["fwd_stats_TF"] = flop / timeit(
             lambda: K.conv_gemm(x, w, O, 1, 1, 1, 0, 1, want_stats=True), args.iters) / 1e12
