@@ -142,12 +142,6 @@ int seg_bn_finalize_p(const float* partial, long R, double count, const float* g
                       const float* beta, float eps, float momentum, float* running_mean,
                       float* running_var, float* mean, float* invstd, float* scale, float* shift,
                       int C, const float* mean_offset, double* ws, void* stream);
-/* The same with the running-mean offset given as `offset_rows` partial rows [offset_rows][C],
- * summed here (the b' partials of seg_fold_weights_fin). */
-int seg_bn_finalize_po(const float* partial, long R, double count, const float* gamma,
-                       const float* beta, float eps, float momentum, float* running_mean,
-                       float* running_var, float* mean, float* invstd, float* scale, float* shift,
-                       int C, const float* mean_offset, int offset_rows, double* ws, void* stream);
 /* eval mode: scale/shift from running statistics. */
 int seg_bn_eval_affine(const float* gamma, const float* beta, const float* rm, const float* rv,
                        float eps, float* scale, float* shift, int C, void* stream);
@@ -199,19 +193,6 @@ int seg_bn_bwd_apply(int dtype, const void* g, long ldg, const void* x, long ldx
  *                caller between the two calls under SyncBN. */
 int seg_fold_weights(int dtype, const float* W, const float* scale, const float* shift, void* Wp,
                      void* WpT, float* bprime, int O, int C, void* stream);
-/* seg_bn_finalize_p of the folded BatchNorm (statistics rows `partial` [R][2][C] of the tensor
- * the 1x1 convolution reads) AND seg_fold_weights in one launch: mean / invstd / scale / shift
- * [C] and the running statistics are produced as by seg_bn_finalize_p; Wp / WpT as by
- * seg_fold_weights; b' = W shift arrives as seg_fold_weights_fin_rows(C) partial rows
- * bpart[rows][O] (nullable) whose sum is b' (seg_bn_finalize_po takes them as they are).
- * Needs C % 4 == 0, O % 8 == 0, R <= 1024.  Reference: the bn_depth -> pointwise pair of
- * segmentron/modules/basic.py:41-42 in training mode. */
-int seg_fold_weights_fin_rows(int C);
-int seg_fold_weights_fin(int dtype, const float* W, const float* partial, int R, double count,
-                         const float* gamma, const float* beta, float eps, float momentum,
-                         float* running_mean, float* running_var, float* mean, float* invstd,
-                         float* scale, float* shift, void* Wp, void* WpT, float* bpart, int O,
-                         int C, void* stream);
 /* dWp: the weight-gradient split partials [splits][O*C] as written by seg_conv_gemm_wgrad (summed
  * here); dsdt: [seg_fold_bwd_rows(O)][2][C] partial (ds, dt) rows, summed by the finalize. */
 int seg_fold_bwd_rows(int O);

@@ -412,7 +412,7 @@ __global__ __launch_bounds__(EW_THREADS) void bn_finalize_p_kernel(
     const TIN* __restrict__ part, int R, double count, const float* __restrict__ gamma,
     const float* __restrict__ beta, float eps, float momentum, float* running_mean,
     float* running_var, float* mean_o, float* invstd_o, float* scale_o, float* shift_o, int C,
-    const float* __restrict__ mean_offset, int offset_rows) {
+    const float* __restrict__ mean_offset) {
   __shared__ double red[2][32][9];
   const int cx = threadIdx.x & 7, ry = threadIdx.x >> 3;
   const int c = blockIdx.x * 8 + cx;
@@ -422,9 +422,7 @@ __global__ __launch_bounds__(EW_THREADS) void bn_finalize_p_kernel(
     if (gamma) g = gamma[c];
     if (beta) b = beta[c];
     if (running_mean) { rm = running_mean[c]; rv = running_var[c]; }
-    if (mean_offset) {  // [offset_rows][C] partial rows (seg_fold_weights_fin) or one row
-      for (int r = 0; r < offset_rows; ++r) moff += mean_offset[(long)r * C + c];
-    }
+    if (mean_offset) moff = mean_offset[c];
   }
   double sx, sxx;
   reduce_two_columns<TIN>(part, R, C, c, ry, cx, red, sx, sxx);
@@ -705,11 +703,11 @@ extern "C" int seg_bn_bwd_apply(int dtype, const void* g, long ldg, const void* 
 
 // Fused (non-sync) variants: partial rows [R][2][C] fp32 straight from the conv / reduce kernels.
 // ws: >= 64*2*C doubles, only touched when R > 1024 (two-level reduction).
-static int bn_finalize_p_impl(const float* partial, long R, double count, const float* gamma,
-                              const float* beta, float eps, float momentum, float* running_mean,
-                              float* running_var, float* mean, float* invstd, float* scale,
-                              float* shift, int C, const float* mean_offset, int offset_rows,
-                              double* ws, void* stream) {
+extern "C" int seg_bn_finalize_p(const float* partial, long R, double count, const float* gamma,
+                                 const float* beta, float eps, float momentum,
+                                 float* running_mean, float* running_var, float* mean,
+                                 float* invstd, float* scale, float* shift, int C,
+                                 const float* mean_offset, double* ws, void* stream) {
   using namespace seg;
   SEG_REQUIRE(count >= 1.0 && C >= 1 && R >= 1, "bn_finalize_p: bad count/C/R");
   hipStream_t st = (hipStream_t)stream;
@@ -717,40 +715,16 @@ static int bn_finalize_p_impl(const float* partial, long R, double count, const 
   if (R <= 1024) {
     hipLaunchKernelGGL((bn_finalize_p_kernel<float>), grid, dim3(EW_THREADS), 0, st, partial,
                        (int)R, count, gamma, beta, eps, momentum, running_mean, running_var, mean,
-                       invstd, scale, shift, C, mean_offset, offset_rows);
+                       invstd, scale, shift, C, mean_offset);
   } else {
     SEG_REQUIRE(ws != nullptr, "bn_finalize_p: workspace required for R=%ld", R);
     hipLaunchKernelGGL((colsum_kernel<double>), dim3((2 * C + 31) / 32, 64), dim3(EW_THREADS), 0,
                        st, partial, R, 2 * C, ws);
     hipLaunchKernelGGL((bn_finalize_p_kernel<double>), grid, dim3(EW_THREADS), 0, st, ws, 64,
                        count, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd,
-                       scale, shift, C, mean_offset, offset_rows);
+                       scale, shift, C, mean_offset);
   }
   return check_launch("bn_finalize_p");
-}
-
-extern "C" int seg_bn_finalize_p(const float* partial, long R, double count, const float* gamma,
-                                 const float* beta, float eps, float momentum,
-                                 float* running_mean, float* running_var, float* mean,
-                                 float* invstd, float* scale, float* shift, int C,
-                                 const float* mean_offset, double* ws, void* stream) {
-  return bn_finalize_p_impl(partial, R, count, gamma, beta, eps, momentum, running_mean,
-                            running_var, mean, invstd, scale, shift, C, mean_offset, 1, ws, stream);
-}
-
-// the same with the running-mean offset given as `offset_rows` partial rows [offset_rows][C]
-// that are summed here (the per-tile-column b' partials of seg_fold_weights_fin)
-extern "C" int seg_bn_finalize_po(const float* partial, long R, double count, const float* gamma,
-                                  const float* beta, float eps, float momentum,
-                                  float* running_mean, float* running_var, float* mean,
-                                  float* invstd, float* scale, float* shift, int C,
-                                  const float* mean_offset, int offset_rows, double* ws,
-                                  void* stream) {
-  SEG_REQUIRE(mean_offset != nullptr && offset_rows >= 1 && offset_rows <= 64,
-              "bn_finalize_po: bad offset rows");
-  return bn_finalize_p_impl(partial, R, count, gamma, beta, eps, momentum, running_mean,
-                            running_var, mean, invstd, scale, shift, C, mean_offset, offset_rows,
-                            ws, stream);
 }
 
 extern "C" int seg_bn_bwd_finalize_p(const float* partial, long R, double count,

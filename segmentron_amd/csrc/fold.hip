@@ -99,131 +99,6 @@ __global__ __launch_bounds__(256) void fold_weights_tiled_kernel(
   }
 }
 
-// Fold + the folded BatchNorm's own finalize in ONE launch (61 launches of ~5 us less per C3
-// step): every 64 x 64 tile block first turns the statistics rows [R][2][C] of the depthwise
-// output into (scale, shift) of ITS 64 input channels — fp64, fixed order, every block of a
-// column computes the same numbers — then scales its tile as fold_weights_tiled_kernel does.
-// The blocks of the first tile row publish mean / invstd / scale / shift and update the running
-// statistics (what seg_bn_finalize_p would have done).  b' = W t cannot be finished here (a row
-// needs the shifts of all C channels): each tile emits the partial dot product of its 64 rows
-// over its 64 columns, bpart[tile column][o]; the consumer's BatchNorm finalize sums the rows
-// (seg_bn_finalize_po).
-template <typename T>
-__global__ __launch_bounds__(256) void fold_weights_fin_kernel(
-    const float* __restrict__ W, const float* __restrict__ part, int R, double count,
-    const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
-    float* running_mean, float* running_var, float* mean_o, float* invstd_o, float* scale_o,
-    float* shift_o, T* __restrict__ Wp, T* __restrict__ WpT, float* __restrict__ bpart, int O,
-    int C, int tiles_c) {
-  constexpr int VEC = Vec<T>::N;
-  __shared__ float tile[64][65];
-  __shared__ double red[2][4][64];
-  __shared__ float s_sm[64], t_sm[64];
-  const int tid = threadIdx.x;
-  const int to = blockIdx.x / tiles_c, tc = blockIdx.x - to * tiles_c;
-  const int o0 = to * 64, c0 = tc * 64;
-  // ---- statistics of this block's 64 columns
-  {
-    const int cl = tid & 63, rg = tid >> 6;
-    const int c = c0 + cl;
-    const bool fin = rg == 0 && c < C;
-    float g = 1.f, b = 0.f, rm = 0.f, rv = 0.f;
-    if (fin) {
-      if (gamma) g = gamma[c];
-      if (beta) b = beta[c];
-      if (to == 0 && running_mean) { rm = running_mean[c]; rv = running_var[c]; }
-    }
-    double a0 = 0.0, a1 = 0.0;
-    if (c < C) {
-      int r = rg;
-      for (; r + 12 < R; r += 16) {  // four independent row pairs in flight
-        const float p0 = part[(long)r * 2 * C + c], q0 = part[(long)r * 2 * C + C + c];
-        const float p1 = part[(long)(r + 4) * 2 * C + c], q1 = part[(long)(r + 4) * 2 * C + C + c];
-        const float p2 = part[(long)(r + 8) * 2 * C + c], q2 = part[(long)(r + 8) * 2 * C + C + c];
-        const float p3 = part[(long)(r + 12) * 2 * C + c], q3 = part[(long)(r + 12) * 2 * C + C + c];
-        a0 += (double)p0; a1 += (double)q0;
-        a0 += (double)p1; a1 += (double)q1;
-        a0 += (double)p2; a1 += (double)q2;
-        a0 += (double)p3; a1 += (double)q3;
-      }
-      for (; r < R; r += 4) {
-        a0 += (double)part[(long)r * 2 * C + c];
-        a1 += (double)part[(long)r * 2 * C + C + c];
-      }
-    }
-    red[0][rg][cl] = a0;
-    red[1][rg][cl] = a1;
-    __syncthreads();
-    if (rg == 0) {
-      float sc = 0.f, sh = 0.f;
-      if (fin) {
-        const double sx = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
-        const double sxx = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
-        const double mean = sx / count;
-        double var = sxx / count - mean * mean;
-        if (var < 0.0) var = 0.0;
-        const double invstd = 1.0 / sqrt(var + (double)eps);
-        sc = (float)((double)g * invstd);
-        sh = (float)((double)b - mean * (double)g * invstd);
-        if (to == 0) {
-          mean_o[c] = (float)mean;
-          invstd_o[c] = (float)invstd;
-          scale_o[c] = sc;
-          shift_o[c] = sh;
-          if (running_mean) {
-            const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-            running_mean[c] = (float)((1.0 - momentum) * (double)rm + momentum * mean);
-            running_var[c] = (float)((1.0 - momentum) * (double)rv + momentum * unbiased);
-          }
-        }
-      }
-      s_sm[cl] = sc;
-      t_sm[cl] = sh;
-    }
-    __syncthreads();
-  }
-  // ---- the tile: W' = W diag(s) row-major and transposed, partial b' = W[:, tile columns] t
-  const int cq = tid & 15, r = tid >> 4;
-  const int c = c0 + cq * 4;
-  const float4 sv = make_float4(s_sm[cq * 4], s_sm[cq * 4 + 1], s_sm[cq * 4 + 2], s_sm[cq * 4 + 3]);
-  const float4 tv = make_float4(t_sm[cq * 4], t_sm[cq * 4 + 1], t_sm[cq * 4 + 2], t_sm[cq * 4 + 3]);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int ro = r + 16 * i, o = o0 + ro;
-    float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (o < O && c < C) w = *reinterpret_cast<const float4*>(W + (long)o * C + c);
-    const float f[4] = {w.x * sv.x, w.y * sv.y, w.z * sv.z, w.w * sv.w};
-    if (o < O && c < C) HVec<T>::store(Wp + (long)o * C + c, f);
-    tile[ro][cq * 4 + 0] = f[0];
-    tile[ro][cq * 4 + 1] = f[1];
-    tile[ro][cq * 4 + 2] = f[2];
-    tile[ro][cq * 4 + 3] = f[3];
-    // (columns >= C carry w = 0; their t is 0 as well)
-    float d = fmaf(w.x, tv.x, fmaf(w.y, tv.y, fmaf(w.z, tv.z, w.w * tv.w)));
-    d += __shfl_xor(d, 1, 64);
-    d += __shfl_xor(d, 2, 64);
-    d += __shfl_xor(d, 4, 64);
-    d += __shfl_xor(d, 8, 64);
-    if (cq == 0 && o < O && bpart != nullptr) bpart[(long)tc * O + o] = d;
-  }
-  if (WpT == nullptr) return;
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int idx = tid + 256 * i;
-    const int og = idx & 7, cl = idx >> 3;  // 8 consecutive o of column cl
-    const int o = o0 + og * 8, cc = c0 + cl;
-    if (cc < C && o < O) {  // (O % 8 == 0: the 8 rows exist together)
-      float f[8];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) f[k] = tile[og * 8 + k][cl];
-      T* dst = WpT + (long)cc * O + o;
-#pragma unroll
-      for (int k = 0; k < 8; k += VEC) Vec<T>::store(dst + k, f + k);
-    }
-  }
-}
-
 // dWp arrives as the weight-gradient GEMM's split partials [S][O*C] (summed here in a fixed
 // order: the separate column-sum pass and its 2x2 MB round trip are gone).  Lanes run along c
 // (256 contiguous bytes per row and wave), a block owns 64 columns x one of RS row ranges and
@@ -416,33 +291,6 @@ extern "C" int seg_fold_weights(int dtype, const float* W, const float* scale, c
     hipLaunchKernelGGL((fold_weights_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, W,
                        scale, shift, (float*)Wp, (float*)WpT, bprime, O, C);
   return check_launch("fold_weights");
-}
-
-extern "C" int seg_fold_weights_fin_rows(int C) { return (C + 63) / 64; }
-
-extern "C" int seg_fold_weights_fin(int dtype, const float* W, const float* partial, int R,
-                                    double count, const float* gamma, const float* beta, float eps,
-                                    float momentum, float* running_mean, float* running_var,
-                                    float* mean, float* invstd, float* scale, float* shift, void* Wp,
-                                    void* WpT, float* bpart, int O, int C, void* stream) {
-  using namespace seg;
-  SEG_REQUIRE(dtype == DT_F32 || dtype == DT_BF16, "fold_weights_fin: bad dtype %d", dtype);
-  SEG_REQUIRE(O >= 1 && C >= 1 && W && partial && Wp && mean && invstd && scale && shift,
-              "fold_weights_fin: bad arguments");
-  SEG_REQUIRE(C % 4 == 0 && O % 8 == 0, "fold_weights_fin: needs C %% 4 == 0 and O %% 8 == 0");
-  SEG_REQUIRE(count >= 1.0 && R >= 1, "fold_weights_fin: bad count / rows");
-  const int tiles_c = (C + 63) / 64, tiles = tiles_c * ((O + 63) / 64);
-  if (dtype == DT_BF16)
-    hipLaunchKernelGGL((fold_weights_fin_kernel<bf16_t>), dim3(tiles), dim3(256), 0,
-                       (hipStream_t)stream, W, partial, R, count, gamma, beta, eps, momentum,
-                       running_mean, running_var, mean, invstd, scale, shift, (bf16_t*)Wp,
-                       (bf16_t*)WpT, bpart, O, C, tiles_c);
-  else
-    hipLaunchKernelGGL((fold_weights_fin_kernel<float>), dim3(tiles), dim3(256), 0,
-                       (hipStream_t)stream, W, partial, R, count, gamma, beta, eps, momentum,
-                       running_mean, running_var, mean, invstd, scale, shift, (float*)Wp,
-                       (float*)WpT, bpart, O, C, tiles_c);
-  return check_launch("fold_weights_fin");
 }
 
 extern "C" int seg_fold_bwd_rows(int O) {

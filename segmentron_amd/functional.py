@@ -26,34 +26,13 @@ from .hip_ops import PRO_AFFINE, PRO_NONE, PRO_RELU
 
 # ----------------------------------------------------------------------------- state objects
 class BNState:
-    """One BatchNorm evaluated on one tensor in one forward pass.
+    """One BatchNorm evaluated on one tensor in one forward pass."""
+    __slots__ = ("gamma", "beta", "mean", "invstd", "scale", "shift", "count", "training", "group")
 
-    `pending` (lazy state): the statistics partials have not been finished yet — the consumer
-    that folds this BatchNorm into its weights (`_FoldConvFn`) does that inside its own fold
-    launch (`seg_fold_weights_fin`); any other access to mean / invstd / scale / shift runs the
-    stand-alone finalize first (`ensure`)."""
-    __slots__ = ("gamma", "beta", "_mean", "_invstd", "_scale", "_shift", "count", "training",
-                 "group", "pending")
-
-    def __init__(self, gamma, beta, mean, invstd, scale, shift, count, training, group=None,
-                 pending=None):
+    def __init__(self, gamma, beta, mean, invstd, scale, shift, count, training, group=None):
         self.gamma, self.beta = gamma, beta
-        self._mean, self._invstd, self._scale, self._shift = mean, invstd, scale, shift
+        self.mean, self.invstd, self.scale, self.shift = mean, invstd, scale, shift
         self.count, self.training, self.group = count, training, group
-        self.pending = pending
-
-    def ensure(self):
-        p = self.pending
-        if p is not None:
-            self.pending = None
-            K.bn_finalize_p(p["partial"], self.count, self.gamma, self.beta, p["eps"],
-                            p["momentum"], p["rm"], p["rv"], None,
-                            out=(self._mean, self._invstd, self._scale, self._shift))
-
-    mean = property(lambda self: (self.ensure(), self._mean)[1])
-    invstd = property(lambda self: (self.ensure(), self._invstd)[1])
-    scale = property(lambda self: (self.ensure(), self._scale)[1])
-    shift = property(lambda self: (self.ensure(), self._shift)[1])
 
 
 RELU, RELU6 = 1, 5  # values of `Act.relu`: prologue / mask bits (ReLU6 = relu + clamp-at-6)
@@ -110,12 +89,9 @@ class GradFork:
         return g
 
 
-def finish_bn(bn, partial, count, mean_offset=None, lazy=False):
+def finish_bn(bn, partial, count, mean_offset=None):
     """Turn conv-epilogue partials into a BNState (and update running stats like torch does).
-    bn: nn.BatchNorm2d / nn.SyncBatchNorm module — eps / momentum / training read NOW.
-    mean_offset: [C] or partial rows [rows, C] (summed by the finalize kernel).
-    lazy: single-process training-mode BatchNorm whose finalize may be taken over by the consumer
-    (BNState.pending); the running statistics are updated by whichever launch finishes it."""
+    bn: nn.BatchNorm2d / nn.SyncBatchNorm module — eps / momentum / training read NOW."""
     use_batch = bn.training or bn.running_mean is None
     if not use_batch:
         scale, shift = K.bn_eval_affine(bn.weight, bn.bias, bn.running_mean, bn.running_var,
@@ -133,20 +109,11 @@ def finish_bn(bn, partial, count, mean_offset=None, lazy=False):
     momentum = bn.momentum if bn.momentum is not None else 0.1
     track = bn.training and bn.track_running_stats and bn.running_mean is not None
     rm, rv = (bn.running_mean, bn.running_var) if track else (None, None)
-    if group is None and lazy and mean_offset is None and partial.shape[0] <= 1024:
-        C = partial.shape[-1]
-        out = torch.empty((4, C), dtype=torch.float32, device=partial.device)
-        if track and bn.num_batches_tracked is not None:
-            _PENDING_COUNTERS.append(bn.num_batches_tracked)
-        return BNState(bn.weight, bn.bias, out[0], out[1], out[2], out[3], cnt, True, None,
-                       pending=dict(partial=partial, eps=bn.eps, momentum=momentum, rm=rm, rv=rv))
     if group is None:
         mean, invstd, scale, shift = K.bn_finalize_p(partial, cnt, bn.weight, bn.bias, bn.eps,
                                                      momentum, rm, rv, mean_offset)
     else:
         C = partial.shape[-1]
-        if mean_offset is not None and mean_offset.dim() == 2:
-            mean_offset = mean_offset.sum(0)
         sums = K.colsum(partial.view(partial.shape[0], 2 * C))
         sums, cnt = parallel.allreduce_forward_sums(sums, cnt, group)
         naive = parallel.is_naive_sync(bn)
@@ -369,17 +336,8 @@ class _FoldConvFn(torch.autograd.Function):
         O, C = weight.shape[0], weight.shape[1]
         bn = spec.bn_in
         w2d = weight.detach().view(O, C)
-        if bn.pending is not None and spec.drop_const and C % 4 == 0 and O % 8 == 0:
-            # the folded BatchNorm is finished INSIDE the fold launch; b' = W t (needed for the
-            # consumer's running_mean only) arrives as partial rows
-            p, bn.pending = bn.pending, None
-            wp, wpt, bp = K.fold_weights_fin(w2d, p["partial"], bn.count, bn.gamma, bn.beta,
-                                             p["eps"], p["momentum"], p["rm"], p["rv"],
-                                             (bn._mean, bn._invstd, bn._scale, bn._shift), x.dtype,
-                                             want_transpose=ctx.needs_input_grad[0])
-        else:
-            wp, wpt, bp = K.fold_weights(w2d, bn.scale, bn.shift, x.dtype,
-                                         want_transpose=ctx.needs_input_grad[0])
+        wp, wpt, bp = K.fold_weights(w2d, bn.scale, bn.shift, x.dtype,
+                                     want_transpose=ctx.needs_input_grad[0])
         spec.mean_offset = bp
         # a training-mode BatchNorm right after the conv cancels the constant W@shift exactly, so
         # it is left out of the stored tensor (and only re-enters the running_mean update)
@@ -921,7 +879,7 @@ def dwconv_bn(act, conv, bn, out=None, fork=None):
     g, b = act.params
     y = _DwFn.apply(act.t, g, b, conv.weight, spec)
     N, Ho, Wo, _ = y.shape
-    return Act(y, finish_bn(bn, spec.partial, N * Ho * Wo, lazy=True))
+    return Act(y, finish_bn(bn, spec.partial, N * Ho * Wo))
 
 
 def materialize(act, residual=None, chan_mul=None, post_relu=False, out=None, elem_mul=None,

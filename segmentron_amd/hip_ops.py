@@ -389,24 +389,15 @@ def _ws(R, C, dev):
 
 
 def bn_finalize_p(partial, count, gamma, beta, eps, momentum, running_mean, running_var,
-                  mean_offset=None, out=None):
-    """partial fp32 [R, 2, C] (or [R, 2C]) -> mean, invstd, scale, shift (one fused launch).
-    mean_offset: [C], or partial rows [rows, C] summed by the kernel.  out: four [C] tensors."""
+                  mean_offset=None):
+    """partial fp32 [R, 2, C] (or [R, 2C]) -> mean, invstd, scale, shift (one fused launch)."""
     R = partial.shape[0]
     C = partial.numel() // (2 * R)
-    if out is None:
-        buf = torch.empty((4, C), dtype=torch.float32, device=partial.device)
-        out = (buf[0], buf[1], buf[2], buf[3])
+    out = torch.empty((4, C), dtype=torch.float32, device=partial.device)
     ws = _ws(R, C, partial.device)
-    if mean_offset is not None and mean_offset.dim() == 2:
-        LIB.call("seg_bn_finalize_po", _p(partial), R, float(count), _p(gamma), _p(beta),
-                 float(eps), float(momentum), _p(running_mean), _p(running_var), _p(out[0]),
-                 _p(out[1]), _p(out[2]), _p(out[3]), C, _p(mean_offset), mean_offset.shape[0],
-                 _p(ws), _stream())
-    else:
-        LIB.call("seg_bn_finalize_p", _p(partial), R, float(count), _p(gamma), _p(beta),
-                 float(eps), float(momentum), _p(running_mean), _p(running_var), _p(out[0]),
-                 _p(out[1]), _p(out[2]), _p(out[3]), C, _p(mean_offset), _p(ws), _stream())
+    LIB.call("seg_bn_finalize_p", _p(partial), R, float(count), _p(gamma), _p(beta), float(eps),
+             float(momentum), _p(running_mean), _p(running_var), _p(out[0]), _p(out[1]),
+             _p(out[2]), _p(out[3]), C, _p(mean_offset), _p(ws), _stream())
     return out[0], out[1], out[2], out[3]
 
 
@@ -453,24 +444,6 @@ def fold_weights(w2d, scale, shift, dtype, want_transpose=False, want_bias=True)
     LIB.call("seg_fold_weights", _DT[dtype], _p(w2d), _p(scale), _p(shift), _p(wp), _p(wpt),
              _p(bp), O, C, _stream())
     return wp, wpt, bp
-
-
-def fold_weights_fin(w2d, partial, count, gamma, beta, eps, momentum, running_mean, running_var,
-                     out, dtype, want_transpose=False):
-    """bn_finalize_p(partial) into `out` = (mean, invstd, scale, shift) AND fold_weights with
-    that scale in one launch -> (W*scale in dtype, its transpose or None, b' partial rows
-    [rows, O] whose sum is W@shift)."""
-    O, C = w2d.shape
-    dev = w2d.device
-    R = partial.shape[0]
-    wp = torch.empty((O, C), dtype=dtype, device=dev)
-    wpt = torch.empty((C, O), dtype=dtype, device=dev) if want_transpose else None
-    rows = LIB.query("seg_fold_weights_fin_rows", C)
-    bpart = torch.empty((rows, O), dtype=torch.float32, device=dev)
-    LIB.call("seg_fold_weights_fin", _DT[dtype], _p(w2d), _p(partial), R, float(count), _p(gamma),
-             _p(beta), float(eps), float(momentum), _p(running_mean), _p(running_var), _p(out[0]),
-             _p(out[1]), _p(out[2]), _p(out[3]), _p(wp), _p(wpt), _p(bpart), O, C, _stream())
-    return wp, wpt, bpart
 
 
 def fold_bwd_reduce(w2d, dwp, scale, shift, db=None):

@@ -509,47 +509,6 @@ def test_fold_weights_pack_transpose_and_bias(dtype, O, C):
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
-@pytest.mark.parametrize("O,C,R", [(728, 728, 162), (128, 64, 7), (1024, 728, 33), (40, 300, 1)])
-def test_fold_weights_with_fused_finalize_equals_the_two_launches(dtype, O, C, R):
-    """seg_fold_weights_fin = seg_bn_finalize_p + seg_fold_weights in one launch: the BatchNorm
-    numbers (mean, invstd, scale, shift, running statistics) bit-for-bit those of the stand-alone
-    finalize up to fp64 summation order (1 ulp), the folded weights from them, and the b'
-    partial rows sum to W @ shift; seg_bn_finalize_po consumes the rows as a mean offset."""
-    Km = K()
-    part = (rnd((R, 2, C), 21).abs() * 50 + 5).to(DEV)
-    part[:, 1] = part[:, 1] * 40 + 900           # keep var = E[x^2] - mean^2 positive
-    count = 16770.0 / max(R, 1) * R
-    w = rnd((O, C), 22, 0.3).to(DEV)
-    gamma, beta = (torch.rand(C) + 0.5).to(DEV), rnd((C,), 23, 0.3).to(DEV)
-    rm0, rv0 = rnd((C,), 24, 0.1).to(DEV), (torch.rand(C) + 0.5).to(DEV)
-    rm1, rv1 = rm0.clone(), rv0.clone()
-    mean, invstd, scale, shift = Km.bn_finalize_p(part, count, gamma, beta, 1e-3, 0.1, rm0, rv0)
-    wp, wpt, bp = Km.fold_weights(w, scale, shift, dtype, want_transpose=True)
-    out = torch.empty((4, C), device=DEV)
-    wp2, wpt2, bpart = Km.fold_weights_fin(w, part, count, gamma, beta, 1e-3, 0.1, rm1, rv1,
-                                           (out[0], out[1], out[2], out[3]), dtype,
-                                           want_transpose=True)
-    for a, b, what in ((out[0], mean, "mean"), (out[1], invstd, "invstd"), (out[2], scale, "scale"),
-                       (out[3], shift, "shift"), (rm1, rm0, "running_mean"), (rv1, rv0, "running_var")):
-        assert torch.allclose(a, b, rtol=3e-7, atol=1e-9), what
-    tol = 2 ** -22 if dtype == torch.float32 else 2 ** -7
-    assert ((wp2.float() - wp.float()).abs() <= tol * wp.float().abs() + 1e-7).all()
-    assert torch.equal(wpt2, wp2.t().contiguous())
-    assert bpart.shape == ((C + 63) // 64, O)
-    bref = w.double() @ shift.double()
-    assert (bpart.double().sum(0) - bref).abs().max() <= 1e-5 * (w.abs().double() @ shift.abs().double()).max()
-    # the rows as the consumer's running-mean offset
-    part_o = (rnd((5, 2, O), 25).abs() * 30 + 3).to(DEV)
-    part_o[:, 1] = part_o[:, 1] * 30 + 500
-    g2, b2 = torch.ones(O, device=DEV), torch.zeros(O, device=DEV)
-    ra, va = torch.zeros(O, device=DEV), torch.ones(O, device=DEV)
-    rb, vb = ra.clone(), va.clone()
-    Km.bn_finalize_p(part_o, 500.0, g2, b2, 1e-3, 0.1, ra, va, bpart.sum(0))
-    Km.bn_finalize_p(part_o, 500.0, g2, b2, 1e-3, 0.1, rb, vb, bpart)
-    assert torch.allclose(ra, rb, rtol=1e-6, atol=1e-7) and torch.equal(va, vb)
-
-
-@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
 def test_fold_linear_bn_into_pointwise_matches_autograd(dtype):
     """relu_first SeparableConv2d tail: dw_raw -> BN_train(bn_depth) -> 1x1 conv -> (BN_train
     follows, so the constant W@shift is dropped).  Forward, dW, dgamma, dbeta and dx_raw through
