@@ -226,8 +226,11 @@ bool conv_wgrad_glds_usable(int dtype, const WgradArgs& a) {
   const bool common = dtype == DT_BF16 && a.pro_mode == PRO_NONE && a.stride == 1 &&
                       (a.O % 8) == 0 && (a.ldx % 8) == 0 && (a.lddy % 8) == 0 && a.M >= 2048;
   if (!common) return false;
+  // (narrow outputs — the decoder's 256 -> 48 and the 256 -> 19(24) classifier on 263 k pixels —
+  // waste most of a 128-wide tile's MFMAs but are bound by the one pass over x anyway: 48 / 115 us
+  // on the first-generation kernel, whose 128 x 128 register-transposed tiles re-read x per split)
   if (a.KH == 1 && a.KW == 1)
-    return a.pad == 0 && (a.C % 8) == 0 && (long)a.O * a.C >= 128 * 128;
+    return a.pad == 0 && (a.C % 8) == 0 && ((long)a.O * a.C >= 128 * 128 || a.M >= 32768);
   // KxK: a 128-wide K tile inside one tap, at most one row wrap per 64-pixel slot
   return (a.C % 128) == 0 && a.Wo >= WG_BK && a.O >= 128 &&
          (long)a.N * a.Hi * a.Wi < (1L << 31);

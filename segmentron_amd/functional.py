@@ -287,7 +287,8 @@ class _ConvFn(torch.autograd.Function):
         else:
             dy_full = dy
         Cx = x.shape[-1]
-        dWp = K.conv_wgrad(x, dy, O, KH, KW, s.stride, s.pad, s.dil, s.pro)
+        Ow = dy_full.shape[-1]  # ragged O: the zero-padded gradient keeps the vector kernels usable
+        dWp = K.conv_wgrad(x, dy_full, Ow, KH, KW, s.stride, s.pad, s.dil, s.pro)[:O]
         if KH == 1 and KW == 1 and Cx == Cw:
             dW = dWp.view(O, Cw, 1, 1)
         else:

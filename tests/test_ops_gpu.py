@@ -165,6 +165,10 @@ WGRAD_CASES = [
     (1, 33, 129, 128, 384, 3, 1, 1, 1, 0),
     (1, 70, 66, 256, 136, 3, 1, 4, 4, 0),
     (2, 36, 64, 256, 128, 3, 1, 0, 1, 0),
+    # narrow output on a large map (decoder c1_block 256 -> 48: M >= 32768 -> direct-to-LDS kernel
+    # with a mostly empty 128-wide tile, 128 pixel splits) and a ragged O
+    (1, 190, 180, 256, 48, 1, 1, 0, 1, 0),
+    (1, 182, 181, 64, 24, 1, 1, 0, 1, 0),
 ]
 
 
