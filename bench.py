@@ -40,6 +40,7 @@ batch 2, fp32, 1 warm-up + 2 timed steps (<= 32 threads: oneDNN collapses when o
 the 256-core host); `--cpu-baseline-size HxW` bounds it for quick runs.
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -267,12 +268,56 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    # SEG_BENCH_FORCE_DDP=1 (test plumbing): the N > 1 machinery — RCCL process group,
+    # convert_sync_batchnorm with the statistics all-reduces forced on, gradient averaging — with
+    # ONE rank, so that a single-GPU box exercises the RCCL calls (also inside the HIP graph)
+    force_ddp = os.environ.get("SEG_BENCH_FORCE_DDP") == "1" and world == 1 and conf["train"]
+    multi = world > 1 or force_ddp
+    # N > 1 data-parallel mode:
+    #   native (default) — SyncBN statistics and gradient averaging as direct RCCL calls
+    #                      (segmentron_amd/rccl.py) on the compute stream, the WHOLE step incl. the
+    #                      collectives captured into one HIP graph;
+    #   ddp              — torch DistributedDataParallel + torch.distributed all-reduces, eager
+    #                      launches (ProcessGroupNCCL cannot be captured on this stack)
+    dp_mode = os.environ.get("SEG_BENCH_DP", "native") if (multi and conf["train"]) else None
+    if one_dev and dp_mode == "native":
+        dp_mode = "ddp"  # gloo ranks on one device: no RCCL
+    comm = None
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if one_dev:
-            dist.init_process_group("gloo", init_method="env://")
-        else:
-            dist.init_process_group("nccl", init_method="env://", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        # RCCL prints its version banner on STDOUT at communicator creation: the one JSON line
+        # of this program must stay the only thing there
+        sys.stdout.flush()
+        saved_out = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if one_dev:
+                dist.init_process_group("gloo", init_method="env://")
+            else:
+                dist.init_process_group("nccl", init_method="env://", device_id=dev)
+                warm = torch.zeros(1, device=dev)
+                dist.all_reduce(warm)  # creates torch's communicator (banner) now
+                torch.cuda.synchronize()
+            if dp_mode == "native":
+                try:
+                    from segmentron_amd import parallel as SP
+                    from segmentron_amd import rccl as SR
+                    comm = SR.communicator_from_torch_group()
+                    SP.use_native_rccl(comm)
+                except Exception as e:  # noqa: BLE001 — every rank takes the same branch
+                    sys.stderr.write("bench.py: native RCCL communicator unavailable (%r): "
+                                     "torch DDP, eager\n" % (e,))
+                    dp_mode, comm = "ddp", None
+        finally:
+            sys.stdout.flush()
+            ctypes.CDLL(None).fflush(None)  # the banner sits in libc's stdout buffer
+            os.dup2(saved_out, 1)
+            os.close(saved_out)
+        if force_ddp:
+            os.environ["SEG_SYNC_FORCE"] = "1"  # parallel.sync_group: all-reduce with one rank
 
     import segmentron_amd
     from segmentron_amd.config import cfg, reset_cfg
@@ -292,10 +337,14 @@ def main():
     model = model.to(dev).train(train)
     opt = None
     if train:
-        if world > 1:
+        if multi:
             model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)  # tools/train.py:76
-            model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local],
-                                                              output_device=local)
+            if dp_mode == "ddp":
+                model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local],
+                                                                  output_device=local)
+            elif world > 1:  # what DDP's constructor does: everybody starts from rank 0's state
+                for t in model.state_dict().values():
+                    dist.broadcast(t, src=0)
         params = [{"params": model.parameters(), "lr": cfg.SOLVER.LR}]
         sgd = dict(lr=cfg.SOLVER.LR, momentum=cfg.SOLVER.MOMENTUM,
                    weight_decay=cfg.SOLVER.WEIGHT_DECAY)  # solver/optimizer.py:45-66
@@ -323,25 +372,37 @@ def main():
         loss = loss_fn(model(images), targets)
         opt.zero_grad(set_to_none=True)
         loss.backward()
+        if post_backward is not None:
+            post_backward()
         opt.step()
         return loss
+
+    post_backward = None
+    if train and dp_mode == "native":
+        from segmentron_amd import parallel as SP
+        dp_params = list(model.parameters())
+        post_backward = lambda: SP.average_gradients(dp_params)  # noqa: E731 — DDP's mean
 
     timer = GemmTimer()
     # ---- launch path: one HIP graph of the whole step (single GPU), else eager
     graph, graph_err = None, None
-    use_graph = (world == 1 or not train) and not args.no_graph and \
-        os.environ.get("SEG_BENCH_GRAPH", "1") != "0"
+    use_graph = (not multi or not train or dp_mode == "native") and not args.no_graph \
+        and os.environ.get("SEG_BENCH_GRAPH", "1") != "0"
     from segmentron_amd import functional as SF
     from segmentron_amd import graph as SG
     if use_graph:
         try:  # segmentron_amd/graph.py: eager warm-up on a side stream, then ONE capture
             if train:
-                graph = SG.GraphedTrainStep(model, opt, images, targets, loss_fn)
+                graph = SG.GraphedTrainStep(model, opt, images, targets, loss_fn,
+                                            post_backward=post_backward)
             else:
                 graph = SG.GraphedInference(model, images)
         except Exception as e:  # noqa: BLE001
             graph, graph_err = None, repr(e)[:300]
             sys.stderr.write("bench.py: HIP-graph capture failed, running eager: %s\n" % graph_err)
+            if os.environ.get("SEG_BENCH_DEBUG") == "1":
+                import traceback
+                traceback.print_exc()
             torch.cuda.synchronize()
             SF.clear_weight_cache()
     if graph is None:
@@ -459,8 +520,10 @@ def main():
             "config": {"workload": "%s @%dx%d, batch %d/GPU (%s)"
                                    % (conf["workload"], args.height, args.width, batch, conf["tag"]),
                        "global_batch": world * batch,
-                       "bn": ("SyncBN" if world > 1 else "BN") if train else "eval (running stats)",
+                       "bn": ("SyncBN" if (world > 1 or force_ddp) else "BN") if train
+                       else "eval (running stats)",
                        "parallelism": ("dp%d" % world) if train else ("replicas x%d" % world),
+                       "dp_mode": dp_mode,
                        "full_size": full, "loss" if train else "mean_abs_logit": loss_value},
             "model_flop_fraction_of_bf16_mfma_peak":
                 value / world * FLOP_FWD_BWD_PER_IMAGE / MFMA_BF16_PEAK

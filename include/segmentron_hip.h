@@ -124,6 +124,10 @@ int seg_dwconv3x3_bwd_fused_add(int dtype, const void* dy, long lddy, const void
 /* out[l] = sum_r in[r][l]  (in: fp32 [R][L]); ws: >= 64*L doubles (needed when R > 128). */
 int seg_colsum(const float* in, long R, int L, double* out_d, float* out_f, double* ws,
                void* stream);
+/* float64 column sums with the local element count appended (out_d[L] = count): the
+ * SyncBatchNorm forward message of one BatchNorm, assembled by one launch. */
+int seg_colsum_count(const float* in, long R, int L, double* out_d, double count, double* ws,
+                     void* stream);
 /* sums = [sum x (C), sum x^2 (C)] over `count` samples.  Writes mean, invstd (biased var),
  * scale = gamma*invstd, shift = beta - mean*scale; updates running stats (nullable) with the
  * unbiased variance and `momentum`.  mean_offset (nullable, [C]) is added to the batch mean for the
@@ -165,6 +169,12 @@ int seg_bn_bwd_reduce(int dtype, const void* g, long ldg, const void* x, long ld
 int seg_bn_bwd_finalize(const double* sums, double count, const double* count_dev,
                         const float* mean, const float* invstd, const float* gamma, float* dgamma, float* dbeta, float* c0, float* c1,
                         int C, void* stream);
+/* seg_bn_bwd_finalize with dgamma / dbeta multiplied by grad_scale (SyncBatchNorm: the sums are
+ * global and the data-parallel gradient averaging divides by the world size once more — torch's
+ * SyncBatchNorm returns local sums there, torch/nn/modules/_functions.py:150-170). */
+int seg_bn_bwd_finalize_s(const double* sums, double count, const double* count_dev,
+                          const float* mean, const float* invstd, const float* gamma, float* dgamma,
+                          float* dbeta, float* c0, float* c1, int C, double grad_scale, void* stream);
 int seg_bn_bwd_finalize_p(const float* partial, long R, double count, const float* mean,
                           const float* invstd, const float* gamma, float* dgamma, float* dbeta,
                           float* c0, float* c1, int C, double* ws, void* stream);
@@ -202,6 +212,11 @@ int seg_fold_bwd_reduce(const float* W, const float* dWp, int splits, const floa
 int seg_fold_bwd_finalize(const float* dsdt, int rows, double count, const double* count_dev,
                           const float* mean, const float* invstd, const float* gamma, const float* scale, float* dgamma, float* dbeta,
                           float* c0, float* c1, int C, void* stream);
+/* the same with dgamma / dbeta multiplied by grad_scale (SyncBatchNorm: 1 / world size) */
+int seg_fold_bwd_finalize_s(const float* dsdt, int rows, double count, const double* count_dev,
+                            const float* mean, const float* invstd, const float* gamma,
+                            const float* scale, float* dgamma, float* dbeta, float* c0, float* c1,
+                            int C, double grad_scale, void* stream);
 
 /* ---- pooling --------------------------------------------------------------------------------
  * nn.MaxPool2d(k, stride, pad) (segmentron/models/backbones/resnet.py:119) on a deferred

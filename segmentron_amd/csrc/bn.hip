@@ -22,9 +22,14 @@ constexpr int EW_UN = 4;  // rows per thread per iteration in the row-tile kerne
 
 // ------------------------------------------------------------------ column sums of partials
 // in [R][L] fp32 -> out[gridDim.y][L] (fp64 or fp32)
+// `tail` (nullable): out[L] = *tail is written by the first block — the SyncBatchNorm message is
+// [column sums | local element count] (parallel.allreduce_forward_sums), assembled here instead
+// of by a copy and a fill launch.
 template <typename TOUT>
 __global__ __launch_bounds__(EW_THREADS) void colsum_kernel(const float* __restrict__ in, long R,
-                                                            int L, TOUT* __restrict__ out) {
+                                                            int L, TOUT* __restrict__ out,
+                                                            double tail = 0.0, int has_tail = 0) {
+  if (has_tail && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) out[L] = (TOUT)tail;
   __shared__ double red[8][33];
   const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
   const int col = blockIdx.x * 32 + cx;
@@ -47,7 +52,9 @@ __global__ __launch_bounds__(EW_THREADS) void colsum_kernel(const float* __restr
 
 __global__ __launch_bounds__(EW_THREADS) void colsum_f64_kernel(const double* __restrict__ in,
                                                                 int R, int L, double* out_d,
-                                                                float* out_f) {
+                                                                float* out_f, double tail = 0.0,
+                                                                int has_tail = 0) {
+  if (has_tail && blockIdx.x == 0 && threadIdx.x == 0 && out_d) out_d[L] = tail;
   const int col = blockIdx.x * EW_THREADS + threadIdx.x;
   if (col >= L) return;
   double t = 0.0;
@@ -313,12 +320,16 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_reduce_kernel(const BwdArgs
   }
 }
 
+// grad_scale: factor on the PARAMETER gradients only (SyncBatchNorm: the sums are global, and the
+// data-parallel gradient averaging divides by the world size once more — 1 / world here keeps the
+// averaged value equal to the reference's, parallel.local_param_grads)
 __global__ void bn_bwd_finalize_kernel(const double* __restrict__ sums, double count,
                                        const double* __restrict__ count_dev,
                                        const float* __restrict__ mean,
                                        const float* __restrict__ invstd,
                                        const float* __restrict__ gamma, float* dgamma,
-                                       float* dbeta, float* c0_o, float* c1_o, int C) {
+                                       float* dbeta, float* c0_o, float* c1_o, int C,
+                                       double grad_scale = 1.0) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   if (count_dev) count = *count_dev;
@@ -329,8 +340,8 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ sums, double c
   const double s = g * is;
   const double m1 = sg / count, m2 = dg / count;
   const double c1 = s * m2 * is;
-  if (dgamma) dgamma[c] = (float)dg;
-  if (dbeta) dbeta[c] = (float)sg;
+  if (dgamma) dgamma[c] = (float)(dg * grad_scale);
+  if (dbeta) dbeta[c] = (float)(sg * grad_scale);
   c1_o[c] = (float)c1;
   c0_o[c] = (float)(s * m1 - c1 * mu);
 }
@@ -551,16 +562,37 @@ extern "C" int seg_colsum(const float* in, long R, int L, double* out_d, float* 
   const dim3 grid((L + 31) / 32, gy);
   if (gy == 1) {
     if (out_d)
-      hipLaunchKernelGGL((colsum_kernel<double>), grid, dim3(EW_THREADS), 0, st, in, R, L, out_d);
+      hipLaunchKernelGGL((colsum_kernel<double>), grid, dim3(EW_THREADS), 0, st, in, R, L, out_d, 0.0, 0);
     if (out_f)
-      hipLaunchKernelGGL((colsum_kernel<float>), grid, dim3(EW_THREADS), 0, st, in, R, L, out_f);
+      hipLaunchKernelGGL((colsum_kernel<float>), grid, dim3(EW_THREADS), 0, st, in, R, L, out_f, 0.0, 0);
     return check_launch("colsum");
   }
   SEG_REQUIRE(ws != nullptr, "colsum: workspace required for R=%ld", R);
-  hipLaunchKernelGGL((colsum_kernel<double>), grid, dim3(EW_THREADS), 0, st, in, R, L, ws);
+  hipLaunchKernelGGL((colsum_kernel<double>), grid, dim3(EW_THREADS), 0, st, in, R, L, ws, 0.0, 0);
   hipLaunchKernelGGL(colsum_f64_kernel, dim3((L + EW_THREADS - 1) / EW_THREADS), dim3(EW_THREADS),
-                     0, st, ws, gy, L, out_d, out_f);
+                     0, st, ws, gy, L, out_d, out_f, 0.0, 0);
   return check_launch("colsum");
+}
+
+// float64 column sums with the local element count appended: out_d[0..L) = sums, out_d[L] = count
+extern "C" int seg_colsum_count(const float* in, long R, int L, double* out_d, double count,
+                                double* ws, void* stream) {
+  using namespace seg;
+  SEG_REQUIRE(R >= 1 && L >= 1 && out_d, "colsum_count: empty");
+  hipStream_t st = (hipStream_t)stream;
+  int gy = (int)((R + 127) / 128);
+  if (gy > 64) gy = 64;
+  const dim3 grid((L + 31) / 32, gy);
+  if (gy == 1) {
+    hipLaunchKernelGGL((colsum_kernel<double>), grid, dim3(EW_THREADS), 0, st, in, R, L, out_d,
+                       count, 1);
+    return check_launch("colsum_count");
+  }
+  SEG_REQUIRE(ws != nullptr, "colsum_count: workspace required for R=%ld", R);
+  hipLaunchKernelGGL((colsum_kernel<double>), grid, dim3(EW_THREADS), 0, st, in, R, L, ws, 0.0, 0);
+  hipLaunchKernelGGL(colsum_f64_kernel, dim3((L + EW_THREADS - 1) / EW_THREADS), dim3(EW_THREADS),
+                     0, st, ws, gy, L, out_d, (float*)nullptr, count, 1);
+  return check_launch("colsum_count");
 }
 
 extern "C" int seg_bn_finalize(const double* sums, double count, const double* count_dev,
@@ -667,7 +699,19 @@ extern "C" int seg_bn_bwd_finalize(const double* sums, double count, const doubl
   using namespace seg;
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0,
                      (hipStream_t)stream, sums, count, count_dev, mean, invstd, gamma, dgamma,
-                     dbeta, c0, c1, C);
+                     dbeta, c0, c1, C, 1.0);
+  return check_launch("bn_bwd_finalize");
+}
+
+// the same with dgamma / dbeta multiplied by grad_scale (SyncBatchNorm: 1 / world size)
+extern "C" int seg_bn_bwd_finalize_s(const double* sums, double count, const double* count_dev,
+                                     const float* mean, const float* invstd, const float* gamma,
+                                     float* dgamma, float* dbeta, float* c0, float* c1, int C,
+                                     double grad_scale, void* stream) {
+  using namespace seg;
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0,
+                     (hipStream_t)stream, sums, count, count_dev, mean, invstd, gamma, dgamma,
+                     dbeta, c0, c1, C, grad_scale);
   return check_launch("bn_bwd_finalize");
 }
 
@@ -719,7 +763,7 @@ extern "C" int seg_bn_finalize_p(const float* partial, long R, double count, con
   } else {
     SEG_REQUIRE(ws != nullptr, "bn_finalize_p: workspace required for R=%ld", R);
     hipLaunchKernelGGL((colsum_kernel<double>), dim3((2 * C + 31) / 32, 64), dim3(EW_THREADS), 0,
-                       st, partial, R, 2 * C, ws);
+                       st, partial, R, 2 * C, ws, 0.0, 0);
     hipLaunchKernelGGL((bn_finalize_p_kernel<double>), grid, dim3(EW_THREADS), 0, st, ws, 64,
                        count, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd,
                        scale, shift, C, mean_offset);
@@ -741,7 +785,7 @@ extern "C" int seg_bn_bwd_finalize_p(const float* partial, long R, double count,
   } else {
     SEG_REQUIRE(ws != nullptr, "bn_bwd_finalize_p: workspace required for R=%ld", R);
     hipLaunchKernelGGL((colsum_kernel<double>), dim3((2 * C + 31) / 32, 64), dim3(EW_THREADS), 0,
-                       st, partial, R, 2 * C, ws);
+                       st, partial, R, 2 * C, ws, 0.0, 0);
     hipLaunchKernelGGL((bn_bwd_finalize_p_kernel<double>), grid, dim3(EW_THREADS), 0, st, ws, 64,
                        count, mean, invstd, gamma, dgamma, dbeta, c0, c1, C);
   }

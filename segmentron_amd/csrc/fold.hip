@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) void fold_bwd_finalize_kernel(
     const float* __restrict__ dsdt, int R, double count, const double* __restrict__ count_dev,
     const float* __restrict__ mean, const float* __restrict__ invstd,
     const float* __restrict__ gamma, const float* __restrict__ scale, float* dgamma, float* dbeta,
-    float* c0, float* c1, int C) {
+    float* c0, float* c1, int C, double grad_scale) {
   __shared__ double red[2][4][64];
   const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
@@ -257,8 +257,8 @@ __global__ __launch_bounds__(256) void fold_bwd_finalize_kernel(
   const double g = gf;
   const double u = ds - mu * dt;
   const double A = g * u * is * is * is / count;
-  if (dgamma) dgamma[c] = (float)(is * u);
-  if (dbeta) dbeta[c] = (float)dt;
+  if (dgamma) dgamma[c] = (float)(is * u * grad_scale);
+  if (dbeta) dbeta[c] = (float)(dt * grad_scale);
   c1[c] = (float)A;
   c0[c] = (float)(dt * (double)scf / count - A * mu);
 }
@@ -313,17 +313,35 @@ extern "C" int seg_fold_bwd_reduce(const float* W, const float* dWp, int splits,
   return check_launch("fold_bwd_reduce");
 }
 
-extern "C" int seg_fold_bwd_finalize(const float* dsdt, int rows, double count,
-                                     const double* count_dev, const float* mean,
-                                     const float* invstd, const float* gamma, const float* scale,
-                                     float* dgamma, float* dbeta, float* c0, float* c1, int C,
-                                     void* stream) {
+static int fold_bwd_finalize_impl(const float* dsdt, int rows, double count,
+                                  const double* count_dev, const float* mean, const float* invstd,
+                                  const float* gamma, const float* scale, float* dgamma,
+                                  float* dbeta, float* c0, float* c1, int C, double grad_scale,
+                                  void* stream) {
   using namespace seg;
   SEG_REQUIRE((count_dev || count >= 1.0) && C >= 1 && rows >= 1,
               "fold_bwd_finalize: bad count/C/rows");
   hipLaunchKernelGGL(fold_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0,
                      (hipStream_t)stream, dsdt, rows, count, count_dev, mean, invstd, gamma, scale,
-                     dgamma, dbeta,
-                     c0, c1, C);
+                     dgamma, dbeta, c0, c1, C, grad_scale);
   return check_launch("fold_bwd_finalize");
+}
+
+extern "C" int seg_fold_bwd_finalize(const float* dsdt, int rows, double count,
+                                     const double* count_dev, const float* mean,
+                                     const float* invstd, const float* gamma, const float* scale,
+                                     float* dgamma, float* dbeta, float* c0, float* c1, int C,
+                                     void* stream) {
+  return fold_bwd_finalize_impl(dsdt, rows, count, count_dev, mean, invstd, gamma, scale, dgamma,
+                                dbeta, c0, c1, C, 1.0, stream);
+}
+
+// the same with dgamma / dbeta multiplied by grad_scale (SyncBatchNorm: 1 / world size)
+extern "C" int seg_fold_bwd_finalize_s(const float* dsdt, int rows, double count,
+                                       const double* count_dev, const float* mean,
+                                       const float* invstd, const float* gamma,
+                                       const float* scale, float* dgamma, float* dbeta, float* c0,
+                                       float* c1, int C, double grad_scale, void* stream) {
+  return fold_bwd_finalize_impl(dsdt, rows, count, count_dev, mean, invstd, gamma, scale, dgamma,
+                                dbeta, c0, c1, C, grad_scale, stream);
 }

@@ -114,8 +114,8 @@ def finish_bn(bn, partial, count, mean_offset=None):
                                                      momentum, rm, rv, mean_offset)
     else:
         C = partial.shape[-1]
-        sums = K.colsum(partial.view(partial.shape[0], 2 * C))
-        sums, cnt = parallel.allreduce_forward_sums(sums, cnt, group)
+        sums, cnt = parallel.allreduce_forward_sums(partial.view(partial.shape[0], 2 * C), cnt,
+                                                    group)
         naive = parallel.is_naive_sync(bn)
         if naive:  # the reference's own SyncBN: biased running_var, no counter (batch_norm.py:174)
             rm = rv = None
@@ -157,13 +157,12 @@ def bn_input_backward(g, x, bn, relu, chan_mul=None, inplace=False, elem_mul=Non
                                                     bn.gamma)
     else:
         sums = parallel.allreduce_backward_sums(K.colsum(partial), bn.group)
-        dgamma, dbeta, c0, c1 = K.bn_bwd_finalize(sums, bn.count, bn.mean, bn.invstd, bn.gamma)
+        dgamma, dbeta, c0, c1 = K.bn_bwd_finalize(sums, bn.count, bn.mean, bn.invstd, bn.gamma,
+                                                  parallel.grad_scale(bn.group))
     if not bn.training:
         c0 = c1 = None
     dx = K.bn_bwd_apply(g, x, pro, c0, c1, chan_mul, out=g if inplace else None,
                         elem_mul=elem_mul)
-    if bn.group is not None:
-        dgamma, dbeta = parallel.local_param_grads(dgamma, dbeta, bn.group)
     return dx, dgamma, dbeta
 
 
@@ -366,10 +365,9 @@ class _FoldConvFn(torch.autograd.Function):
         if bn.group is not None:
             dsdt = K.colsum(dsdt, f64=False)
             parallel.allreduce_backward_sums(dsdt, bn.group)
-        dgamma, dbeta, c0, c1 = K.fold_bwd_finalize(dsdt, bn.count, bn.mean, bn.invstd, bn.gamma,
-                                                    bn.scale)
-        if bn.group is not None:
-            dgamma, dbeta = parallel.local_param_grads(dgamma, dbeta, bn.group)
+        dgamma, dbeta, c0, c1 = K.fold_bwd_finalize(
+            dsdt, bn.count, bn.mean, bn.invstd, bn.gamma, bn.scale,
+            parallel.grad_scale(bn.group) if bn.group is not None else 1.0)
         dx = None
         if ctx.needs_input_grad[0]:
             if s.stride == 1:
@@ -455,8 +453,7 @@ class _DwFn(torch.autograd.Function):
                 else:
                     sums = parallel.allreduce_backward_sums(K.colsum(pb), bn.group)
                     dgamma, dbeta, c0, c1 = K.bn_bwd_finalize(sums, bn.count, bn.mean, bn.invstd,
-                                                              bn.gamma)
-                    dgamma, dbeta = parallel.local_param_grads(dgamma, dbeta, bn.group)
+                                                              bn.gamma, parallel.grad_scale(bn.group))
                 if not bn.training:
                     c0 = c1 = None
                 # the ReLU mask is already in g: apply only the affine part of the BN backward

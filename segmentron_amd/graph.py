@@ -13,8 +13,10 @@ allocation, no host synchronisation), so a fixed-shape pass is captured ONCE int
     loss = step()                                        # forward + loss + backward + optimizer
 
 The static input / output tensors belong to the graph: results are overwritten by the next call.
-One process per GPU, single stream; DistributedDataParallel / SyncBatchNorm steps stay eager
-(their collectives would have to be captured too, which has not been validated on RCCL here).
+One process per GPU, single stream.  Data-parallel steps are captured too when their exchange
+steps are direct RCCL calls (`parallel.use_native_rccl`, `GraphedTrainStep(post_backward=...)`);
+DistributedDataParallel / torch.distributed collectives stay eager (ProcessGroupNCCL's watchdog
+aborts on events recorded in a capturing stream — measured r03).
 """
 import torch
 
@@ -58,13 +60,19 @@ class GraphedInference:
 class GraphedTrainStep:
     """forward -> loss_fn(outputs, targets) -> backward -> optimizer.step() as one graph."""
 
-    def __init__(self, model, optimizer, images, targets, loss_fn, warmup=3):
+    def __init__(self, model, optimizer, images, targets, loss_fn, warmup=3, post_backward=None):
+        """post_backward: called between backward and the optimizer step — the data-parallel
+        gradient averaging (`parallel.average_gradients`: direct RCCL calls on the capturing
+        stream become nodes of the graph; torch.distributed collectives do NOT survive a capture
+        on this stack, see segmentron_amd/rccl.py)."""
         self.images, self.targets = images, targets
 
         def eager():
             loss = loss_fn(model(self.images), self.targets)
             optimizer.zero_grad(set_to_none=True)
             loss.backward()
+            if post_backward is not None:
+                post_backward()
             optimizer.step()
             return loss
         self.eager = eager
@@ -75,6 +83,8 @@ class GraphedTrainStep:
         with torch.cuda.graph(self.graph):
             self.loss = loss_fn(model(self.images), self.targets)
             self.loss.backward()
+            if post_backward is not None:
+                post_backward()
             optimizer.step()
         torch.cuda.synchronize()
 

@@ -135,6 +135,17 @@ def colsum(partial2d, f64=True):
     return out
 
 
+def colsum_count(partial2d, count):
+    """partial2d fp32 [R, L] -> float64 [L + 1] = (column sums | count): the SyncBatchNorm
+    forward message of one BatchNorm in one launch."""
+    R, L = partial2d.shape
+    dev = partial2d.device
+    out = torch.empty(L + 1, dtype=torch.float64, device=dev)
+    ws = torch.empty(64 * L, dtype=torch.float64, device=dev) if R > 128 else None
+    LIB.call("seg_colsum_count", _p(partial2d), R, L, _p(out), float(count), _p(ws), _stream())
+    return out
+
+
 def conv_wgrad(x, dy, O, KH, KW, stride, pad, dil, pro=None, raw_partial=False):
     """-> dW fp32 [O, KH*KW*C]."""
     N, Hi, Wi, C, ldx = nhwc(x)
@@ -411,11 +422,12 @@ def bn_bwd_finalize_p(partial, count, mean, invstd, gamma):
     return out[0], out[1], out[2], out[3]
 
 
-def bn_bwd_finalize(sums, count, mean, invstd, gamma):
+def bn_bwd_finalize(sums, count, mean, invstd, gamma, grad_scale=1.0):
+    """grad_scale multiplies dgamma / dbeta only (SyncBatchNorm: 1 / world size)."""
     C = mean.numel()
     out = torch.empty((4, C), dtype=torch.float32, device=mean.device)
-    LIB.call("seg_bn_bwd_finalize", _p(sums), *_count(count), _p(mean), _p(invstd), _p(gamma),
-             _p(out[0]), _p(out[1]), _p(out[2]), _p(out[3]), C, _stream())
+    LIB.call("seg_bn_bwd_finalize_s", _p(sums), *_count(count), _p(mean), _p(invstd), _p(gamma),
+             _p(out[0]), _p(out[1]), _p(out[2]), _p(out[3]), C, float(grad_scale), _stream())
     return out[0], out[1], out[2], out[3]  # dgamma, dbeta, c0, c1
 
 
@@ -466,12 +478,13 @@ def fold_bwd_reduce(w2d, dwp, scale, shift, db=None):
     return dW, dsdt
 
 
-def fold_bwd_finalize(dsdt, count, mean, invstd, gamma, scale):
+def fold_bwd_finalize(dsdt, count, mean, invstd, gamma, scale, grad_scale=1.0):
     C = mean.numel()
     out = torch.empty((4, C), dtype=torch.float32, device=mean.device)
     dsdt = dsdt.view(-1, 2 * C)
-    LIB.call("seg_fold_bwd_finalize", _p(dsdt), dsdt.shape[0], *_count(count), _p(mean),
-             _p(invstd), _p(gamma), _p(scale), _p(out[0]), _p(out[1]), _p(out[2]), _p(out[3]), C, _stream())
+    LIB.call("seg_fold_bwd_finalize_s", _p(dsdt), dsdt.shape[0], *_count(count), _p(mean),
+             _p(invstd), _p(gamma), _p(scale), _p(out[0]), _p(out[1]), _p(out[2]), _p(out[3]), C,
+             float(grad_scale), _stream())
     return out[0], out[1], out[2], out[3]  # dgamma, dbeta, c0, c1
 
 

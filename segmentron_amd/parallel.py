@@ -12,6 +12,52 @@ import torch.distributed as dist
 import torch.nn as nn
 
 
+def _FORCE():
+    """SEG_SYNC_FORCE=1 (test plumbing, set by bench.py's SEG_BENCH_FORCE_DDP): run the SyncBN
+    exchange with a single rank too, so that a one-GPU box exercises the RCCL calls."""
+    import os
+    return os.environ.get("SEG_SYNC_FORCE") == "1"
+
+
+_NATIVE = [None]
+
+
+def use_native_rccl(comm):
+    """Route the SyncBatchNorm statistics exchanges (and `average_gradients`) through a
+    `segmentron_amd.rccl.Communicator` instead of torch.distributed: direct `ncclAllReduce` calls
+    on the current stream — a few microseconds of host work each and, unlike ProcessGroupNCCL,
+    safe inside a HIP-graph capture.  None switches back.  Returns the previous setting."""
+    prev, _NATIVE[0] = _NATIVE[0], comm
+    return prev
+
+
+def native_rccl():
+    return _NATIVE[0]
+
+
+def _all_reduce(t, group):
+    if _NATIVE[0] is not None:
+        _NATIVE[0].all_reduce(t)
+    else:
+        dist.all_reduce(t, group=group)
+
+
+def average_gradients(params):
+    """What DistributedDataParallel does for the gradients (tools/train.py:108-111: mean over
+    ranks), as ONE grouped RCCL all-reduce over the native communicator after backward —
+    capturable with the rest of the step."""
+    comm = _NATIVE[0]
+    if comm is None:
+        raise RuntimeError("average_gradients needs parallel.use_native_rccl(comm)")
+    grads = []
+    for p in params:
+        if p.grad is not None:
+            if not p.grad.is_contiguous():
+                p.grad = p.grad.contiguous()
+            grads.append(p.grad)
+    comm.all_reduce_many(grads, "avg")
+
+
 def is_naive_sync(bn):
     """The reference's own NaiveSyncBatchNorm (an nn.BatchNorm2d subclass)."""
     return type(bn).__name__ == "NaiveSyncBatchNorm" and isinstance(bn, nn.BatchNorm2d)
@@ -20,7 +66,7 @@ def is_naive_sync(bn):
 def sync_group(bn):
     """Process group to synchronise over, or None (plain BN / eval / single process)."""
     if not (bn.training and dist.is_available() and dist.is_initialized()
-            and dist.get_world_size() > 1):
+            and (dist.get_world_size() > 1 or _FORCE())):
         return None
     if isinstance(bn, nn.SyncBatchNorm):
         return bn.process_group if bn.process_group is not None else dist.group.WORLD
@@ -41,30 +87,42 @@ def naive_running_update(bn, mean, invstd):
         bn.running_var += m * (var.to(bn.running_var.dtype) - bn.running_var)
 
 
-def allreduce_forward_sums(sums, local_count, group):
-    """sums: float64 [2C] local (sum x, sum x^2) -> (global sums, global count).
-    The local element count rides in the same message ([2C+1]), so ranks with different
-    N*H*W (uneven last batch, variable-size inputs) still get the exact global statistics —
-    torch's SyncBatchNorm all-gathers per-rank counts for the same reason
-    (torch/nn/modules/_functions.py:49-74)."""
+def allreduce_forward_sums(partial2d, local_count, group):
+    """partial2d: fp32 [R, 2C] local partial rows of (sum x, sum x^2) -> (global float64 sums
+    [2C], global count).  The local element count rides in the same message ([2C+1], assembled
+    by ONE launch: hip_ops.colsum_count), so ranks with different N*H*W (uneven last batch,
+    variable-size inputs) still get the exact global statistics — torch's SyncBatchNorm
+    all-gathers per-rank counts for the same reason (torch/nn/modules/_functions.py:49-74)."""
     import torch
-    n = sums.numel()
-    buf = torch.empty(n + 1, dtype=sums.dtype, device=sums.device)
-    buf[:n] = sums
-    buf[n] = float(local_count)
-    dist.all_reduce(buf, group=group)
+    if partial2d.dim() == 1:  # already summed (host-side protocol tests over gloo)
+        n = partial2d.numel()
+        buf = torch.empty(n + 1, dtype=partial2d.dtype, device=partial2d.device)
+        buf[:n] = partial2d
+        buf[n:].fill_(float(local_count))  # (a fill kernel: `buf[n] = x` is a host-to-device
+        #                                    copy, which a HIP-graph capture does not allow)
+    else:
+        from . import hip_ops as K
+        n = partial2d.shape[1]
+        buf = K.colsum_count(partial2d, float(local_count))
+    _all_reduce(buf, group)
     return buf[:n], buf[n:]
 
 
 def allreduce_backward_sums(sums, group):
     """sums: [2C] local (sum g', sum g'*x) or (ds, dt) -> global, in place."""
-    dist.all_reduce(sums, group=group)
+    _all_reduce(sums, group)
     return sums
 
 
+def grad_scale(group):
+    """Every rank computes dgamma / dbeta from GLOBAL sums; the data-parallel gradient averaging
+    (DistributedDataParallel / average_gradients) divides by the world size once more, and
+    torch's SyncBatchNorm returns LOCAL sums there — the finalize kernels multiply by this
+    factor so that the averaged value reproduces the reference's."""
+    return 1.0 / dist.get_world_size(group)
+
+
 def local_param_grads(dgamma, dbeta, group):
-    """Every rank computed dgamma/dbeta from GLOBAL sums; DistributedDataParallel will average
-    parameter gradients over ranks, and torch's SyncBatchNorm returns LOCAL sums there — divide
-    so that DDP's mean reproduces the reference value (global / world)."""
+    """The same as two tensor divisions (paths whose finalize kernel takes no scale)."""
     ws = dist.get_world_size(group)
     return dgamma / ws, dbeta / ws

@@ -3,7 +3,9 @@ data-parallel path of tools/train.py:73-79,108-111 — nn.SyncBatchNorm.convert_
 DistributedDataParallel around the HIP model — must reproduce the single-process full-batch
 step: each rank's logits equal its slice of the full-batch logits, and the DDP-averaged
 gradients equal the full-batch gradients (HRNet-W18-small, fp32: the least chaotic of the five
-configs, see tests/test_more_models.py)."""
+configs, see tests/test_more_models.py).  The same for the NATIVE exchange path (no DDP wrapper:
+parallel.use_native_rccl + parallel.average_gradients, the path bench.py --gpus N captures into a
+HIP graph), and — with one rank — for the RCCL binding itself incl. graph capture."""
 import os
 import socket
 
@@ -69,7 +71,27 @@ def _data(world):
     return x, y
 
 
-def _worker(rank, world, port, ret, naive=False):
+class _GlooComm:
+    """Stand-in for segmentron_amd.rccl.Communicator over the gloo group (RCCL refuses two ranks
+    on one device): the same two methods, so that the NATIVE data-parallel code path —
+    parallel.use_native_rccl + parallel.average_gradients, no DistributedDataParallel — is what
+    runs; only the transport differs."""
+
+    def __init__(self, world):
+        self.world = world
+
+    def all_reduce(self, t, op="sum"):
+        dist.all_reduce(t)
+        if op == "avg":
+            t /= self.world
+        return t
+
+    def all_reduce_many(self, tensors, op="sum"):
+        for t in tensors:
+            self.all_reduce(t, op)
+
+
+def _worker(rank, world, port, ret, naive=False, native=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     import sys
@@ -80,11 +102,15 @@ def _worker(rank, world, port, ret, naive=False):
         model = _build(naive)
         if not naive:  # tools/train.py:76; the Naive modules synchronise by themselves
             model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
-        ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0], output_device=0,
-                                                        find_unused_parameters=True)  # train.py:110
+        from segmentron_amd import parallel
+        if native:  # the graph-capturable path of bench.py --gpus N: no DDP wrapper
+            parallel.use_native_rccl(_GlooComm(world))
+            ddp = model
+        else:
+            ddp = torch.nn.parallel.DistributedDataParallel(
+                model, device_ids=[0], output_device=0, find_unused_parameters=True)  # train.py:110
         x, y = _data(world)
         xs, ys = x[rank * PER:(rank + 1) * PER].cuda(), y[rank * PER:(rank + 1) * PER].cuda()
-        from segmentron_amd import parallel
         calls = [0]
         orig = parallel.allreduce_forward_sums
 
@@ -98,6 +124,8 @@ def _worker(rank, world, port, ret, naive=False):
               flush=True)
         loss = torch.nn.functional.cross_entropy(out[0], ys)
         loss.backward()
+        if native:
+            parallel.average_gradients(model.parameters())
         torch.cuda.synchronize()
         ret[rank] = {"logits": out[0].detach().cpu(), "loss": loss.item(),
                      "grads": {k: p.grad.detach().cpu() for k, p in model.named_parameters()
@@ -108,8 +136,9 @@ def _worker(rank, world, port, ret, naive=False):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("naive", [False, True], ids=["nn.SyncBatchNorm", "NaiveSyncBatchNorm"])
-def test_syncbn_ddp_two_ranks_match_full_batch(naive):
+@pytest.mark.parametrize("naive,native", [(False, False), (True, False), (False, True)],
+                         ids=["nn.SyncBatchNorm", "NaiveSyncBatchNorm", "native-exchange"])
+def test_syncbn_ddp_two_ranks_match_full_batch(naive, native):
     world = 2
     # single-process full batch: plain BatchNorm (a lone NaiveSyncBatchNorm process IS plain BN)
     model = _build(naive)
@@ -130,7 +159,8 @@ def test_syncbn_ddp_two_ranks_match_full_batch(naive):
     mgr = ctx.Manager()
     ret = mgr.dict()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, ret, naive)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, ret, naive, native))
+             for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -188,3 +218,77 @@ def test_bench_self_launches_two_ranks_and_reports_one_line():
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 4 and d["config"]["bn"] == "SyncBN"
     assert d["launch"] == "eager" and d["steps"] == 2 and d["value"] > 0
     assert d["config"]["loss"] == d["config"]["loss"]  # finite (not NaN)
+
+
+def _one_rank_group():
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ["MASTER_PORT"] = str(_free_port())
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+
+
+def test_native_rccl_communicator_one_rank_eager_and_inside_a_hip_graph():
+    """segmentron_amd/rccl.py: the ctypes binding of ncclGetUniqueId / ncclCommInitRank /
+    ncclAllReduce / ncclGroupStart/End over the librccl.so torch loaded — communicator creation
+    through the torch group (self-check included), sum / avg all-reduces, a grouped call, and the
+    same calls RECORDED INTO A HIP GRAPH and replayed (what ProcessGroupNCCL cannot do on this
+    stack).  One rank: the API path of every rank count; the transport itself needs N GPUs."""
+    from segmentron_amd import rccl
+    _one_rank_group()
+    try:
+        comm = rccl.communicator_from_torch_group()
+        assert (comm.rank, comm.world) == (0, 1)
+        a = torch.arange(1000, dtype=torch.float64, device="cuda")
+        b = torch.ones(37, dtype=torch.float32, device="cuda") * 3
+        c = torch.full((5,), 2.0, dtype=torch.bfloat16, device="cuda")
+        comm.all_reduce(a)
+        comm.all_reduce_many([b, c], "avg")
+        torch.cuda.synchronize()
+        assert torch.equal(a.cpu(), torch.arange(1000, dtype=torch.float64))
+        assert float(b.sum()) == 111.0 and float(c.float().sum()) == 10.0
+        # captured: y = 2 * x ; all_reduce(y) ; z = y + 1
+        x = torch.ones(4096, device="cuda")
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            y = x * 2
+            comm.all_reduce(y)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=s):
+                y = x * 2
+                comm.all_reduce(y)
+                z = y + 1
+        torch.cuda.current_stream().wait_stream(s)
+        for k in range(3):
+            x.fill_(float(k))
+            g.replay()
+            torch.cuda.synchronize()
+            assert float(z[0]) == 2.0 * k + 1.0 and float(z.sum()) == 4096 * (2.0 * k + 1.0)
+        comm.destroy()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_native_data_parallel_step_is_one_graph_with_the_collectives_inside():
+    """bench.py's N > 1 machinery with ONE rank (SEG_BENCH_FORCE_DDP=1): RCCL process group,
+    SyncBatchNorm statistics exchanges forced on, gradient averaging — all as direct RCCL calls
+    captured into the step's HIP graph; stdout carries exactly the one JSON line (RCCL's version
+    banner goes to stderr)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["SEG_BENCH_FORCE_DDP"] = "1"
+    env["MASTER_PORT"] = str(_free_port())
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3",
+                        "--warmup", "1", "--height", "129", "--width", "257", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(out) == 1 and out[0].startswith("{"), p.stdout[-2000:]
+    d = json.loads(out[0])
+    assert d["launch"] == "hip_graph" and d["config"]["dp_mode"] == "native", d
+    assert d["config"]["bn"] == "SyncBN" and "hip_graph_error" not in d
+    assert d["config"]["loss"] == d["config"]["loss"] and d["value"] > 0
