@@ -378,10 +378,31 @@ def main():
         return loss
 
     post_backward = None
+    grad_overlap = None
     if train and dp_mode == "native":
         from segmentron_amd import parallel as SP
         dp_params = list(model.parameters())
         post_backward = lambda: SP.average_gradients(dp_params)  # noqa: E731 — DDP's mean
+        if os.environ.get("SEG_BENCH_GRAD_OVERLAP", "1") == "1":
+            # DDP's other half: bucketed all-reduces overlapped with backward on a side stream,
+            # over a communicator of their own (the SyncBN exchanges keep the first one busy)
+            try:
+                from segmentron_amd import rccl as SR
+                sys.stdout.flush()
+                saved_out = os.dup(1)
+                os.dup2(2, 1)
+                try:
+                    comm_grad = SR.communicator_from_torch_group()
+                finally:
+                    ctypes.CDLL(None).fflush(None)
+                    os.dup2(saved_out, 1)
+                    os.close(saved_out)
+                grad_overlap = SP.OverlappedGradientAverager(dp_params, comm_grad)
+                post_backward = grad_overlap.finish
+            except Exception as e:  # noqa: BLE001
+                sys.stderr.write("bench.py: gradient overlap unavailable (%r): one grouped "
+                                 "all-reduce after backward\n" % (e,))
+                grad_overlap = None
 
     timer = GemmTimer()
     # ---- launch path: one HIP graph of the whole step (single GPU), else eager
@@ -524,6 +545,10 @@ def main():
                        else "eval (running stats)",
                        "parallelism": ("dp%d" % world) if train else ("replicas x%d" % world),
                        "dp_mode": dp_mode,
+                       "grad_allreduce": (None if dp_mode != "native" else
+                                          ("bucketed, overlapped with backward (side stream, "
+                                           "%d buckets)" % len(grad_overlap.buckets))
+                                          if grad_overlap is not None else "grouped, after backward"),
                        "full_size": full, "loss" if train else "mean_abs_logit": loss_value},
             "model_flop_fraction_of_bf16_mfma_peak":
                 value / world * FLOP_FWD_BWD_PER_IMAGE / MFMA_BF16_PEAK

@@ -58,6 +58,81 @@ def average_gradients(params):
     comm.all_reduce_many(grads, "avg")
 
 
+class OverlappedGradientAverager:
+    """DistributedDataParallel's bucketed, backward-overlapped gradient averaging
+    (tools/train.py:108-111) on direct RCCL calls: parameters are bucketed in REVERSE order (the
+    order backward produces their gradients, ~`bucket_bytes` each); when the last gradient of a
+    bucket has been accumulated (post-accumulate-grad hooks) a side HIP stream waits for the
+    compute stream and issues ONE grouped `avg` all-reduce for the bucket, while backward goes
+    on; `finish()` (call it between backward and the optimizer step) makes the compute stream
+    wait for the side stream.
+
+    `comm` must be a communicator of its OWN — the SyncBatchNorm exchanges keep running on the
+    compute stream over `native_rccl()`, and one communicator must not be driven from two
+    streams at once.  Inside a HIP-graph capture the side stream joins the capture through the
+    stream waits, so the overlap is part of the replayed graph."""
+
+    def __init__(self, params, comm, bucket_bytes=32 << 20):
+        import torch
+        self.comm = comm
+        self.side = torch.cuda.Stream()
+        self.buckets, cur, size = [], [], 0
+        for p in reversed([p for p in params if p.requires_grad]):
+            cur.append(p)
+            size += p.numel() * p.element_size()
+            if size >= bucket_bytes:
+                self.buckets.append(cur)
+                cur, size = [], 0
+        if cur:
+            self.buckets.append(cur)
+        self._bucket_of = {}
+        for bi, b in enumerate(self.buckets):
+            for p in b:
+                self._bucket_of[id(p)] = bi
+        self._left = [len(b) for b in self.buckets]
+        self._launched = [False] * len(self.buckets)
+        self._hooks = [p.register_post_accumulate_grad_hook(self._ready) for b in self.buckets
+                       for p in b]
+
+    def _ready(self, p):
+        bi = self._bucket_of[id(p)]
+        self._left[bi] -= 1
+        if self._left[bi] == 0:
+            self._launch(bi)
+
+    def _launch(self, bi):
+        import torch
+        grads = []
+        for p in self.buckets[bi]:
+            if p.grad is not None:
+                if not p.grad.is_contiguous():
+                    p.grad = p.grad.contiguous()
+                grads.append(p.grad)
+        self._launched[bi] = True
+        if not grads:
+            return
+        main = torch.cuda.current_stream()
+        self.side.wait_stream(main)  # the bucket's gradients are complete on the compute stream
+        with torch.cuda.stream(self.side):
+            self.comm.all_reduce_many(grads, "avg")
+
+    def finish(self):
+        """After backward: buckets whose hooks did not all fire (parameters without a gradient
+        this step) are averaged now; the compute stream then waits for the side stream."""
+        import torch
+        for bi in range(len(self.buckets)):
+            if not self._launched[bi]:
+                self._launch(bi)
+        torch.cuda.current_stream().wait_stream(self.side)
+        self._left = [len(b) for b in self.buckets]
+        self._launched = [False] * len(self.buckets)
+
+    def remove(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+
+
 def is_naive_sync(bn):
     """The reference's own NaiveSyncBatchNorm (an nn.BatchNorm2d subclass)."""
     return type(bn).__name__ == "NaiveSyncBatchNorm" and isinstance(bn, nn.BatchNorm2d)

@@ -103,9 +103,15 @@ def _worker(rank, world, port, ret, naive=False, native=False):
         if not naive:  # tools/train.py:76; the Naive modules synchronise by themselves
             model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
         from segmentron_amd import parallel
+        averager = None
         if native:  # the graph-capturable path of bench.py --gpus N: no DDP wrapper
             parallel.use_native_rccl(_GlooComm(world))
             ddp = model
+            # DDP's bucketed, backward-overlapped averaging on a side stream (small buckets here:
+            # several launch while backward is still running)
+            averager = parallel.OverlappedGradientAverager(list(model.parameters()),
+                                                           _GlooComm(world), bucket_bytes=256 << 10)
+            assert len(averager.buckets) > 4
         else:
             ddp = torch.nn.parallel.DistributedDataParallel(
                 model, device_ids=[0], output_device=0, find_unused_parameters=True)  # train.py:110
@@ -125,7 +131,7 @@ def _worker(rank, world, port, ret, naive=False, native=False):
         loss = torch.nn.functional.cross_entropy(out[0], ys)
         loss.backward()
         if native:
-            parallel.average_gradients(model.parameters())
+            averager.finish()
         torch.cuda.synchronize()
         ret[rank] = {"logits": out[0].detach().cpu(), "loss": loss.item(),
                      "grads": {k: p.grad.detach().cpu() for k, p in model.named_parameters()
