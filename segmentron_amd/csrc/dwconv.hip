@@ -469,6 +469,8 @@ extern "C" int seg_dwconv_grid_y(int dtype, int C, int N, int Ho, int Wo, int st
   const int tiled_stride = kind == 0 ? stride : 1;  // kinds 1/2 describe a stride-1 layer's backward
   if ((kind == 0 || stride == 1) && dw_tiled_supported(tiled_stride, dil))
     return dw_tiled_grid_y(dtype, C, N, Ho, Wo, kind);
+  if (kind == 0 && stride == 2 && dil == 1)  // LDS-tiled stride-2 forward
+    return dw_tiled_s2_grid_y(dtype, C, N, Ho, Wo);
   if (g_dw_row && (kind == 0 || kind == 1) && dw_row_supported(stride, dil) && C % 4 == 0)
     return dw_row_grid_y(dtype, C, N, Ho, Wo, dil);  // stride 1: Ho x Wo is the input size too
   const int vec = dtype == DT_BF16 ? 8 : 4;
@@ -500,6 +502,12 @@ extern "C" int seg_dwconv3x3(int dtype, int mode, const void* x, long ldx, int N
     SEG_REQUIRE(Ho == Hi && Wo == Wi, "dwconv3x3: stride 1 keeps the size");
     return launch_dw_tiled(dtype, x, ldx, N, Hi, Wi, C, w9c, w_layout, dil, pro_mode, pro_scale,
                            pro_shift, y, ldy, stat_partial, grid_y, (hipStream_t)stream);
+  }
+  if (mode == MODE_FWD && stride == 2 && dil == 1) {  // LDS-tiled stride-2 forward
+    SEG_REQUIRE(Ho == (Hi + 1) / 2 && Wo == (Wi + 1) / 2, "dwconv3x3: stride-2 output size");
+    SEG_REQUIRE((long)N * Hi * Wi < (1L << 31), "dwconv3x3: tensor exceeds 32-bit pixel offsets");
+    return launch_dw_tiled_s2(dtype, x, ldx, N, Hi, Wi, C, w9c, w_layout, pro_mode, pro_scale,
+                              pro_shift, y, ldy, stat_partial, grid_y, (hipStream_t)stream);
   }
   SEG_REQUIRE(w_layout == 0, "dwconv3x3: the strip kernels take tap-major [9][C] weights");
   if (g_dw_row && mode == MODE_FWD && dw_row_supported(stride, dil) && C % 4 == 0) {

@@ -9,6 +9,12 @@ int launch_dw_tiled(int dtype, const void* x, long ldx, int N, int H, int W, int
                     const float* w, int w_layout, int dil, int pro_mode, const float* sc,
                     const float* sh, void* y, long ldy, float* stat_partial, int grid_y,
                     hipStream_t st);
+// stride 2, pad 1, dilation 1 (H x W: input size)
+int dw_tiled_s2_grid_y(int dtype, int C, int N, int Ho, int Wo);
+int launch_dw_tiled_s2(int dtype, const void* x, long ldx, int N, int H, int W, int C,
+                       const float* w, int w_layout, int pro_mode, const float* sc,
+                       const float* sh, void* y, long ldy, float* stat_partial, int grid_y,
+                       hipStream_t st);
 int launch_dw_bwd_tiled(int dtype, const void* dy, long lddy, const void* x, long ldx, int N, int H,
                         int W, int C, const float* w, int w_layout, int dil, int pro_mode,
                         const float* sc, const float* sh, void* g, long ldg, float* partial_w,

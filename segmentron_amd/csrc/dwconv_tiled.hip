@@ -318,6 +318,192 @@ __global__ __launch_bounds__(LT_THREADS, sizeof(T) == 2 ? 3 : 4) void dwconv_til
   }
 }
 
+// ------------------------------------------------------------------ forward, stride 2
+// The last separable conv of the Xception entry blocks (xception.py:31-33) and MobileNetV2's
+// stride-2 depthwise layers ran on the strip kernel (dwconv.hip): every thread fetched its own
+// neighbourhood through L1/TA — 431 MB fetched for 268 MB on block1, 160 µs where the tensor
+// moves in ≈ 60.  Same scheme as dwconv_tiled_kernel: a block owns 4 x 16 OUTPUT pixels x 8
+// channel vectors, stages the 9 x 33 input pixels they read ONCE (activation applied once,
+// zero padding after it), taps from LDS.  A thread computes two horizontally adjacent outputs.
+struct S2Geom {
+  static constexpr int TH = 4, TW = 16;
+  static constexpr int IH = 2 * TH + 1, IW = 2 * TW + 1, IWP = IW + 1;
+  static constexpr int NPIX = IH * IW;
+  static constexpr int PER = (NPIX * LT_CVB + LT_THREADS - 1) / LT_THREADS;
+  static constexpr int TILE_VECS = IH * IWP * LT_CVB;
+};
+
+template <typename T, int MODE>
+__global__ __launch_bounds__(LT_THREADS, 3) void dwconv_tiled_s2_kernel(const DwTiledArgs a) {
+  using G = S2Geom;
+  constexpr int VEC = Vec<T>::N, WQ = VEC / 4;
+  extern __shared__ uint4 lt_smem[];
+  uint4* tile = lt_smem;
+  float4* wsm = reinterpret_cast<float4*>(lt_smem + G::TILE_VECS);
+  const int tid = threadIdx.x;
+  const LtBlock lb = lt_block();
+  const int cvb0 = lb.x * LT_CVB;
+  const int cx = tid & (LT_CVB - 1), row = (tid >> 3) & (G::TH - 1), strip = tid >> 5;
+  const int cv = cvb0 + cx, cvc = min(cv, a.CV - 1);
+  const T* __restrict__ X = reinterpret_cast<const T*>(a.x);
+  T* __restrict__ Y = reinterpret_cast<T*>(a.y);
+  // a.H / a.W: INPUT size; a.tiles_h / tiles_w / ntiles: tiles of the OUTPUT (Ho x Wo)
+  const int Ho = (a.H + 1) / 2, Wo = (a.W + 1) / 2;
+  const int mode = MODE >= 0 ? MODE : a.pro_mode;
+
+  stage_params<Vec<T>>(a, wsm, cvb0, true);
+  __syncthreads();
+  float sc[VEC], sh[VEC];
+  if (mode & PRO_AFFINE) {
+#pragma unroll
+    for (int q = 0; q < WQ; ++q) {
+      const float4 s4 = wsm[(9 * LT_CVB + cx) * WQ + q], t4 = wsm[(10 * LT_CVB + cx) * WQ + q];
+      sc[q * 4] = s4.x; sc[q * 4 + 1] = s4.y; sc[q * 4 + 2] = s4.z; sc[q * 4 + 3] = s4.w;
+      sh[q * 4] = t4.x; sh[q * 4 + 1] = t4.y; sh[q * 4 + 2] = t4.z; sh[q * 4 + 3] = t4.w;
+    }
+  }
+  float ssum[VEC], ssq[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) ssum[i] = ssq[i] = 0.f;
+
+  for (int t = lb.y; t < a.ntiles; t += gridDim.y) {
+    int n, ho0, wo0;
+    {
+      int tt = t;
+      const int tw = tt % a.tiles_w;
+      tt /= a.tiles_w;
+      const int th = tt % a.tiles_h;
+      n = tt / a.tiles_h;
+      ho0 = th * G::TH;
+      wo0 = tw * G::TW;
+    }
+    const int h0 = 2 * ho0 - 1, w0 = 2 * wo0 - 1;  // input coordinates of tile element (0, 0)
+    // ---- global -> registers (interior tiles: offsets relative to the tile origin)
+    uint4 raw[G::PER];
+    unsigned okmask = 0;
+    const bool inside = h0 >= 0 && h0 + G::IH <= a.H && w0 >= 0 && w0 + G::IW <= a.W;
+    if (inside) {
+      const int origin = (n * a.H + h0) * a.W + w0;
+      const T* __restrict__ base = X + cvc * VEC;
+#pragma unroll
+      for (int u = 0; u < G::PER; ++u) {
+        const int p = (tid >> 3) + u * (LT_THREADS / LT_CVB);
+        const int pc = p < G::NPIX ? p : G::NPIX - 1;
+        const int r = pc / G::IW, c = pc - r * G::IW;
+        okmask |= (p < G::NPIX && cv < a.CV) ? (1u << u) : 0u;
+        raw[u] = ldg16(base + (long)(origin + r * a.W + c) * a.ldx);
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < G::PER; ++u) {
+        const int p = (tid >> 3) + u * (LT_THREADS / LT_CVB);
+        const int r = p / G::IW, c = p - r * G::IW;
+        const int hi = h0 + r, wi = w0 + c;
+        const bool ok = p < G::NPIX && cv < a.CV && hi >= 0 && hi < a.H && wi >= 0 && wi < a.W;
+        okmask |= ok ? (1u << u) : 0u;
+        const int hic = min(max(hi, 0), a.H - 1), wic = min(max(wi, 0), a.W - 1);
+        raw[u] = ldg16(X + (((long)n * a.H + hic) * a.W + wic) * a.ldx + cvc * VEC);
+      }
+    }
+    __syncthreads();  // every thread is done reading the previous tile
+    // ---- registers -> LDS: activation once per element, zero padding outside the image
+#pragma unroll
+    for (int u = 0; u < G::PER; ++u) {
+      const int p = (tid >> 3) + u * (LT_THREADS / LT_CVB);
+      if (p < G::NPIX) {
+        const int r = p / G::IW, c = p - r * G::IW;
+        uint4 v = raw[u];
+        if (mode != PRO_NONE) {
+          float f[VEC];
+          Vec<T>::unpack(raw[u], f);
+          if (mode & PRO_AFFINE) {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) f[i] = fmaf(f[i], sc[i], sh[i]);
+          }
+          if (mode & PRO_RELU) {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) f[i] = fmaxf(f[i], 0.f);
+          }
+          if (mode & PRO_CLAMP6) {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) f[i] = fminf(f[i], 6.f);
+          }
+          v = Vec<T>::pack(f);
+        }
+        tile[(r * G::IWP + c) * LT_CVB + cx] = mask_u4(v, (okmask >> u) & 1u);
+      }
+    }
+    __syncthreads();
+    // ---- two outputs per thread: columns 2 * strip + {0, 1} of tile row `row`
+    float acc[2][VEC];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) acc[j][i] = 0.f;
+#pragma unroll 1
+    for (int kh = 0; kh < 3; ++kh) {
+      float wv[3][VEC];
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+        for (int q = 0; q < WQ; ++q) {
+          const float4 w4 = wsm[((kh * 3 + kw) * LT_CVB + cx) * WQ + q];
+          wv[kw][q * 4] = w4.x; wv[kw][q * 4 + 1] = w4.y;
+          wv[kw][q * 4 + 2] = w4.z; wv[kw][q * 4 + 3] = w4.w;
+        }
+      const uint4* trow = tile + ((2 * row + kh) * G::IWP + 4 * strip) * LT_CVB + cx;
+#pragma unroll
+      for (int q = 0; q < 5; ++q) {
+        float v[VEC];
+        Vec<T>::unpack(trow[q * LT_CVB], v);
+        if (q < 3) {
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) acc[0][i] = fmaf(v[i], wv[q][i], acc[0][i]);
+        }
+        if (q >= 2) {
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) acc[1][i] = fmaf(v[i], wv[q - 2][i], acc[1][i]);
+        }
+      }
+    }
+    const int ho = ho0 + row;
+    if (cv < a.CV && ho < Ho) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int wo = wo0 + 2 * strip + j;
+        if (wo < Wo) {
+          stg16(Y + (((long)n * Ho + ho) * Wo + wo) * a.ldy + cv * VEC, Vec<T>::pack(acc[j]));
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) {
+            ssum[i] += acc[j][i];
+            ssq[i] = fmaf(acc[j][i], acc[j][i], ssq[i]);
+          }
+        }
+      }
+    }
+  }
+
+  if (a.partial != nullptr) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(tile);
+    float* mine = red + ((tid >> 3) * LT_CVB + cx) * 2 * VEC;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      mine[i] = ssum[i];
+      mine[VEC + i] = ssq[i];
+    }
+    __syncthreads();
+    if (tid < LT_CVB * 2 * VEC) {
+      float tot = 0.f;
+      for (int r = 0; r < LT_THREADS / LT_CVB; ++r) tot += red[r * LT_CVB * 2 * VEC + tid];
+      const int lcx = tid / (2 * VEC), k = tid - lcx * 2 * VEC;
+      const int which = k / VEC, ci = k - which * VEC;
+      const int c = (cvb0 + lcx) * VEC + ci;
+      if (c < a.C) a.partial[((long)lb.y * 2 + which) * a.C + c] = tot;
+    }
+  }
+}
+
 // ------------------------------------------------------------------ weight gradient
 // dW[kh,kw,c] = sum_p dy[p,c] * act(x)[p + (kh-1)d, (kw-1)d, c]: same tile, the thread's four dy
 // vectors come straight from global memory (each is used by one thread only).
@@ -738,6 +924,52 @@ template <int DIL> static size_t tiled_lds(int dtype, bool with_weights) {
   (void)with_weights;
   b += (size_t)11 * LT_CVB * vec * sizeof(float);  // taps + prologue scale / shift
   return b;
+}
+
+// ---- stride 2 (pad 1, dilation 1): the launcher takes the INPUT size H x W, tiles cover the
+// output ((H + 1) / 2 x (W + 1) / 2); the grid query takes the output size
+int dw_tiled_s2_grid_y(int dtype, int C, int N, int Ho, int Wo) {
+  const int vec = dtype == DT_BF16 ? 8 : 4;
+  const long ntiles = (long)N * ((Ho + S2Geom::TH - 1) / S2Geom::TH) * ((Wo + S2Geom::TW - 1) / S2Geom::TW);
+  const int gx = (C / vec + LT_CVB - 1) / LT_CVB;
+  long cap = 2048 / gx;
+  if (cap < 1) cap = 1;
+  return (int)(ntiles < cap ? ntiles : cap);
+}
+
+int launch_dw_tiled_s2(int dtype, const void* x, long ldx, int N, int H, int W, int C,
+                       const float* w, int w_layout, int pro_mode, const float* sc,
+                       const float* sh, void* y, long ldy, float* stat_partial, int grid_y,
+                       hipStream_t st) {
+  DwTiledArgs a;
+  const int vec = dtype == DT_BF16 ? 8 : 4;
+  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+  a.N = N; a.H = H; a.W = W; a.C = C; a.CV = C / vec;
+  a.tiles_h = (Ho + S2Geom::TH - 1) / S2Geom::TH;
+  a.tiles_w = (Wo + S2Geom::TW - 1) / S2Geom::TW;
+  a.ntiles = N * a.tiles_h * a.tiles_w;
+  a.w_layout = w_layout;
+  a.x = x; a.w = w; a.y = y; a.dy = nullptr; a.sc = sc; a.sh = sh; a.partial = stat_partial;
+  a.partial_bn = nullptr; a.res = nullptr; a.ldr = 0;
+  a.ldx = ldx; a.ldy = ldy; a.lddy = 0; a.pro_mode = pro_mode;
+  const dim3 grid((a.CV + LT_CVB - 1) / LT_CVB, grid_y);
+  size_t lds = (size_t)S2Geom::TILE_VECS * 16;
+  const size_t red = (size_t)LT_THREADS * 2 * vec * sizeof(float);
+  if (lds < red) lds = red;
+  lds += (size_t)11 * LT_CVB * vec * sizeof(float);
+#define SEG_S2(TT, MM) \
+  hipLaunchKernelGGL((dwconv_tiled_s2_kernel<TT, MM>), grid, dim3(LT_THREADS), lds, st, a)
+  if (dtype == DT_BF16) {
+    switch (pro_mode) {
+      case PRO_RELU: SEG_S2(bf16_t, PRO_RELU); break;
+      case PRO_AFFINE_RELU: SEG_S2(bf16_t, PRO_AFFINE_RELU); break;
+      default: SEG_S2(bf16_t, -1); break;
+    }
+  } else {
+    SEG_S2(float, -1);
+  }
+#undef SEG_S2
+  return check_launch("dwconv3x3 (tiled, stride 2)");
 }
 
 int launch_dw_tiled(int dtype, const void* x, long ldx, int N, int H, int W, int C,

@@ -253,6 +253,7 @@ DW_CASES = [
     (2, 16, 32, 256, 2, 1, 2),
     (1, 33, 47, 96, 2, 1, 7),
     (2, 129, 131, 32, 2, 1, 3),
+    (1, 19, 22, 40, 2, 1, 0),       # no prologue, ragged channel vectors
 ]
 
 

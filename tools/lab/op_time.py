@@ -64,6 +64,8 @@ def main():
     M = N * H * W
     ops = {}
     ops["dw_fwd"] = lambda: K.dwconv(x, wdw, 1, 1, pro, None, True)
+    w9c = wdw.reshape(C, 9).t().contiguous()  # tap-major packing (functional.pack_dw_weight)
+    ops["dw_fwd_s2"] = lambda: K.dwconv(x, w9c, 2, 1, pro, None, True)
     ops["dw_bwd"] = lambda: K.dwconv_bwd_fused(x, dy, wdw, 1, pro, want_bn=True, torch_layout=True,
                                                raw_dw=True)
     ops["dw_bwd_res"] = lambda: K.dwconv_bwd_fused(x, dy, wdw, 1, (1, None, None), want_bn=False,
