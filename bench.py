@@ -306,6 +306,11 @@ def main():
                     from segmentron_amd import parallel as SP
                     from segmentron_amd import rccl as SR
                     comm = SR.communicator_from_torch_group()
+                    if os.environ.get("SEG_BENCH_XGMI", "1") == "1":
+                        # SyncBatchNorm statistics as one-hop xGMI peer writes, checked against
+                        # this communicator first (falls back to it with a line on stderr)
+                        from segmentron_amd import xgmi as SX
+                        comm = SX.connect(comm, rank, world)
                     SP.use_native_rccl(comm)
                 except Exception as e:  # noqa: BLE001 — every rank takes the same branch
                     sys.stderr.write("bench.py: native RCCL communicator unavailable (%r): "
@@ -472,6 +477,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
     loss_value = float(loss.item()) if train else float(loss.float().abs().mean().item())
+    if hasattr(comm, "check"):
+        comm.check()  # a peer that stopped publishing its statistics invalidates the run: raise
     kernel_ms, n_kernels = (None, None)
     # per-launch HIP events of the dominant kernel: three EAGER steps (same kernels, same shapes)
     # AFTER the timed region — event pairs around every launch slow the launch-bound eager path
@@ -545,6 +552,9 @@ def main():
                        else "eval (running stats)",
                        "parallelism": ("dp%d" % world) if train else ("replicas x%d" % world),
                        "dp_mode": dp_mode,
+                       "syncbn_exchange": (None if dp_mode != "native" else
+                                           "xgmi peer mailbox (csrc/p2p.hip)"
+                                           if hasattr(comm, "mailbox") else "rccl all-reduce"),
                        "grad_allreduce": (None if dp_mode != "native" else
                                           ("bucketed, overlapped with backward (side stream, "
                                            "%d buckets)" % len(grad_overlap.buckets))

@@ -335,6 +335,27 @@ int seg_cca_map(int dtype, const float* wt, const void* b, long ldb, int N, int 
                 int transposed, const float* gamma, const void* res, long ldres, void* out,
                 long ldo, void* raw, long ldraw, void* stream);
 
+/* ---- SyncBatchNorm statistics exchange: one-hop xGMI peer writes ----------------------------
+ * Replaces, for the data-parallel path of tools/train.py:73-79 (convert_sync_batchnorm +
+ * DistributedDataParallel), the two collectives per BatchNorm that torch's SyncBatchNorm issues
+ * (torch/nn/modules/_functions.py:49-74 all_gather of mean/invstd/count, :140 all_reduce of the
+ * backward sums): an in-place float64 SUM over the ranks of one node, every rank writing its
+ * vector into a mailbox on each peer (csrc/p2p.hip).  One process per GPU.
+ *   seg_p2p_create       : this rank's mailbox (uncached device memory), slot_bytes % 128 == 0
+ *                          bounds one message; *handle_out is an opaque object of THIS process
+ *   seg_p2p_ipc_handle   : the 64-byte hipIpcMemHandle_t of the mailbox, to be sent to the peers
+ *   seg_p2p_connect      : handles = [world][64] bytes in rank order (own entry ignored)
+ *   seg_p2p_all_reduce_f64: buf[n] <- sum over ranks, on `stream` (capturable); every rank must
+ *                          issue the same sequence of calls
+ *   seg_p2p_status       : synchronises; 3 = a peer failed to publish within 30 s (the kernel
+ *                          stops waiting instead of hanging)                                    */
+int seg_p2p_create(int rank, int world, long slot_bytes, void** handle_out);
+int seg_p2p_ipc_handle(void* handle, void* out64);
+int seg_p2p_connect(void* handle, const void* handles);
+int seg_p2p_all_reduce_f64(void* handle, void* buf, int n, void* stream);
+int seg_p2p_status(void* handle);
+int seg_p2p_destroy(void* handle);
+
 #ifdef __cplusplus
 }
 #endif

@@ -19,9 +19,10 @@ Rounding points of the HIP bf16 path (segmentron_amd/csrc):
     bf16 tensor as stored, weights = bf16(W * scale), the constant W @ shift is dropped when a
     training-mode BN follows (it cancels) and added as an fp32 bias otherwise
   * depthwise (seg_dwconv3x3): operand act(raw) rounded to bf16 once by the LDS-tiled kernels
-    (stride 1, dilation <= 2; the activated tile is parked in LDS in the storage dtype) and kept
-    in fp32 by the strip kernels (stride 2 / wide dilations); weights fp32, fp32 accumulation,
-    statistics from fp32, output stored bf16
+    (stride 1 with dilation <= 2, and stride 2 with dilation 1; the activated tile is parked in
+    LDS in the storage dtype) and kept in fp32 by the strip kernels (wide dilations on maps too
+    small for the row-chain kernel); weights fp32, fp32 accumulation, statistics from fp32,
+    output stored bf16
   * BN finalize in fp64 -> fp32 scale/shift;  act(x) = relu(fma(x, scale, shift)) in fp32
   * materialise / residual add / bilinear / global pool: fp32 math, bf16 store
   * logits upsample: bf16 in, fp32 NCHW out
@@ -145,7 +146,7 @@ class Bf16EmuNet:
     def dw(self, a, p, bnp, stride, dil):
         c = a.t.shape[1]
         v = a.val()
-        if stride == 1 and dil <= 2:
+        if (stride == 1 and dil <= 2) or (stride == 2 and dil == 1):
             v = r16(v)
         if self.accum64:
             y = F.conv2d(v.double(), self.sd[p + ".weight"].double(), None, stride, dil, dil,

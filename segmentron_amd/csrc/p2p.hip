@@ -1,0 +1,231 @@
+// SyncBatchNorm statistics exchange as ONE-HOP peer writes over xGMI (the 2C+1
+// float64 sums of tools/train.py:76's SyncBatchNorm, 584 exchanges per DeepLabv3+/xception65
+// train step).  A ring all-reduce of a 12-33 KB message pays 2 (W - 1) hops of latency; MI355X's
+// xGMI is a full point-to-point mesh, so every rank can instead WRITE its vector straight into
+// a mailbox slot on each peer (hipIpc-mapped, uncached device memory), raise a flag there, wait
+// for the W flags in its own mailbox and add the W slots in rank order — one hop, one launch,
+// and every rank adds the same numbers in the same order (bit-identical replicas).
+//
+//   mailbox (one allocation per rank, exported with hipIpcGetMemHandle):
+//     [2 parities][W sender slots][slot_bytes]   data
+//     [W][16] u64                                 flags: exchange number last published by sender r
+//   exchange k uses parity k & 1.  A rank can reach exchange k + 2 (same parity) only after every
+//   peer has published k + 1, i.e. after that peer's kernel of exchange k — the reader of the
+//   slot — has ended: two parities are enough, no acknowledgements travel back.
+//
+// The exchange number lives in device memory and is advanced by the kernel itself, so the launch
+// can be captured into a HIP graph and replayed.  Waiting is bounded (P2P_TIMEOUT_TICKS of the
+// constant 100 MHz clock): on a timeout the kernel sets the error word, stops waiting in every
+// later exchange and the host reports it (seg_p2p_status) — never a hang.
+#include "common.h"
+#include <cstring>
+
+namespace seg {
+
+constexpr int P2P_MAX_WORLD = 16;
+constexpr int P2P_THREADS = 1024;
+constexpr int P2P_FLAG_STRIDE = 16;  // u64 per flag: one 128-byte line each
+constexpr unsigned long long P2P_TIMEOUT_TICKS = 30ull * 100000000ull;  // 30 s at 100 MHz
+
+struct P2PState {
+  int rank, world;
+  long slot_bytes;
+  unsigned char* local;                 // this rank's mailbox
+  unsigned char* peer[P2P_MAX_WORLD];   // every rank's mailbox as mapped here (peer[rank] = local)
+  bool opened[P2P_MAX_WORLD];
+  unsigned long long* seq;              // device: exchanges completed
+  int* err;                             // device: 0 ok, 1 timed out
+};
+
+struct P2PArgs {
+  unsigned char* peer[P2P_MAX_WORLD];
+  double* buf;
+  unsigned long long* seq;
+  int* err;
+  long slot_bytes;
+  int n, rank, world;
+};
+
+__device__ __forceinline__ unsigned long long* p2p_flags(unsigned char* box, int world,
+                                                         long slot_bytes) {
+  return reinterpret_cast<unsigned long long*>(box + 2L * world * slot_bytes);
+}
+
+__global__ __launch_bounds__(P2P_THREADS) void p2p_allreduce_kernel(const P2PArgs a) {
+  __shared__ unsigned long long s_seq;
+  __shared__ int s_bad;
+  const int tid = threadIdx.x;
+  if (tid == 0) {
+    s_seq = *a.seq + 1;
+    s_bad = *a.err;
+  }
+  __syncthreads();
+  const unsigned long long seq = s_seq;
+  const int par = (int)(seq & 1);
+  // 1. my vector into slot [par][rank] of every mailbox (my own included)
+  for (int r = 0; r < a.world; ++r) {
+    unsigned long long* dst = reinterpret_cast<unsigned long long*>(
+        a.peer[r] + ((long)par * a.world + a.rank) * a.slot_bytes);
+    const unsigned long long* src = reinterpret_cast<const unsigned long long*>(a.buf);
+    for (int i = tid; i < a.n; i += P2P_THREADS)
+      __hip_atomic_store(dst + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  __threadfence_system();  // this thread's slot writes are visible before any flag below
+  __syncthreads();
+  // 2. publish the exchange number on every rank; 3. wait for every rank's number here
+  if (tid < a.world) {
+    __hip_atomic_store(p2p_flags(a.peer[tid], a.world, a.slot_bytes) + (long)a.rank * P2P_FLAG_STRIDE,
+                       seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    const unsigned long long* mine =
+        p2p_flags(a.peer[a.rank], a.world, a.slot_bytes) + (long)tid * P2P_FLAG_STRIDE;
+    if (!s_bad) {
+      const unsigned long long t0 = wall_clock64();
+      while (__hip_atomic_load(mine, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+        __builtin_amdgcn_s_sleep(2);
+        if (wall_clock64() - t0 > P2P_TIMEOUT_TICKS) {
+          atomicExch(a.err, 1);
+          break;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  __threadfence_system();  // (acquire side: nothing below is served from a line cached earlier)
+  // 4. the sum over ranks, in rank order
+  for (int i = tid; i < a.n; i += P2P_THREADS) {
+    double s = 0.0;
+    for (int r = 0; r < a.world; ++r) {
+      const unsigned long long* slot = reinterpret_cast<const unsigned long long*>(
+          a.peer[a.rank] + ((long)par * a.world + r) * a.slot_bytes);
+      const unsigned long long bits =
+          __hip_atomic_load(slot + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      s += __longlong_as_double((long long)bits);
+    }
+    a.buf[i] = s;
+  }
+  if (tid == 0) *a.seq = seq;
+}
+
+static long p2p_box_bytes(int world, long slot_bytes) {
+  return 2L * world * slot_bytes + (long)world * P2P_FLAG_STRIDE * 8;
+}
+
+}  // namespace seg
+
+#define P2P_HIP(call, what)                                                        \
+  do {                                                                             \
+    hipError_t e_ = (call);                                                        \
+    if (e_ != hipSuccess) {                                                        \
+      seg::set_error("%s: %s", what, hipGetErrorString(e_));                       \
+      return 2;                                                                    \
+    }                                                                              \
+  } while (0)
+
+extern "C" int seg_p2p_create(int rank, int world, long slot_bytes, void** handle_out) {
+  using namespace seg;
+  SEG_REQUIRE(world >= 1 && world <= P2P_MAX_WORLD && rank >= 0 && rank < world,
+              "p2p_create: rank %d / world %d (at most %d ranks)", rank, world, P2P_MAX_WORLD);
+  SEG_REQUIRE(slot_bytes > 0 && slot_bytes % 128 == 0, "p2p_create: slot_bytes must be a multiple of 128");
+  P2PState* s = new P2PState();
+  s->rank = rank; s->world = world; s->slot_bytes = slot_bytes;
+  for (int r = 0; r < P2P_MAX_WORLD; ++r) { s->peer[r] = nullptr; s->opened[r] = false; }
+  const long bytes = p2p_box_bytes(world, slot_bytes);
+  void* box = nullptr;
+  // uncached device memory: a peer's xGMI writes land in HBM behind this GPU's L2, so the
+  // owner must not read the mailbox through cached lines
+  hipError_t e = hipExtMallocWithFlags(&box, bytes, hipDeviceMallocUncached);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    e = hipExtMallocWithFlags(&box, bytes, hipDeviceMallocFinegrained);
+  }
+  if (e != hipSuccess) {
+    delete s;
+    set_error("p2p_create: no uncached / fine-grained device memory (%s)", hipGetErrorString(e));
+    return 2;
+  }
+  void* words = nullptr;
+  if (hipMalloc(&words, 128) != hipSuccess || hipMemset(box, 0, bytes) != hipSuccess ||
+      hipMemset(words, 0, 128) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+    (void)hipFree(box);
+    if (words) (void)hipFree(words);
+    delete s;
+    set_error("p2p_create: cannot initialise the mailbox");
+    return 2;
+  }
+  s->local = static_cast<unsigned char*>(box);
+  s->peer[rank] = s->local;
+  s->seq = static_cast<unsigned long long*>(words);
+  s->err = reinterpret_cast<int*>(static_cast<unsigned char*>(words) + 64);
+  *handle_out = s;
+  return 0;
+}
+
+extern "C" int seg_p2p_ipc_handle(void* handle, void* out64) {
+  using namespace seg;
+  P2PState* s = static_cast<P2PState*>(handle);
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is 64 bytes");
+  hipIpcMemHandle_t h;
+  P2P_HIP(hipIpcGetMemHandle(&h, s->local), "p2p_ipc_handle: hipIpcGetMemHandle");
+  memcpy(out64, &h, 64);
+  return 0;
+}
+
+extern "C" int seg_p2p_connect(void* handle, const void* handles) {
+  using namespace seg;
+  P2PState* s = static_cast<P2PState*>(handle);
+  for (int r = 0; r < s->world; ++r) {
+    if (r == s->rank || s->peer[r] != nullptr) continue;
+    hipIpcMemHandle_t h;
+    memcpy(&h, static_cast<const unsigned char*>(handles) + 64L * r, 64);
+    void* p = nullptr;
+    P2P_HIP(hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess),
+            "p2p_connect: hipIpcOpenMemHandle");
+    s->peer[r] = static_cast<unsigned char*>(p);
+    s->opened[r] = true;
+  }
+  return 0;
+}
+
+extern "C" int seg_p2p_all_reduce_f64(void* handle, void* buf, int n, void* stream) {
+  using namespace seg;
+  P2PState* s = static_cast<P2PState*>(handle);
+  SEG_REQUIRE(n > 0 && (long)n * 8 <= s->slot_bytes, "p2p_all_reduce: %d doubles exceed the %ld-byte slot",
+              n, s->slot_bytes);
+  P2PArgs a;
+  for (int r = 0; r < P2P_MAX_WORLD; ++r) a.peer[r] = r < s->world ? s->peer[r] : nullptr;
+  for (int r = 0; r < s->world; ++r)
+    SEG_REQUIRE(a.peer[r] != nullptr, "p2p_all_reduce: rank %d is not connected", r);
+  a.buf = static_cast<double*>(buf);
+  a.seq = s->seq; a.err = s->err;
+  a.slot_bytes = s->slot_bytes;
+  a.n = n; a.rank = s->rank; a.world = s->world;
+  hipLaunchKernelGGL(p2p_allreduce_kernel, dim3(1), dim3(P2P_THREADS), 0, (hipStream_t)stream, a);
+  return check_launch("p2p_all_reduce");
+}
+
+// Synchronises the device; 0 = every exchange so far completed, 3 = a wait timed out.
+extern "C" int seg_p2p_status(void* handle) {
+  using namespace seg;
+  P2PState* s = static_cast<P2PState*>(handle);
+  int err = 0;
+  P2P_HIP(hipDeviceSynchronize(), "p2p_status: synchronize");
+  P2P_HIP(hipMemcpy(&err, s->err, sizeof(int), hipMemcpyDeviceToHost), "p2p_status: read");
+  if (err != 0) {
+    set_error("p2p: a peer did not publish its statistics within 30 s");
+    return 3;
+  }
+  return 0;
+}
+
+extern "C" int seg_p2p_destroy(void* handle) {
+  using namespace seg;
+  P2PState* s = static_cast<P2PState*>(handle);
+  if (s == nullptr) return 0;
+  (void)hipDeviceSynchronize();
+  for (int r = 0; r < s->world; ++r)
+    if (s->opened[r]) (void)hipIpcCloseMemHandle(s->peer[r]);
+  (void)hipFree(s->local);
+  (void)hipFree(s->seq);
+  delete s;
+  return 0;
+}

@@ -272,7 +272,7 @@ def test_dwconv_fwd_dgrad_wgrad(case, dtype):
     assert_close(to_cpu_nchw(y), ref.detach(), dtype, "dw y")
     sums = K().colsum(partial.view(partial.shape[0], -1)).cpu()
     r = ref.detach()
-    # bf16, tiled kernels (stride 1, dil <= 2): the activated operand is rounded to bf16 once (it
+    # bf16, tiled kernels (stride 1 dil <= 2, stride 2 dil 1): the activated operand is rounded to bf16 once (it
     # is parked in LDS in the storage dtype), so the sums carry that rounding (2^-9 per term)
     sfac = 5 if dtype == torch.float32 else 60
     assert_close(sums[:C], r.sum((0, 2, 3)), torch.float32, "dw sum",

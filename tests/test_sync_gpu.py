@@ -105,7 +105,12 @@ def _worker(rank, world, port, ret, naive=False, native=False):
         from segmentron_amd import parallel
         averager = None
         if native:  # the graph-capturable path of bench.py --gpus N: no DDP wrapper
-            parallel.use_native_rccl(_GlooComm(world))
+            comm = _GlooComm(world)
+            if native == "mailbox":  # statistics through the hipIpc peer mailbox (csrc/p2p.hip)
+                from segmentron_amd import xgmi
+                comm = xgmi.connect(comm, rank, world)
+                assert isinstance(comm, xgmi.StatsExchange), "the mailbox failed its start-up check"
+            parallel.use_native_rccl(comm)
             ddp = model
             # DDP's bucketed, backward-overlapped averaging on a side stream (small buckets here:
             # several launch while backward is still running)
@@ -133,6 +138,8 @@ def _worker(rank, world, port, ret, naive=False, native=False):
         if native:
             averager.finish()
         torch.cuda.synchronize()
+        if native == "mailbox":
+            comm.check()
         ret[rank] = {"logits": out[0].detach().cpu(), "loss": loss.item(),
                      "grads": {k: p.grad.detach().cpu() for k, p in model.named_parameters()
                                if p.grad is not None},
@@ -142,8 +149,10 @@ def _worker(rank, world, port, ret, naive=False, native=False):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("naive,native", [(False, False), (True, False), (False, True)],
-                         ids=["nn.SyncBatchNorm", "NaiveSyncBatchNorm", "native-exchange"])
+@pytest.mark.parametrize("naive,native", [(False, False), (True, False), (False, True),
+                                          (False, "mailbox")],
+                         ids=["nn.SyncBatchNorm", "NaiveSyncBatchNorm", "native-exchange",
+                              "peer-mailbox"])
 def test_syncbn_ddp_two_ranks_match_full_batch(naive, native):
     world = 2
     # single-process full batch: plain BatchNorm (a lone NaiveSyncBatchNorm process IS plain BN)
@@ -199,6 +208,78 @@ def test_syncbn_ddp_two_ranks_match_full_batch(naive, native):
           % ((num / den) ** 0.5, rels[len(rels) // 2], rels[-1]))
     # (ReLU near-ties can move single tensors by percents — see test_more_models.py)
     assert (num / den) ** 0.5 < 6e-2 and rels[len(rels) // 2] < 2e-3
+
+
+def _mailbox_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from segmentron_amd import xgmi
+        box = xgmi.PeerMailbox(rank, world)
+        gens = [torch.Generator().manual_seed(77 + r) for r in range(world)]
+        worst = 0.0
+        for n in (1, 3, 1457, 4097, 8192) * 6:  # 30 exchanges of every size class, back to back
+            xs = [torch.randn(n, dtype=torch.float64, generator=g) for g in gens]
+            mine = xs[rank].cuda()
+            box.all_reduce(mine)
+            want = torch.zeros(n, dtype=torch.float64)
+            for x in xs:  # the kernel adds the slots in rank order
+                want = want + x
+            worst = max(worst, float((mine.cpu() - want).abs().max()))
+            assert torch.equal(mine.cpu(), want), (n, worst)
+        # captured: three dependent exchanges per replay (the SyncBN chain of a train step)
+        x = torch.zeros(1457, dtype=torch.float64, device="cuda")
+        y = torch.zeros_like(x)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            y.copy_(x)
+            box.all_reduce(y)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side):
+                y.copy_(x)
+                box.all_reduce(y)
+                y.mul_(0.5)
+                box.all_reduce(y)
+                y.add_(1.0)
+                box.all_reduce(y)
+        torch.cuda.current_stream().wait_stream(side)
+        for k in range(20):
+            x.fill_(float(k + rank))  # sum over ranks: 2k + 1
+            g.replay()
+            torch.cuda.synchronize()
+            want = ((2.0 * k + 1.0) * 0.5 * world + 1.0) * world
+            assert float(y[0]) == want and float(y[-1]) == want, (k, float(y[0]), want)
+        box.check()
+        # a message larger than a slot is refused on the host
+        with pytest.raises(RuntimeError):
+            box.all_reduce(torch.zeros(8193, dtype=torch.float64, device="cuda"))
+        box.destroy()
+        ret[rank] = worst
+    finally:
+        dist.destroy_process_group()
+
+
+def test_peer_mailbox_two_processes_exchange_through_hipipc_eager_and_in_a_graph():
+    """csrc/p2p.hip + segmentron_amd/xgmi.py with two PROCESSES (hipIpc-mapped mailboxes, here
+    on one device — the peer pointers then resolve to local HBM instead of an xGMI link; the
+    protocol, the IPC plumbing, the flag/parity logic and graph replay are what is tested):
+    sums are bit-exact (rank-order addition), also across 60 replayed dependent exchanges."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    mgr = ctx.Manager()
+    ret = mgr.dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_mailbox_worker, args=(r, world, port, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert ret[0] == 0.0 and ret[1] == 0.0
 
 
 def test_bench_self_launches_two_ranks_and_reports_one_line():
@@ -297,4 +378,5 @@ def test_bench_native_data_parallel_step_is_one_graph_with_the_collectives_insid
     d = json.loads(out[0])
     assert d["launch"] == "hip_graph" and d["config"]["dp_mode"] == "native", d
     assert d["config"]["bn"] == "SyncBN" and "hip_graph_error" not in d
+    assert d["config"]["syncbn_exchange"].startswith("xgmi peer mailbox"), (d, p.stderr[-2000:])
     assert d["config"]["loss"] == d["config"]["loss"] and d["value"] > 0
