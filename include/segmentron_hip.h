@@ -345,14 +345,16 @@ int seg_cca_map(int dtype, const float* wt, const void* b, long ldb, int N, int 
  *                          bounds one message; *handle_out is an opaque object of THIS process
  *   seg_p2p_ipc_handle   : the 64-byte hipIpcMemHandle_t of the mailbox, to be sent to the peers
  *   seg_p2p_connect      : handles = [world][64] bytes in rank order (own entry ignored)
- *   seg_p2p_all_reduce_f64: buf[n] <- sum over ranks, on `stream` (capturable); every rank must
- *                          issue the same sequence of calls
+ *   seg_p2p_all_reduce_f64 / _f32: buf[n] <- sum over ranks (added in rank order: bit-identical
+ *                          on every rank), on `stream` (capturable); every rank must issue the
+ *                          same sequence of calls
  *   seg_p2p_status       : synchronises; 3 = a peer failed to publish within 30 s (the kernel
  *                          stops waiting instead of hanging)                                    */
 int seg_p2p_create(int rank, int world, long slot_bytes, void** handle_out);
 int seg_p2p_ipc_handle(void* handle, void* out64);
 int seg_p2p_connect(void* handle, const void* handles);
 int seg_p2p_all_reduce_f64(void* handle, void* buf, int n, void* stream);
+int seg_p2p_all_reduce_f32(void* handle, void* buf, int n, void* stream);
 int seg_p2p_status(void* handle);
 int seg_p2p_destroy(void* handle);
 

@@ -39,7 +39,7 @@ struct P2PState {
 
 struct P2PArgs {
   unsigned char* peer[P2P_MAX_WORLD];
-  double* buf;
+  void* buf;
   unsigned long long* seq;
   int* err;
   long slot_bytes;
@@ -51,7 +51,19 @@ __device__ __forceinline__ unsigned long long* p2p_flags(unsigned char* box, int
   return reinterpret_cast<unsigned long long*>(box + 2L * world * slot_bytes);
 }
 
+template <typename T> struct P2PBits;
+template <> struct P2PBits<double> {
+  typedef unsigned long long U;
+  __device__ static __forceinline__ double val(U b) { return __longlong_as_double((long long)b); }
+};
+template <> struct P2PBits<float> {
+  typedef unsigned int U;
+  __device__ static __forceinline__ float val(U b) { return __uint_as_float(b); }
+};
+
+template <typename T>
 __global__ __launch_bounds__(P2P_THREADS) void p2p_allreduce_kernel(const P2PArgs a) {
+  typedef typename P2PBits<T>::U U;
   __shared__ unsigned long long s_seq;
   __shared__ int s_bad;
   const int tid = threadIdx.x;
@@ -64,9 +76,8 @@ __global__ __launch_bounds__(P2P_THREADS) void p2p_allreduce_kernel(const P2PArg
   const int par = (int)(seq & 1);
   // 1. my vector into slot [par][rank] of every mailbox (my own included)
   for (int r = 0; r < a.world; ++r) {
-    unsigned long long* dst = reinterpret_cast<unsigned long long*>(
-        a.peer[r] + ((long)par * a.world + a.rank) * a.slot_bytes);
-    const unsigned long long* src = reinterpret_cast<const unsigned long long*>(a.buf);
+    U* dst = reinterpret_cast<U*>(a.peer[r] + ((long)par * a.world + a.rank) * a.slot_bytes);
+    const U* src = reinterpret_cast<const U*>(a.buf);
     for (int i = tid; i < a.n; i += P2P_THREADS)
       __hip_atomic_store(dst + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
@@ -92,16 +103,15 @@ __global__ __launch_bounds__(P2P_THREADS) void p2p_allreduce_kernel(const P2PArg
   __syncthreads();
   __threadfence_system();  // (acquire side: nothing below is served from a line cached earlier)
   // 4. the sum over ranks, in rank order
+  T* out = reinterpret_cast<T*>(a.buf);
   for (int i = tid; i < a.n; i += P2P_THREADS) {
-    double s = 0.0;
+    T s = (T)0;
     for (int r = 0; r < a.world; ++r) {
-      const unsigned long long* slot = reinterpret_cast<const unsigned long long*>(
+      const U* slot = reinterpret_cast<const U*>(
           a.peer[a.rank] + ((long)par * a.world + r) * a.slot_bytes);
-      const unsigned long long bits =
-          __hip_atomic_load(slot + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      s += __longlong_as_double((long long)bits);
+      s += P2PBits<T>::val(__hip_atomic_load(slot + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
     }
-    a.buf[i] = s;
+    out[i] = s;
   }
   if (tid == 0) *a.seq = seq;
 }
@@ -186,21 +196,30 @@ extern "C" int seg_p2p_connect(void* handle, const void* handles) {
   return 0;
 }
 
-extern "C" int seg_p2p_all_reduce_f64(void* handle, void* buf, int n, void* stream) {
+template <typename T>
+static int p2p_all_reduce(void* handle, void* buf, int n, void* stream) {
   using namespace seg;
   P2PState* s = static_cast<P2PState*>(handle);
-  SEG_REQUIRE(n > 0 && (long)n * 8 <= s->slot_bytes, "p2p_all_reduce: %d doubles exceed the %ld-byte slot",
-              n, s->slot_bytes);
+  SEG_REQUIRE(n > 0 && (long)n * (long)sizeof(T) <= s->slot_bytes,
+              "p2p_all_reduce: %d elements exceed the %ld-byte slot", n, s->slot_bytes);
   P2PArgs a;
   for (int r = 0; r < P2P_MAX_WORLD; ++r) a.peer[r] = r < s->world ? s->peer[r] : nullptr;
   for (int r = 0; r < s->world; ++r)
     SEG_REQUIRE(a.peer[r] != nullptr, "p2p_all_reduce: rank %d is not connected", r);
-  a.buf = static_cast<double*>(buf);
+  a.buf = buf;
   a.seq = s->seq; a.err = s->err;
   a.slot_bytes = s->slot_bytes;
   a.n = n; a.rank = s->rank; a.world = s->world;
-  hipLaunchKernelGGL(p2p_allreduce_kernel, dim3(1), dim3(P2P_THREADS), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(p2p_allreduce_kernel<T>, dim3(1), dim3(P2P_THREADS), 0, (hipStream_t)stream, a);
   return check_launch("p2p_all_reduce");
+}
+
+extern "C" int seg_p2p_all_reduce_f64(void* handle, void* buf, int n, void* stream) {
+  return p2p_all_reduce<double>(handle, buf, n, stream);
+}
+
+extern "C" int seg_p2p_all_reduce_f32(void* handle, void* buf, int n, void* stream) {
+  return p2p_all_reduce<float>(handle, buf, n, stream);
 }
 
 // Synchronises the device; 0 = every exchange so far completed, 3 = a wait timed out.

@@ -8,8 +8,8 @@ exchange as ONE kernel: write my vector into my slot on each peer, raise a flag,
 flags here, add the W slots in rank order.  One hop; results are bit-identical on all ranks; the
 launch is capturable (the exchange counter lives in device memory).
 
-`StatsExchange` is what `parallel.use_native_rccl` takes: float64 sums that fit a mailbox slot
-go through the mailbox, everything else (gradient buckets, other dtypes) through the wrapped
+`StatsExchange` is what `parallel.use_native_rccl` takes: float64 / float32 sums that fit a mailbox
+slot go through the mailbox, everything else (gradient buckets, other dtypes) through the wrapped
 communicator (segmentron_amd.rccl.Communicator).  `connect()` verifies the mailbox against that
 communicator before handing it out and returns the plain communicator if anything is off.
 
@@ -35,7 +35,7 @@ def _gather_bytes_torch(payload):
 
 
 class PeerMailbox:
-    """In-place float64 SUM over the ranks of one node.  `gather(bytes) -> [bytes] * world`
+    """In-place float64 / float32 SUM over the ranks of one node.  `gather(bytes) -> [bytes] * world`
     (rank order) carries the 64-byte IPC handles; default: torch.distributed.all_gather_object
     over the default group.  Every rank must construct it, and issue the same calls."""
 
@@ -57,15 +57,15 @@ class PeerMailbox:
             raise
 
     def fits(self, t):
-        return (t.dtype == torch.float64 and t.is_cuda and t.is_contiguous()
-                and 0 < t.numel() * 8 <= self.slot_bytes)
+        return (t.dtype in (torch.float64, torch.float32) and t.is_cuda and t.is_contiguous()
+                and 0 < t.numel() * t.element_size() <= self.slot_bytes)
 
     def all_reduce(self, t):
         if not self.fits(t):
-            raise RuntimeError("xgmi.PeerMailbox: contiguous float64 HIP tensor of at most %d "
-                               "elements required" % (self.slot_bytes // 8))
-        LIB.call("seg_p2p_all_reduce_f64", self._h, t.data_ptr(), t.numel(),
-                 torch.cuda.current_stream(t.device).cuda_stream)
+            raise RuntimeError("xgmi.PeerMailbox: contiguous float64 / float32 HIP tensor of at "
+                               "most %d bytes required" % self.slot_bytes)
+        LIB.call("seg_p2p_all_reduce_f64" if t.dtype == torch.float64 else "seg_p2p_all_reduce_f32",
+                 self._h, t.data_ptr(), t.numel(), torch.cuda.current_stream(t.device).cuda_stream)
         return t
 
     def check(self):
@@ -79,7 +79,7 @@ class PeerMailbox:
 
 
 class StatsExchange:
-    """`rccl.Communicator`'s interface: mailbox for the float64 statistics, `comm` for the rest."""
+    """`rccl.Communicator`'s interface: mailbox for the statistics vectors, `comm` for the rest."""
 
     def __init__(self, mailbox, comm):
         self.mailbox, self.comm = mailbox, comm
@@ -124,8 +124,10 @@ def connect(comm, rank, world, gather=None, rounds=4, log=sys.stderr):
         return comm
     # phase 1: the mailbox alone (a failure here must not change how many calls phase 2 makes)
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
-    inputs = [torch.randn(n, dtype=torch.float64, device=dev, generator=gen)
-              for n in (3, 1457, 4097, SLOT_BYTES // 8) for _ in range(rounds)]
+    inputs = [torch.randn(n, dtype=dt, device=dev, generator=gen)
+              for n, dt in ((3, torch.float64), (1457, torch.float64), (4097, torch.float64),
+                            (SLOT_BYTES // 8, torch.float64), (1456, torch.float32),
+                            (SLOT_BYTES // 4, torch.float32)) for _ in range(rounds)]
     src = torch.randn(1457, dtype=torch.float64, device=dev, generator=gen)
     got, a, bad = [], torch.zeros_like(src), 0.0
     try:
@@ -152,7 +154,8 @@ def connect(comm, rank, world, gather=None, rounds=4, log=sys.stderr):
     # phase 2: the same sums through the communicator
     for i, x in enumerate(inputs):
         want = comm.all_reduce(x.clone(), "sum")
-        if bad == 0.0 and not torch.allclose(got[i], want, rtol=1e-12, atol=1e-12):
+        tol = 1e-12 if x.dtype == torch.float64 else 1e-5
+        if bad == 0.0 and not torch.allclose(got[i], want, rtol=tol, atol=tol):
             bad = 1.0
     want = comm.all_reduce(comm.all_reduce(src.clone(), "sum"), "sum")
     if bad == 0.0 and not torch.allclose(a, want, rtol=1e-12, atol=1e-12):

@@ -257,6 +257,14 @@ def _mailbox_worker(rank, world, port, ret):
         # a message larger than a slot is refused on the host
         with pytest.raises(RuntimeError):
             box.all_reduce(torch.zeros(8193, dtype=torch.float64, device="cuda"))
+        # float32 vectors (the folded layers' [ds, dt] sums) take the same route
+        f = torch.full((1456,), 0.1 * (rank + 1), dtype=torch.float32, device="cuda")
+        box.all_reduce(f)
+        fw = torch.zeros(1456, dtype=torch.float32)
+        for r in range(world):
+            fw = fw + torch.full((1456,), 0.1 * (r + 1), dtype=torch.float32)
+        assert torch.equal(f.cpu(), fw)
+        box.check()
         box.destroy()
         ret[rank] = worst
     finally:
