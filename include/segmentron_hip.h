@@ -357,6 +357,30 @@ int seg_p2p_all_reduce_f64(void* handle, void* buf, int n, void* stream);
 int seg_p2p_all_reduce_f32(void* handle, void* buf, int n, void* stream);
 int seg_p2p_status(void* handle);
 int seg_p2p_destroy(void* handle);
+/* The BatchNorm finalize steps with the exchange INSIDE the kernel (column sums of this rank's
+ * partial rows -> peer writes -> finalize): a SyncBatchNorm then costs the same single launch per
+ * direction as a plain BatchNorm.  p2p = handle of seg_p2p_create; Rb <= 1024; ws (>= 128 C
+ * doubles) is needed for R > 1024 as in seg_bn_finalize_p; count_out /
+ * count_dev: the GLOBAL element count (float64, device) produced by the forward step and read by
+ * the backward ones; grad_scale multiplies dgamma / dbeta (1 / world, see seg_bn_bwd_finalize_s). */
+int seg_bn_finalize_p_sync(void* p2p, const float* partial, long R, double local_count,
+                           const float* gamma, const float* beta, float eps, float momentum,
+                           float* running_mean, float* running_var, float* mean, float* invstd,
+                           float* scale, float* shift, int C, const float* mean_offset,
+                           double* count_out, double* ws, void* stream);
+int seg_bn_bwd_finalize_p_sync(void* p2p, const float* partial, long R, const double* count_dev,
+                               const float* mean, const float* invstd, const float* gamma,
+                               float* dgamma, float* dbeta, float* c0, float* c1, int C,
+                               double grad_scale, double* ws, void* stream);
+int seg_dw_bwd_finalize_sync(void* p2p, const float* partial_bn, int Rb, const double* count_dev,
+                             const float* mean, const float* invstd, const float* gamma,
+                             float* dgamma, float* dbeta, float* c0, float* c1,
+                             const float* partial_w, int Rw, float* dw_c9, int C,
+                             double grad_scale, void* stream);
+int seg_fold_bwd_finalize_sync(void* p2p, const float* dsdt, int rows, const double* count_dev,
+                               const float* mean, const float* invstd, const float* gamma,
+                               const float* scale, float* dgamma, float* dbeta, float* c0,
+                               float* c1, int C, double grad_scale, void* stream);
 
 #ifdef __cplusplus
 }

@@ -14,6 +14,7 @@
 //                   -> seg_bn_bwd_apply:  dx = scale*g' - c0 - c1*x
 // Wavefront (64-lane) layout: lanes run along 16-byte channel vectors of NHWC rows.
 #include "common.h"
+#include "p2p.h"
 
 namespace seg {
 
@@ -423,7 +424,7 @@ __global__ __launch_bounds__(EW_THREADS) void bn_finalize_p_kernel(
     const TIN* __restrict__ part, int R, double count, const float* __restrict__ gamma,
     const float* __restrict__ beta, float eps, float momentum, float* running_mean,
     float* running_var, float* mean_o, float* invstd_o, float* scale_o, float* shift_o, int C,
-    const float* __restrict__ mean_offset) {
+    const float* __restrict__ mean_offset, const P2PDev p2p, double* count_out) {
   __shared__ double red[2][32][9];
   const int cx = threadIdx.x & 7, ry = threadIdx.x >> 3;
   const int c = blockIdx.x * 8 + cx;
@@ -437,6 +438,12 @@ __global__ __launch_bounds__(EW_THREADS) void bn_finalize_p_kernel(
   }
   double sx, sxx;
   reduce_two_columns<TIN>(part, R, C, c, ry, cx, red, sx, sxx);
+  if (p2p.world) {  // SyncBatchNorm: (sum, sum of squares, element count) summed over the ranks
+    double v[3] = {sx, sxx, count};
+    p2p_block_exchange<3>(p2p, blockIdx.x, gridDim.x, ry == 0, cx, 8, v);
+    sx = v[0]; sxx = v[1]; count = v[2];
+    if (count_out && blockIdx.x == 0 && threadIdx.x == 0) *count_out = count;
+  }
   if (!fin) return;
   const double mean = sx / count;
   double var = sxx / count - mean * mean;
@@ -457,7 +464,8 @@ template <typename TIN>
 __device__ __forceinline__ void bn_bwd_finalize_block(
     const TIN* __restrict__ part, int R, double count, const float* __restrict__ mean,
     const float* __restrict__ invstd, const float* __restrict__ gamma, float* dgamma, float* dbeta,
-    float* c0_o, float* c1_o, int C, int block, double (&red)[2][32][9]) {
+    float* c0_o, float* c1_o, int C, int block, double (&red)[2][32][9],
+    const double* __restrict__ count_dev, double grad_scale, const P2PDev& p2p, int nblocks) {
   const int cx = threadIdx.x & 7, ry = threadIdx.x >> 3;
   const int c = block * 8 + cx;
   const bool fin = ry == 0 && c < C;
@@ -466,17 +474,23 @@ __device__ __forceinline__ void bn_bwd_finalize_block(
     muf = mean[c];
     isf = invstd[c];
     if (gamma) gf = gamma[c];
+    if (count_dev) count = *count_dev;  // SyncBatchNorm: the global element count
   }
   double sg, sgx;
   reduce_two_columns<TIN>(part, R, C, c, ry, cx, red, sg, sgx);
+  if (p2p.world) {
+    double v[2] = {sg, sgx};
+    p2p_block_exchange<2>(p2p, block, nblocks, ry == 0, cx, 8, v);
+    sg = v[0]; sgx = v[1];
+  }
   if (!fin) return;
   const double mu = muf, is = isf;
   const double dg = (sgx - mu * sg) * is;
   const double s = (double)gf * is;
   const double m1 = sg / count, m2 = dg / count;
   const double c1 = s * m2 * is;
-  if (dgamma) dgamma[c] = (float)dg;
-  if (dbeta) dbeta[c] = (float)sg;
+  if (dgamma) dgamma[c] = (float)(dg * grad_scale);
+  if (dbeta) dbeta[c] = (float)(sg * grad_scale);
   c1_o[c] = (float)c1;
   c0_o[c] = (float)(s * m1 - c1 * mu);
 }
@@ -485,10 +499,11 @@ template <typename TIN>
 __global__ __launch_bounds__(EW_THREADS) void bn_bwd_finalize_p_kernel(
     const TIN* __restrict__ part, int R, double count, const float* __restrict__ mean,
     const float* __restrict__ invstd, const float* __restrict__ gamma, float* dgamma, float* dbeta,
-    float* c0_o, float* c1_o, int C) {
+    float* c0_o, float* c1_o, int C, const double* __restrict__ count_dev, double grad_scale,
+    const P2PDev p2p) {
   __shared__ double red[2][32][9];
   bn_bwd_finalize_block<TIN>(part, R, count, mean, invstd, gamma, dgamma, dbeta, c0_o, c1_o, C,
-                             blockIdx.x, red);
+                             blockIdx.x, red, count_dev, grad_scale, p2p, gridDim.x);
 }
 
 // The two reductions behind the fused depthwise backward in ONE launch (they were two: 65 + 78
@@ -499,11 +514,12 @@ __global__ __launch_bounds__(EW_THREADS) void dw_bwd_finalize_kernel(
     const float* __restrict__ part_bn, int Rb, double count, const float* __restrict__ mean,
     const float* __restrict__ invstd, const float* __restrict__ gamma, float* dgamma, float* dbeta,
     float* c0_o, float* c1_o, int C, int nb_bn, const float* __restrict__ part_w, int Rw,
-    float* __restrict__ dw_out) {
+    float* __restrict__ dw_out, const double* __restrict__ count_dev, double grad_scale,
+    const P2PDev p2p) {
   __shared__ double red[2][32][9];
-  if ((int)blockIdx.x < nb_bn) {
+  if ((int)blockIdx.x < nb_bn) {  // (SyncBatchNorm: only these blocks exchange; dW stays local)
     bn_bwd_finalize_block<float>(part_bn, Rb, count, mean, invstd, gamma, dgamma, dbeta, c0_o,
-                                 c1_o, C, blockIdx.x, red);
+                                 c1_o, C, blockIdx.x, red, count_dev, grad_scale, p2p, nb_bn);
     return;
   }
   const int cx = threadIdx.x & 7, ry = threadIdx.x >> 3;
@@ -759,14 +775,14 @@ extern "C" int seg_bn_finalize_p(const float* partial, long R, double count, con
   if (R <= 1024) {
     hipLaunchKernelGGL((bn_finalize_p_kernel<float>), grid, dim3(EW_THREADS), 0, st, partial,
                        (int)R, count, gamma, beta, eps, momentum, running_mean, running_var, mean,
-                       invstd, scale, shift, C, mean_offset);
+                       invstd, scale, shift, C, mean_offset, p2p_dev_none(), (double*)nullptr);
   } else {
     SEG_REQUIRE(ws != nullptr, "bn_finalize_p: workspace required for R=%ld", R);
     hipLaunchKernelGGL((colsum_kernel<double>), dim3((2 * C + 31) / 32, 64), dim3(EW_THREADS), 0,
                        st, partial, R, 2 * C, ws, 0.0, 0);
     hipLaunchKernelGGL((bn_finalize_p_kernel<double>), grid, dim3(EW_THREADS), 0, st, ws, 64,
                        count, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd,
-                       scale, shift, C, mean_offset);
+                       scale, shift, C, mean_offset, p2p_dev_none(), (double*)nullptr);
   }
   return check_launch("bn_finalize_p");
 }
@@ -781,13 +797,15 @@ extern "C" int seg_bn_bwd_finalize_p(const float* partial, long R, double count,
   const dim3 grid((C + 7) / 8);
   if (R <= 1024) {
     hipLaunchKernelGGL((bn_bwd_finalize_p_kernel<float>), grid, dim3(EW_THREADS), 0, st, partial,
-                       (int)R, count, mean, invstd, gamma, dgamma, dbeta, c0, c1, C);
+                       (int)R, count, mean, invstd, gamma, dgamma, dbeta, c0, c1, C,
+                       (const double*)nullptr, 1.0, p2p_dev_none());
   } else {
     SEG_REQUIRE(ws != nullptr, "bn_bwd_finalize_p: workspace required for R=%ld", R);
     hipLaunchKernelGGL((colsum_kernel<double>), dim3((2 * C + 31) / 32, 64), dim3(EW_THREADS), 0,
                        st, partial, R, 2 * C, ws, 0.0, 0);
     hipLaunchKernelGGL((bn_bwd_finalize_p_kernel<double>), grid, dim3(EW_THREADS), 0, st, ws, 64,
-                       count, mean, invstd, gamma, dgamma, dbeta, c0, c1, C);
+                       count, mean, invstd, gamma, dgamma, dbeta, c0, c1, C, (const double*)nullptr,
+                       1.0, p2p_dev_none());
   }
   return check_launch("bn_bwd_finalize_p");
 }
@@ -802,6 +820,87 @@ extern "C" int seg_dw_bwd_finalize(const float* partial_bn, int Rb, double count
   const int nb_bn = (C + 7) / 8;
   hipLaunchKernelGGL(dw_bwd_finalize_kernel, dim3(nb_bn + (9 * C + 7) / 8), dim3(EW_THREADS), 0,
                      (hipStream_t)stream, partial_bn, Rb, count, mean, invstd, gamma, dgamma, dbeta,
-                     c0, c1, C, nb_bn, partial_w, Rw, dw_c9);
+                     c0, c1, C, nb_bn, partial_w, Rw, dw_c9, (const double*)nullptr, 1.0,
+                     p2p_dev_none());
   return check_launch("dw_bwd_finalize");
+}
+
+// ---- the same three finalize steps for SyncBatchNorm: the sums are exchanged between the ranks
+// INSIDE the kernel (p2p.h: one-hop peer writes), so the launch count equals plain BatchNorm's.
+// `p2p` = handle of seg_p2p_create; every rank issues the same calls in the same order.
+extern "C" int seg_bn_finalize_p_sync(void* p2p, const float* partial, long R, double local_count,
+                                      const float* gamma, const float* beta, float eps,
+                                      float momentum, float* running_mean, float* running_var,
+                                      float* mean, float* invstd, float* scale, float* shift, int C,
+                                      const float* mean_offset, double* count_out, double* ws,
+                                      void* stream) {
+  using namespace seg;
+  SEG_REQUIRE(local_count >= 0.0 && C >= 1 && R >= 1, "bn_finalize_p_sync: bad count/C/R");
+  P2PDev d;
+  if (!p2p_dev_of(p2p, d)) return 2;
+  const int nb = (C + 7) / 8;
+  SEG_REQUIRE(nb <= P2P_MAX_BLOCKS && (long)nb * 8 * 3 * 8 <= d.slot_bytes,
+              "bn_finalize_p_sync: C=%d exceeds the mailbox", C);
+  hipStream_t st = (hipStream_t)stream;
+  if (R <= 1024) {
+    hipLaunchKernelGGL((bn_finalize_p_kernel<float>), dim3(nb), dim3(EW_THREADS), 0, st, partial,
+                       (int)R, local_count, gamma, beta, eps, momentum, running_mean, running_var,
+                       mean, invstd, scale, shift, C, mean_offset, d, count_out);
+  } else {  // two-level, as seg_bn_finalize_p
+    SEG_REQUIRE(ws != nullptr, "bn_finalize_p_sync: workspace required for R=%ld", R);
+    hipLaunchKernelGGL((colsum_kernel<double>), dim3((2 * C + 31) / 32, 64), dim3(EW_THREADS), 0,
+                       st, partial, R, 2 * C, ws, 0.0, 0);
+    hipLaunchKernelGGL((bn_finalize_p_kernel<double>), dim3(nb), dim3(EW_THREADS), 0, st, ws, 64,
+                       local_count, gamma, beta, eps, momentum, running_mean, running_var, mean,
+                       invstd, scale, shift, C, mean_offset, d, count_out);
+  }
+  return check_launch("bn_finalize_p_sync");
+}
+
+extern "C" int seg_bn_bwd_finalize_p_sync(void* p2p, const float* partial, long R,
+                                          const double* count_dev, const float* mean,
+                                          const float* invstd, const float* gamma, float* dgamma,
+                                          float* dbeta, float* c0, float* c1, int C,
+                                          double grad_scale, double* ws, void* stream) {
+  using namespace seg;
+  SEG_REQUIRE(count_dev && C >= 1 && R >= 1, "bn_bwd_finalize_p_sync: bad count/C/R");
+  P2PDev d;
+  if (!p2p_dev_of(p2p, d)) return 2;
+  const int nb = (C + 7) / 8;
+  SEG_REQUIRE(nb <= P2P_MAX_BLOCKS && (long)nb * 8 * 2 * 8 <= d.slot_bytes,
+              "bn_bwd_finalize_p_sync: C=%d exceeds the mailbox", C);
+  hipStream_t st = (hipStream_t)stream;
+  if (R <= 1024) {
+    hipLaunchKernelGGL((bn_bwd_finalize_p_kernel<float>), dim3(nb), dim3(EW_THREADS), 0, st,
+                       partial, (int)R, 1.0, mean, invstd, gamma, dgamma, dbeta, c0, c1, C,
+                       count_dev, grad_scale, d);
+  } else {
+    SEG_REQUIRE(ws != nullptr, "bn_bwd_finalize_p_sync: workspace required for R=%ld", R);
+    hipLaunchKernelGGL((colsum_kernel<double>), dim3((2 * C + 31) / 32, 64), dim3(EW_THREADS), 0,
+                       st, partial, R, 2 * C, ws, 0.0, 0);
+    hipLaunchKernelGGL((bn_bwd_finalize_p_kernel<double>), dim3(nb), dim3(EW_THREADS), 0, st, ws,
+                       64, 1.0, mean, invstd, gamma, dgamma, dbeta, c0, c1, C, count_dev,
+                       grad_scale, d);
+  }
+  return check_launch("bn_bwd_finalize_p_sync");
+}
+
+extern "C" int seg_dw_bwd_finalize_sync(void* p2p, const float* partial_bn, int Rb,
+                                        const double* count_dev, const float* mean,
+                                        const float* invstd, const float* gamma, float* dgamma,
+                                        float* dbeta, float* c0, float* c1, const float* partial_w,
+                                        int Rw, float* dw_c9, int C, double grad_scale,
+                                        void* stream) {
+  using namespace seg;
+  SEG_REQUIRE(count_dev && C >= 1 && Rb >= 1 && Rw >= 1 && Rb <= 1024,
+              "dw_bwd_finalize_sync: bad count/C/rows");
+  P2PDev d;
+  if (!p2p_dev_of(p2p, d)) return 2;
+  const int nb_bn = (C + 7) / 8;
+  SEG_REQUIRE(nb_bn <= P2P_MAX_BLOCKS && (long)nb_bn * 8 * 2 * 8 <= d.slot_bytes,
+              "dw_bwd_finalize_sync: C=%d exceeds the mailbox", C);
+  hipLaunchKernelGGL(dw_bwd_finalize_kernel, dim3(nb_bn + (9 * C + 7) / 8), dim3(EW_THREADS), 0,
+                     (hipStream_t)stream, partial_bn, Rb, 1.0, mean, invstd, gamma, dgamma, dbeta,
+                     c0, c1, C, nb_bn, partial_w, Rw, dw_c9, count_dev, grad_scale, d);
+  return check_launch("dw_bwd_finalize_sync");
 }

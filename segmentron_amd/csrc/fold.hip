@@ -10,6 +10,7 @@
 //                                          c0 = dt s / n - c1 mean
 // (63 of the 79 GEMM-shaped convolutions of DeepLabv3+/xception65, ~80 % of its FLOPs.)
 #include "common.h"
+#include "p2p.h"
 
 namespace seg {
 
@@ -218,7 +219,7 @@ __global__ __launch_bounds__(256) void fold_bwd_finalize_kernel(
     const float* __restrict__ dsdt, int R, double count, const double* __restrict__ count_dev,
     const float* __restrict__ mean, const float* __restrict__ invstd,
     const float* __restrict__ gamma, const float* __restrict__ scale, float* dgamma, float* dbeta,
-    float* c0, float* c1, int C, double grad_scale) {
+    float* c0, float* c1, int C, double grad_scale, const P2PDev p2p) {
   __shared__ double red[2][4][64];
   const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
@@ -250,9 +251,16 @@ __global__ __launch_bounds__(256) void fold_bwd_finalize_kernel(
   red[0][rg][cl] = ds;
   red[1][rg][cl] = dt;
   __syncthreads();
+  if (rg == 0) {
+    ds = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
+    dt = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
+  }
+  if (p2p.world) {  // SyncBatchNorm: (ds, dt) summed over the ranks inside this kernel (p2p.h)
+    double v[2] = {ds, dt};
+    p2p_block_exchange<2>(p2p, blockIdx.x, gridDim.x, rg == 0, cl, 64, v);
+    ds = v[0]; dt = v[1];
+  }
   if (!fin) return;
-  ds = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
-  dt = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
   const double mu = muf, is = isf;
   const double g = gf;
   const double u = ds - mu * dt;
@@ -317,14 +325,33 @@ static int fold_bwd_finalize_impl(const float* dsdt, int rows, double count,
                                   const double* count_dev, const float* mean, const float* invstd,
                                   const float* gamma, const float* scale, float* dgamma,
                                   float* dbeta, float* c0, float* c1, int C, double grad_scale,
-                                  void* stream) {
+                                  void* stream, const seg::P2PDev& p2p = seg::p2p_dev_none()) {
   using namespace seg;
   SEG_REQUIRE((count_dev || count >= 1.0) && C >= 1 && rows >= 1,
               "fold_bwd_finalize: bad count/C/rows");
   hipLaunchKernelGGL(fold_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0,
                      (hipStream_t)stream, dsdt, rows, count, count_dev, mean, invstd, gamma, scale,
-                     dgamma, dbeta, c0, c1, C, grad_scale);
+                     dgamma, dbeta, c0, c1, C, grad_scale, p2p);
   return check_launch("fold_bwd_finalize");
+}
+
+// SyncBatchNorm: (ds, dt) exchanged between the ranks inside the kernel (p2p.h) — dsdt holds this
+// rank's LOCAL partial rows; `p2p` = handle of seg_p2p_create
+extern "C" int seg_fold_bwd_finalize_sync(void* p2p, const float* dsdt, int rows,
+                                          const double* count_dev, const float* mean,
+                                          const float* invstd, const float* gamma,
+                                          const float* scale, float* dgamma, float* dbeta,
+                                          float* c0, float* c1, int C, double grad_scale,
+                                          void* stream) {
+  using namespace seg;
+  SEG_REQUIRE(count_dev != nullptr, "fold_bwd_finalize_sync: the global count lives on the device");
+  P2PDev d;
+  if (!p2p_dev_of(p2p, d)) return 2;
+  const int nb = (C + 63) / 64;
+  SEG_REQUIRE(nb <= P2P_MAX_BLOCKS && (long)nb * 64 * 2 * 8 <= d.slot_bytes,
+              "fold_bwd_finalize_sync: C=%d exceeds the mailbox", C);
+  return fold_bwd_finalize_impl(dsdt, rows, 1.0, count_dev, mean, invstd, gamma, scale, dgamma,
+                                dbeta, c0, c1, C, grad_scale, stream, d);
 }
 
 extern "C" int seg_fold_bwd_finalize(const float* dsdt, int rows, double count,

@@ -2,7 +2,8 @@
 // float64 sums of tools/train.py:76's SyncBatchNorm, 584 exchanges per DeepLabv3+/xception65
 // train step).  A ring all-reduce of a 12-33 KB message pays 2 (W - 1) hops of latency; MI355X's
 // xGMI is a full point-to-point mesh, so every rank can instead WRITE its vector straight into
-// a mailbox slot on each peer (hipIpc-mapped, uncached device memory), raise a flag there, wait
+// a mailbox slot on each peer (hipIpc-mapped, uncached device memory; every access a
+// cache-bypassing system-scope atomic — ordering rules in p2p.h), raise a flag there, wait
 // for the W flags in its own mailbox and add the W slots in rank order — one hop, one launch,
 // and every rank adds the same numbers in the same order (bit-identical replicas).
 //
@@ -17,25 +18,12 @@
 // can be captured into a HIP graph and replayed.  Waiting is bounded (P2P_TIMEOUT_TICKS of the
 // constant 100 MHz clock): on a timeout the kernel sets the error word, stops waiting in every
 // later exchange and the host reports it (seg_p2p_status) — never a hang.
-#include "common.h"
+#include "p2p.h"
 #include <cstring>
 
 namespace seg {
 
-constexpr int P2P_MAX_WORLD = 16;
 constexpr int P2P_THREADS = 1024;
-constexpr int P2P_FLAG_STRIDE = 16;  // u64 per flag: one 128-byte line each
-constexpr unsigned long long P2P_TIMEOUT_TICKS = 30ull * 100000000ull;  // 30 s at 100 MHz
-
-struct P2PState {
-  int rank, world;
-  long slot_bytes;
-  unsigned char* local;                 // this rank's mailbox
-  unsigned char* peer[P2P_MAX_WORLD];   // every rank's mailbox as mapped here (peer[rank] = local)
-  bool opened[P2P_MAX_WORLD];
-  unsigned long long* seq;              // device: exchanges completed
-  int* err;                             // device: 0 ok, 1 timed out
-};
 
 struct P2PArgs {
   unsigned char* peer[P2P_MAX_WORLD];
@@ -45,11 +33,6 @@ struct P2PArgs {
   long slot_bytes;
   int n, rank, world;
 };
-
-__device__ __forceinline__ unsigned long long* p2p_flags(unsigned char* box, int world,
-                                                         long slot_bytes) {
-  return reinterpret_cast<unsigned long long*>(box + 2L * world * slot_bytes);
-}
 
 template <typename T> struct P2PBits;
 template <> struct P2PBits<double> {
@@ -81,27 +64,17 @@ __global__ __launch_bounds__(P2P_THREADS) void p2p_allreduce_kernel(const P2PArg
     for (int i = tid; i < a.n; i += P2P_THREADS)
       __hip_atomic_store(dst + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
-  __threadfence_system();  // this thread's slot writes are visible before any flag below
+  p2p_stores_done();  // this thread's slot writes are acknowledged before any flag below (p2p.h)
   __syncthreads();
   // 2. publish the exchange number on every rank; 3. wait for every rank's number here
   if (tid < a.world) {
     __hip_atomic_store(p2p_flags(a.peer[tid], a.world, a.slot_bytes) + (long)a.rank * P2P_FLAG_STRIDE,
-                       seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                       seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     const unsigned long long* mine =
         p2p_flags(a.peer[a.rank], a.world, a.slot_bytes) + (long)tid * P2P_FLAG_STRIDE;
-    if (!s_bad) {
-      const unsigned long long t0 = wall_clock64();
-      while (__hip_atomic_load(mine, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
-        __builtin_amdgcn_s_sleep(2);
-        if (wall_clock64() - t0 > P2P_TIMEOUT_TICKS) {
-          atomicExch(a.err, 1);
-          break;
-        }
-      }
-    }
+    if (!s_bad) p2p_wait(mine, seq, a.err);
   }
   __syncthreads();
-  __threadfence_system();  // (acquire side: nothing below is served from a line cached earlier)
   // 4. the sum over ranks, in rank order
   T* out = reinterpret_cast<T*>(a.buf);
   for (int i = tid; i < a.n; i += P2P_THREADS) {
@@ -114,10 +87,6 @@ __global__ __launch_bounds__(P2P_THREADS) void p2p_allreduce_kernel(const P2PArg
     out[i] = s;
   }
   if (tid == 0) *a.seq = seq;
-}
-
-static long p2p_box_bytes(int world, long slot_bytes) {
-  return 2L * world * slot_bytes + (long)world * P2P_FLAG_STRIDE * 8;
 }
 
 }  // namespace seg
@@ -165,6 +134,7 @@ extern "C" int seg_p2p_create(int rank, int world, long slot_bytes, void** handl
   s->local = static_cast<unsigned char*>(box);
   s->peer[rank] = s->local;
   s->seq = static_cast<unsigned long long*>(words);
+  s->arrive = reinterpret_cast<unsigned int*>(static_cast<unsigned char*>(words) + 32);
   s->err = reinterpret_cast<int*>(static_cast<unsigned char*>(words) + 64);
   *handle_out = s;
   return 0;

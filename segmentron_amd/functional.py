@@ -114,13 +114,19 @@ def finish_bn(bn, partial, count, mean_offset=None):
                                                      momentum, rm, rv, mean_offset)
     else:
         C = partial.shape[-1]
-        sums, cnt = parallel.allreduce_forward_sums(partial.view(partial.shape[0], 2 * C), cnt,
-                                                    group)
         naive = parallel.is_naive_sync(bn)
         if naive:  # the reference's own SyncBN: biased running_var, no counter (batch_norm.py:174)
             rm = rv = None
-        mean, invstd, scale, shift = K.bn_finalize(sums, cnt, bn.weight, bn.bias, bn.eps,
-                                                   momentum, rm, rv, mean_offset)
+        box = parallel.mailbox()
+        if box is not None:
+            # column sums -> exchange (peer writes) -> finalize in ONE launch, like plain BN
+            mean, invstd, scale, shift, cnt = K.bn_finalize_p_sync(
+                box, partial, cnt, bn.weight, bn.bias, bn.eps, momentum, rm, rv, mean_offset)
+        else:
+            sums, cnt = parallel.allreduce_forward_sums(partial.view(partial.shape[0], 2 * C),
+                                                        cnt, group)
+            mean, invstd, scale, shift = K.bn_finalize(sums, cnt, bn.weight, bn.bias, bn.eps,
+                                                       momentum, rm, rv, mean_offset)
         if naive and track:
             mo = mean if mean_offset is None else mean + mean_offset
             parallel.naive_running_update(bn, mo, invstd)
@@ -141,6 +147,17 @@ def flush_bn_counters():
         del _PENDING_COUNTERS[:]
 
 
+def _sync_bwd_finalize(partial, bn):
+    """SyncBatchNorm backward sums [R, 2C] -> (dgamma, dbeta, c0, c1): inside the finalize kernel
+    when the peer mailbox is active, else column sums -> all-reduce -> finalize."""
+    box = parallel.mailbox()
+    scale = parallel.grad_scale(bn.group)
+    if box is not None and isinstance(bn.count, torch.Tensor):
+        return K.bn_bwd_finalize_p_sync(box, partial, bn.count, bn.mean, bn.invstd, bn.gamma, scale)
+    sums = parallel.allreduce_backward_sums(K.colsum(partial), bn.group)
+    return K.bn_bwd_finalize(sums, bn.count, bn.mean, bn.invstd, bn.gamma, scale)
+
+
 def bn_input_backward(g, x, bn, relu, chan_mul=None, inplace=False, elem_mul=None):
     """g = dLoss/d(act(x)*chan_mul*elem_mul)  ->  (dLoss/dx_raw, dgamma, dbeta)."""
     mode = (PRO_AFFINE if bn is not None else PRO_NONE) | int(relu)
@@ -156,9 +173,7 @@ def bn_input_backward(g, x, bn, relu, chan_mul=None, inplace=False, elem_mul=Non
         dgamma, dbeta, c0, c1 = K.bn_bwd_finalize_p(partial, bn.count, bn.mean, bn.invstd,
                                                     bn.gamma)
     else:
-        sums = parallel.allreduce_backward_sums(K.colsum(partial), bn.group)
-        dgamma, dbeta, c0, c1 = K.bn_bwd_finalize(sums, bn.count, bn.mean, bn.invstd, bn.gamma,
-                                                  parallel.grad_scale(bn.group))
+        dgamma, dbeta, c0, c1 = _sync_bwd_finalize(partial, bn)
     if not bn.training:
         c0 = c1 = None
     dx = K.bn_bwd_apply(g, x, pro, c0, c1, chan_mul, out=g if inplace else None,
@@ -362,12 +377,18 @@ class _FoldConvFn(torch.autograd.Function):
         if not s.drop_const:  # eval-mode consumer: the constant term carries gradient
             db = K.bn_bwd_reduce(dy, dy, (PRO_NONE, None, None))[:O].float()
         dW, dsdt = K.fold_bwd_reduce(weight.detach().view(O, C), dwp, bn.scale, bn.shift, db)
-        if bn.group is not None:
-            dsdt = K.colsum(dsdt, f64=False)
-            parallel.allreduce_backward_sums(dsdt, bn.group)
-        dgamma, dbeta, c0, c1 = K.fold_bwd_finalize(
-            dsdt, bn.count, bn.mean, bn.invstd, bn.gamma, bn.scale,
-            parallel.grad_scale(bn.group) if bn.group is not None else 1.0)
+        box = parallel.mailbox() if bn.group is not None else None
+        if box is not None and isinstance(bn.count, torch.Tensor):
+            dgamma, dbeta, c0, c1 = K.fold_bwd_finalize_sync(
+                box, dsdt, bn.count, bn.mean, bn.invstd, bn.gamma, bn.scale,
+                parallel.grad_scale(bn.group))
+        else:
+            if bn.group is not None:
+                dsdt = K.colsum(dsdt, f64=False)
+                parallel.allreduce_backward_sums(dsdt, bn.group)
+            dgamma, dbeta, c0, c1 = K.fold_bwd_finalize(
+                dsdt, bn.count, bn.mean, bn.invstd, bn.gamma, bn.scale,
+                parallel.grad_scale(bn.group) if bn.group is not None else 1.0)
         dx = None
         if ctx.needs_input_grad[0]:
             if s.stride == 1:
@@ -419,7 +440,9 @@ class _DwFn(torch.autograd.Function):
             bn = s.bn_in
             # single-process BatchNorm on the input: the weight-gradient partials and the
             # BatchNorm-backward partials are reduced by ONE launch (K.dw_bwd_finalize)
-            both = bn is not None and bn.group is None and (strided or tiled)
+            box = parallel.mailbox() if (bn is not None and bn.group is not None) else None
+            both = bn is not None and (strided or tiled) and \
+                (bn.group is None or (box is not None and isinstance(bn.count, torch.Tensor)))
             if strided:
                 g, dW, pb = K.dwconv_bwd_fused_s2(x, dy, weight.detach().contiguous(), s.pro,
                                                   want_bn=bn is not None, raw_dw=both)
@@ -440,20 +463,25 @@ class _DwFn(torch.autograd.Function):
             if bn is None:
                 dx = g  # plain / ReLU input: the masked gradient is final
             else:
-                if both and pb.shape[0] <= 1024:
+                if both and pb.shape[0] <= 1024 and bn.group is None:
                     dgamma, dbeta, c0, c1, dW = K.dw_bwd_finalize(pb, dW, bn.count, bn.mean,
                                                                   bn.invstd, bn.gamma)
+                elif both and pb.shape[0] <= 1024:  # SyncBN: the exchange inside the same launch
+                    dgamma, dbeta, c0, c1, dW = K.dw_bwd_finalize_sync(
+                        box, pb, dW, bn.count, bn.mean, bn.invstd, bn.gamma,
+                        parallel.grad_scale(bn.group))
                 elif both:
                     dW = K.dw_wgrad_finalize(dW, C)
-                    dgamma, dbeta, c0, c1 = K.bn_bwd_finalize_p(pb, bn.count, bn.mean, bn.invstd,
-                                                                bn.gamma)
+                    if bn.group is None:
+                        dgamma, dbeta, c0, c1 = K.bn_bwd_finalize_p(pb, bn.count, bn.mean,
+                                                                    bn.invstd, bn.gamma)
+                    else:
+                        dgamma, dbeta, c0, c1 = _sync_bwd_finalize(pb, bn)
                 elif bn.group is None:
                     dgamma, dbeta, c0, c1 = K.bn_bwd_finalize_p(pb, bn.count, bn.mean, bn.invstd,
                                                                 bn.gamma)
                 else:
-                    sums = parallel.allreduce_backward_sums(K.colsum(pb), bn.group)
-                    dgamma, dbeta, c0, c1 = K.bn_bwd_finalize(sums, bn.count, bn.mean, bn.invstd,
-                                                              bn.gamma, parallel.grad_scale(bn.group))
+                    dgamma, dbeta, c0, c1 = _sync_bwd_finalize(pb, bn)
                 if not bn.training:
                     c0 = c1 = None
                 # the ReLU mask is already in g: apply only the affine part of the BN backward

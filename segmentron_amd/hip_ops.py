@@ -241,6 +241,18 @@ def dw_bwd_finalize(pb, pw, count, mean, invstd, gamma):
     return out[0], out[1], out[2], out[3], dW
 
 
+def dw_bwd_finalize_sync(box, pb, pw, count_dev, mean, invstd, gamma, grad_scale):
+    """dw_bwd_finalize for SyncBatchNorm: the BatchNorm sums are exchanged between the ranks
+    inside the kernel (box: xgmi.PeerMailbox); the weight gradient stays local."""
+    C = mean.numel()
+    out = torch.empty((4, C), dtype=torch.float32, device=mean.device)
+    dW = torch.empty((C, 1, 3, 3), dtype=torch.float32, device=mean.device)
+    LIB.call("seg_dw_bwd_finalize_sync", box.handle, _p(pb), pb.shape[0], _p(count_dev), _p(mean),
+             _p(invstd), _p(gamma), _p(out[0]), _p(out[1]), _p(out[2]), _p(out[3]), _p(pw),
+             pw.shape[0], _p(dW), C, float(grad_scale), _stream())
+    return out[0], out[1], out[2], out[3], dW
+
+
 def dwconv_bwd_fused_add_ok(x, dil):
     """Can the fused depthwise backward add a second gradient in its store path?"""
     return bool(LIB.query("seg_dwconv3x3_bwd_fused_add_ok", int(dil)))
@@ -412,6 +424,32 @@ def bn_finalize_p(partial, count, gamma, beta, eps, momentum, running_mean, runn
     return out[0], out[1], out[2], out[3]
 
 
+def bn_finalize_p_sync(box, partial, local_count, gamma, beta, eps, momentum, running_mean,
+                       running_var, mean_offset=None):
+    """bn_finalize_p for SyncBatchNorm in ONE launch: this rank's partial rows are summed, the
+    sums and the local element count exchanged through the peer mailbox inside the kernel, and
+    the global statistics finalized -> mean, invstd, scale, shift, global count (float64 [1])."""
+    R = partial.shape[0]
+    C = partial.numel() // (2 * R)
+    out = torch.empty((4, C), dtype=torch.float32, device=partial.device)
+    cnt = torch.empty(1, dtype=torch.float64, device=partial.device)
+    ws = _ws(R, C, partial.device)
+    LIB.call("seg_bn_finalize_p_sync", box.handle, _p(partial), R, float(local_count), _p(gamma),
+             _p(beta), float(eps), float(momentum), _p(running_mean), _p(running_var), _p(out[0]),
+             _p(out[1]), _p(out[2]), _p(out[3]), C, _p(mean_offset), _p(cnt), _p(ws), _stream())
+    return out[0], out[1], out[2], out[3], cnt
+
+
+def bn_bwd_finalize_p_sync(box, partial, count_dev, mean, invstd, gamma, grad_scale):
+    C = mean.numel()
+    out = torch.empty((4, C), dtype=torch.float32, device=mean.device)
+    ws = _ws(partial.shape[0], C, mean.device)
+    LIB.call("seg_bn_bwd_finalize_p_sync", box.handle, _p(partial), partial.shape[0], _p(count_dev),
+             _p(mean), _p(invstd), _p(gamma), _p(out[0]), _p(out[1]), _p(out[2]), _p(out[3]), C,
+             float(grad_scale), _p(ws), _stream())
+    return out[0], out[1], out[2], out[3]
+
+
 def bn_bwd_finalize_p(partial, count, mean, invstd, gamma):
     R = partial.shape[0]
     C = mean.numel()
@@ -486,6 +524,18 @@ def fold_bwd_finalize(dsdt, count, mean, invstd, gamma, scale, grad_scale=1.0):
              _p(invstd), _p(gamma), _p(scale), _p(out[0]), _p(out[1]), _p(out[2]), _p(out[3]), C,
              float(grad_scale), _stream())
     return out[0], out[1], out[2], out[3]  # dgamma, dbeta, c0, c1
+
+
+def fold_bwd_finalize_sync(box, dsdt, count_dev, mean, invstd, gamma, scale, grad_scale):
+    """fold_bwd_finalize for SyncBatchNorm: dsdt = this rank's LOCAL (ds, dt) partial rows; the
+    exchange happens inside the kernel."""
+    C = mean.numel()
+    out = torch.empty((4, C), dtype=torch.float32, device=mean.device)
+    dsdt = dsdt.view(-1, 2 * C)
+    LIB.call("seg_fold_bwd_finalize_sync", box.handle, _p(dsdt), dsdt.shape[0], _p(count_dev),
+             _p(mean), _p(invstd), _p(gamma), _p(scale), _p(out[0]), _p(out[1]), _p(out[2]),
+             _p(out[3]), C, float(grad_scale), _stream())
+    return out[0], out[1], out[2], out[3]
 
 
 # ----------------------------------------------------------------------------- pooling

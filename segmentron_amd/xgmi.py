@@ -24,7 +24,8 @@ import torch
 from ._lib import LIB
 
 _HANDLE_BYTES = 64
-SLOT_BYTES = 64 * 1024  # 8192 doubles: 2C + 1 up to C = 4095
+SLOT_BYTES = 128 * 1024  # one message: 16384 doubles; the in-kernel exchange of the finalize
+#                          kernels needs 24 B per channel (forward) -> C up to 4096
 
 
 def _gather_bytes_torch(payload):
@@ -44,6 +45,7 @@ class PeerMailbox:
         h = ctypes.c_void_p()
         LIB.call("seg_p2p_create", self.rank, self.world, self.slot_bytes, ctypes.byref(h))
         self._h = h
+        self.handle = h  # what the seg_*_sync entry points take
         try:
             mine = ctypes.create_string_buffer(_HANDLE_BYTES)
             LIB.call("seg_p2p_ipc_handle", self._h, mine)
@@ -75,7 +77,7 @@ class PeerMailbox:
     def destroy(self):
         if self._h:
             LIB.query("seg_p2p_destroy", self._h)
-            self._h = ctypes.c_void_p()
+            self._h = self.handle = ctypes.c_void_p()
 
 
 class StatsExchange:

@@ -26,9 +26,29 @@ def _free_port():
     return p
 
 
-def _build(naive=False):
+def _join_or_kill(procs, seconds):
+    """Wait `seconds` IN TOTAL for the rank processes; a rank that is still running then is
+    killed (exit code != 0 fails the test) — a lost peer must never stall the suite."""
+    import time
+    deadline = time.time() + seconds
+    for p in procs:
+        p.join(max(0.0, deadline - time.time()))
+    for p in procs:
+        if p.is_alive():
+            p.kill()
+            p.join(10)
+
+
+def _build(naive=False, case="c5"):
     import segmentron_amd
     import test_more_models as T
+    if case == "c3":  # DeepLabv3+/xception65: depthwise + folded-BN layers (their finalize kernels)
+        import test_model_gpu as M
+        model, _ = M._build(torch.float32, train=True)
+        for m in model.modules():
+            if isinstance(m, (torch.nn.Dropout, torch.nn.Dropout2d)):
+                m.p = 0.0
+        return model
     if not naive:
         model, _ = T._build_hip("c5", torch.float32, True)
         return model
@@ -91,7 +111,7 @@ class _GlooComm:
             self.all_reduce(t, op)
 
 
-def _worker(rank, world, port, ret, naive=False, native=False):
+def _worker(rank, world, port, ret, naive=False, native=False, case="c5"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     import sys
@@ -99,7 +119,7 @@ def _worker(rank, world, port, ret, naive=False, native=False):
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        model = _build(naive)
+        model = _build(naive, case)
         if not naive:  # tools/train.py:76; the Naive modules synchronise by themselves
             model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
         from segmentron_amd import parallel
@@ -149,14 +169,15 @@ def _worker(rank, world, port, ret, naive=False, native=False):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("naive,native", [(False, False), (True, False), (False, True),
-                                          (False, "mailbox")],
+@pytest.mark.parametrize("naive,native,case", [(False, False, "c5"), (True, False, "c5"),
+                                               (False, True, "c5"), (False, "mailbox", "c5"),
+                                               (False, "mailbox", "c3")],
                          ids=["nn.SyncBatchNorm", "NaiveSyncBatchNorm", "native-exchange",
-                              "peer-mailbox"])
-def test_syncbn_ddp_two_ranks_match_full_batch(naive, native):
+                              "peer-mailbox", "peer-mailbox-xception"])
+def test_syncbn_ddp_two_ranks_match_full_batch(naive, native, case):
     world = 2
     # single-process full batch: plain BatchNorm (a lone NaiveSyncBatchNorm process IS plain BN)
-    model = _build(naive)
+    model = _build(naive, case)
     x, y = _data(world)
     out = model(x.cuda())
     loss = torch.nn.functional.cross_entropy(out[0], y.cuda())
@@ -174,12 +195,11 @@ def test_syncbn_ddp_two_ranks_match_full_batch(naive, native):
     mgr = ctx.Manager()
     ret = mgr.dict()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, ret, naive, native))
+    procs = [ctx.Process(target=_worker, args=(r, world, port, ret, naive, native, case))
              for r in range(world)]
     for p in procs:
         p.start()
-    for p in procs:
-        p.join(600)
+    _join_or_kill(procs, 300)
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     # forward: each rank's logits = its slice; mean of the rank losses = full-batch loss
     for r in range(world):
@@ -206,8 +226,14 @@ def test_syncbn_ddp_two_ranks_match_full_batch(naive, native):
     rels.sort()
     print("gradients vs full batch: global rel err %.3e, median per-tensor %.3e, worst %.3e"
           % ((num / den) ** 0.5, rels[len(rels) // 2], rels[-1]))
-    # (ReLU near-ties can move single tensors by percents — see test_more_models.py)
-    assert (num / den) ** 0.5 < 6e-2 and rels[len(rels) // 2] < 2e-3
+    # (ReLU near-ties can move single tensors by percents — see test_more_models.py; the
+    # random-init xception amplifies any fp32 summation-order difference to the level at which
+    # the fp32 step differs from the fp64 oracle, 1.6e-2 — profiles/r03_parity.txt — so there the
+    # bar only catches structural errors: a wrong scale or a missing term is O(1) on its tensor)
+    if case == "c3":
+        assert (num / den) ** 0.5 < 3e-2 and rels[-1] < 0.2
+    else:
+        assert (num / den) ** 0.5 < 6e-2 and rels[len(rels) // 2] < 2e-3
 
 
 def _mailbox_worker(rank, world, port, ret):
@@ -220,7 +246,7 @@ def _mailbox_worker(rank, world, port, ret):
         box = xgmi.PeerMailbox(rank, world)
         gens = [torch.Generator().manual_seed(77 + r) for r in range(world)]
         worst = 0.0
-        for n in (1, 3, 1457, 4097, 8192) * 6:  # 30 exchanges of every size class, back to back
+        for n in (1, 3, 1457, 4097, 16384) * 6:  # 30 exchanges of every size class, back to back
             xs = [torch.randn(n, dtype=torch.float64, generator=g) for g in gens]
             mine = xs[rank].cuda()
             box.all_reduce(mine)
@@ -256,7 +282,7 @@ def _mailbox_worker(rank, world, port, ret):
         box.check()
         # a message larger than a slot is refused on the host
         with pytest.raises(RuntimeError):
-            box.all_reduce(torch.zeros(8193, dtype=torch.float64, device="cuda"))
+            box.all_reduce(torch.zeros(box.slot_bytes // 8 + 1, dtype=torch.float64, device="cuda"))
         # float32 vectors (the folded layers' [ds, dt] sums) take the same route
         f = torch.full((1456,), 0.1 * (rank + 1), dtype=torch.float32, device="cuda")
         box.all_reduce(f)
@@ -284,8 +310,7 @@ def test_peer_mailbox_two_processes_exchange_through_hipipc_eager_and_in_a_graph
     procs = [ctx.Process(target=_mailbox_worker, args=(r, world, port, ret)) for r in range(world)]
     for p in procs:
         p.start()
-    for p in procs:
-        p.join(300)
+    _join_or_kill(procs, 200)
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     assert ret[0] == 0.0 and ret[1] == 0.0
 
