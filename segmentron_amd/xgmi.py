@@ -42,17 +42,26 @@ class PeerMailbox:
 
     def __init__(self, rank, world, slot_bytes=SLOT_BYTES, gather=None):
         self.rank, self.world, self.slot_bytes = int(rank), int(world), int(slot_bytes)
-        h = ctypes.c_void_p()
-        LIB.call("seg_p2p_create", self.rank, self.world, self.slot_bytes, ctypes.byref(h))
-        self._h = h
-        self.handle = h  # what the seg_*_sync entry points take
+        self._h = self.handle = ctypes.c_void_p()
+        err, mine = None, b""
         try:
-            mine = ctypes.create_string_buffer(_HANDLE_BYTES)
-            LIB.call("seg_p2p_ipc_handle", self._h, mine)
+            h = ctypes.c_void_p()
+            LIB.call("seg_p2p_create", self.rank, self.world, self.slot_bytes, ctypes.byref(h))
+            self._h = self.handle = h  # (`handle`: what the seg_*_sync entry points take)
+            buf = ctypes.create_string_buffer(_HANDLE_BYTES)
+            LIB.call("seg_p2p_ipc_handle", self._h, buf)
+            mine = buf.raw
+        except Exception as e:  # noqa: BLE001 — the handle exchange below is collective: a rank
+            err = e             # that failed still takes part (with an empty payload)
+        every = [mine]
+        if self.world > 1:
+            every = (gather or _gather_bytes_torch)(mine)
+        try:
+            if err is not None:
+                raise err
+            if len(every) != self.world or any(len(b) != _HANDLE_BYTES for b in every):
+                raise RuntimeError("xgmi.PeerMailbox: a peer has no mailbox to share")
             if self.world > 1:
-                every = (gather or _gather_bytes_torch)(mine.raw)
-                if len(every) != self.world or any(len(b) != _HANDLE_BYTES for b in every):
-                    raise RuntimeError("xgmi.PeerMailbox: handle exchange returned %r" % (every,))
                 LIB.call("seg_p2p_connect", self._h, ctypes.create_string_buffer(b"".join(every)))
         except Exception:
             self.destroy()

@@ -99,3 +99,50 @@ def test_syncbn_exchange_protocol_world_size_2():
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
     assert dict(ret) == {0: 1, 1: 1}
+
+
+def test_stats_exchange_routing_and_mailbox_lookup():
+    """Host logic of segmentron_amd/xgmi.py + parallel.mailbox() (no GPU): float64 / float32 sums
+    that fit a slot go to the mailbox, everything else — other ops, other dtypes, oversized
+    vectors, grouped gradient calls — to the wrapped communicator; `parallel.mailbox()` is what
+    switches functional.finish_bn to the in-kernel exchange."""
+    from segmentron_amd import parallel, xgmi
+    calls = []
+
+    class Box:
+        rank, world, slot_bytes = 0, 2, 64
+
+        def fits(self, t):
+            return t.dtype in (torch.float64, torch.float32) and \
+                0 < t.numel() * t.element_size() <= self.slot_bytes
+
+        def all_reduce(self, t):
+            calls.append(("box", t.dtype, t.numel()))
+            return t
+
+    class Comm:
+        def all_reduce(self, t, op="sum"):
+            calls.append(("comm", op, t.dtype, t.numel()))
+            return t
+
+        def all_reduce_many(self, ts, op="sum"):
+            calls.append(("comm-many", op, len(ts)))
+
+    ex = xgmi.StatsExchange(Box(), Comm())
+    ex.all_reduce(torch.zeros(8, dtype=torch.float64))
+    ex.all_reduce(torch.zeros(16, dtype=torch.float32))
+    ex.all_reduce(torch.zeros(9, dtype=torch.float64))           # 72 bytes > slot
+    ex.all_reduce(torch.zeros(4, dtype=torch.float64), "avg")    # not a sum
+    ex.all_reduce(torch.zeros(4, dtype=torch.bfloat16))
+    ex.all_reduce_many([torch.zeros(3), torch.zeros(5)], "avg")
+    assert calls == [("box", torch.float64, 8), ("box", torch.float32, 16),
+                     ("comm", "sum", torch.float64, 9), ("comm", "avg", torch.float64, 4),
+                     ("comm", "sum", torch.bfloat16, 4), ("comm-many", "avg", 2)]
+    assert parallel.mailbox() is None
+    prev = parallel.use_native_rccl(ex)
+    try:
+        assert parallel.mailbox() is ex.mailbox
+        parallel.use_native_rccl(Comm())
+        assert parallel.mailbox() is None  # a plain communicator: three-launch exchange path
+    finally:
+        parallel.use_native_rccl(prev)
