@@ -117,7 +117,9 @@ def connect(comm, rank, world, gather=None, rounds=4, log=sys.stderr):
     """-> StatsExchange(mailbox, comm) if the mailbox reproduces `comm.all_reduce` on this node,
     else `comm` itself (reason printed to `log`).  Collective: every rank calls it.  The check
     runs `rounds` exchanges of several sizes against the communicator, eagerly and from a
-    replayed HIP graph, and all ranks agree on the verdict through `comm`."""
+    replayed HIP graph, then the in-kernel exchange of a BatchNorm finalize (728 and 2048
+    channels, eager and replayed) against the same sums, and all ranks agree on the verdict
+    through `comm`."""
     box, why = None, None
     try:
         box = PeerMailbox(rank, world, gather=gather)
@@ -162,7 +164,46 @@ def connect(comm, rank, world, gather=None, rounds=4, log=sys.stderr):
         box.check()
     except Exception as e:
         why, bad = "%s: %s" % (type(e).__name__, e), 1.0
+    # ... and the exchange INSIDE a finalize kernel (p2p.h p2p_block_exchange: what the train step
+    # uses for every BatchNorm), 91 and 256 blocks, eager and replayed
+    fin_in = [(torch.randn(8, 2 * C, dtype=torch.float32, device=dev, generator=gen), C)
+              for C in (728, 2048)]  # (built outside the try: phase 2 walks this list on every rank)
+    fin_got = []
+    try:
+        from . import hip_ops as K
+        for part, C in fin_in:
+            ones, zeros = torch.ones(C, device=dev), torch.zeros(C, device=dev)
+            mean, _, _, _, cnt = K.bn_finalize_p_sync(box, part, 10.0 + rank, ones, zeros, 1e-5,
+                                                      0.1, None, None)
+            g2 = torch.cuda.CUDAGraph()
+            side2 = torch.cuda.Stream()
+            side2.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side2):
+                torch.cuda.synchronize()
+                with torch.cuda.graph(g2, stream=side2):
+                    mean_g, _, _, _, cnt_g = K.bn_finalize_p_sync(box, part, 10.0 + rank, ones,
+                                                                  zeros, 1e-5, 0.1, None, None)
+            torch.cuda.current_stream().wait_stream(side2)
+            g2.replay()
+            g2.replay()
+            torch.cuda.synchronize()  # (the graph object goes away with this loop iteration)
+            fin_got.append((mean, cnt, mean_g, cnt_g))
+        box.check()
+    except Exception as e:
+        why, bad = "%s: %s" % (type(e).__name__, e), 1.0
     # phase 2: the same sums through the communicator
+    for i, (part, C) in enumerate(fin_in):
+        sums = comm.all_reduce(part.double().sum(0), "sum")
+        cnt = comm.all_reduce(torch.tensor([10.0 + rank], dtype=torch.float64, device=dev), "sum")
+        if bad == 0.0 and i < len(fin_got):
+            want_mean = (sums[:C] / cnt).float()
+            mean, c1, mean_g, c2 = fin_got[i]
+            if not (torch.allclose(mean, want_mean, rtol=1e-5, atol=1e-6)
+                    and torch.allclose(mean_g, want_mean, rtol=1e-5, atol=1e-6)
+                    and float(c1) == float(cnt) and float(c2) == float(cnt)):
+                bad = 1.0
+        elif bad == 0.0:
+            bad = 1.0
     for i, x in enumerate(inputs):
         want = comm.all_reduce(x.clone(), "sum")
         tol = 1e-12 if x.dtype == torch.float64 else 1e-5
