@@ -117,7 +117,7 @@ def finish_bn(bn, partial, count, mean_offset=None):
         naive = parallel.is_naive_sync(bn)
         if naive:  # the reference's own SyncBN: biased running_var, no counter (batch_norm.py:174)
             rm = rv = None
-        box = parallel.mailbox()
+        box = parallel.mailbox(group)
         if box is not None:
             # column sums -> exchange (peer writes) -> finalize in ONE launch, like plain BN
             mean, invstd, scale, shift, cnt = K.bn_finalize_p_sync(
@@ -150,7 +150,7 @@ def flush_bn_counters():
 def _sync_bwd_finalize(partial, bn):
     """SyncBatchNorm backward sums [R, 2C] -> (dgamma, dbeta, c0, c1): inside the finalize kernel
     when the peer mailbox is active, else column sums -> all-reduce -> finalize."""
-    box = parallel.mailbox()
+    box = parallel.mailbox(bn.group)
     scale = parallel.grad_scale(bn.group)
     if box is not None and isinstance(bn.count, torch.Tensor):
         return K.bn_bwd_finalize_p_sync(box, partial, bn.count, bn.mean, bn.invstd, bn.gamma, scale)
@@ -377,7 +377,7 @@ class _FoldConvFn(torch.autograd.Function):
         if not s.drop_const:  # eval-mode consumer: the constant term carries gradient
             db = K.bn_bwd_reduce(dy, dy, (PRO_NONE, None, None))[:O].float()
         dW, dsdt = K.fold_bwd_reduce(weight.detach().view(O, C), dwp, bn.scale, bn.shift, db)
-        box = parallel.mailbox() if bn.group is not None else None
+        box = parallel.mailbox(bn.group) if bn.group is not None else None
         if box is not None and isinstance(bn.count, torch.Tensor):
             dgamma, dbeta, c0, c1 = K.fold_bwd_finalize_sync(
                 box, dsdt, bn.count, bn.mean, bn.invstd, bn.gamma, bn.scale,
@@ -440,7 +440,7 @@ class _DwFn(torch.autograd.Function):
             bn = s.bn_in
             # single-process BatchNorm on the input: the weight-gradient partials and the
             # BatchNorm-backward partials are reduced by ONE launch (K.dw_bwd_finalize)
-            box = parallel.mailbox() if (bn is not None and bn.group is not None) else None
+            box = parallel.mailbox(bn.group) if (bn is not None and bn.group is not None) else None
             both = bn is not None and (strided or tiled) and \
                 (bn.group is None or (box is not None and isinstance(bn.count, torch.Tensor)))
             if strided:

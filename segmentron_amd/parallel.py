@@ -35,11 +35,17 @@ def native_rccl():
     return _NATIVE[0]
 
 
-def mailbox():
+def mailbox(group=None):
     """The xGMI peer mailbox of the active exchange (xgmi.StatsExchange), or None: with it the
     BatchNorm finalize kernels exchange their sums themselves (hip_ops.*_sync) and a SyncBatchNorm
-    costs the same one launch per direction as a plain BatchNorm."""
-    return getattr(_NATIVE[0], "mailbox", None)
+    costs the same one launch per direction as a plain BatchNorm.  The mailbox spans the ranks it
+    was connected over (the default group): a BatchNorm that synchronises over a SUBGROUP
+    (nn.SyncBatchNorm(process_group=...)) keeps the all-reduce path."""
+    box = getattr(_NATIVE[0], "mailbox", None)
+    if box is not None and group is not None and dist.is_initialized() \
+            and dist.get_world_size(group) != box.world:
+        return None
+    return box
 
 
 def _all_reduce(t, group):
