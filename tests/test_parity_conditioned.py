@@ -1,0 +1,393 @@
+"""End-to-end parity on the WELL-CONDITIONED fixtures (tests/golden/<tag>_cond.npz, generated from
+the reference by oracle/gen_golden_cond.py; `oracle.synth(conditioned=True)`), with FIXED bars —
+also for the bf16 throughput path that bench.py measures.
+
+On the default synth state a random 70-layer ReLU+BatchNorm chain is a chaotic map (CPU fp32
+gradients 1.7e-2 from fp64, bf16 gradients decorrelated), so the whole-model tests in
+test_model_gpu.py / test_more_models.py can only bound the HIP error relative to the CPU's own.
+Here the generator asserted the conditioning (CPU fp32 vs fp64: logits <= 1e-5, gradients
+<= 1.5e-4 global) before writing, so the bars below are absolute:
+
+  fp32 path   eval / train logits max-rel <= 1e-3 of the reference fixture, arg-max masks identical
+              (up to oracle top-2 ties, counted and printed), loss 1e-3, running statistics 1e-3,
+              gradients <= 1e-3 global-rel of the fp64 oracle, every tensor <= 1e-2 of its norm
+              (+ 1e-5 of the global norm for the analytically-zero ones);
+  bf16 path   vs the fp32 fixture / fp64 oracle, yardstick = the REFERENCE ITSELF under torch's
+              CPU bf16 autocast on the same state and input (stored in the fixture:
+              `ref_autocast_bf16`): logits L2-rel <= max(2e-2, 1.5 x reference-autocast), arg-max
+              agreement >= reference-autocast - 0.03, loss 1e-2, global gradient cosine >=
+              min(0.99, reference-autocast) - 0.03, norm ratio within 10 %;
+  bf16 tight  (C3) gradients vs torch autograd of oracle/bf16_emulation.py — the bf16 forward
+              with the kernels' rounding points and EXACT backward arithmetic: same ReLU masks and
+              BatchNorm statistics, so only the bf16 storage of the gradient tensors differs:
+              global cosine >= 0.999, global rel <= 5e-2, every tensor that carries >= 1e-4 of the
+              gradient energy cosine >= 0.99 and norm ratio within 5 %;
+  graph       the same C3 bf16 step through GraphedTrainStep + FusedSGD, one eager step + 3 replays,
+              against 4 SGD steps of the fp64 oracle (loss 5.30 -> 4.54 -> 4.17 -> 3.87): losses 2e-2,
+              weight-update cosine >= 0.9 — the bf16 gradient's own cosine to fp64 is ~0.93 on this
+              net (reference autocast: 0.92) — a stale weight pack or a gradient that is not
+              re-accumulated inside the graph leaves the loss flat and fails this.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import C3_OVERRIDES, GOLDEN
+from oracle import synth, torch_ref
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CASES = {
+    "c3": dict(fn="deeplabv3_plus_xception65", hw=(65, 129), os=16, aux=False, eps_enc=1e-3),
+    "c2": dict(model="DeepLabV3_Plus", backbone="mobilenet_v2", os=16, aux=False,
+               fn="deeplab_mobilenet", hw=(65, 97),
+               over=["MODEL.DEEPLABV3_PLUS.USE_ASPP", "False",
+                     "MODEL.DEEPLABV3_PLUS.ENABLE_DECODER", "False"]),
+    "c4": dict(model="PSPNet", backbone="resnet101", os=8, aux=True, fn="pspnet_resnet",
+               hw=(49, 65)),
+    "c5": dict(model="HRNet", backbone="hrnet_w18_small_v1", os=16, aux=False, fn="hrnet_seg",
+               hw=(64, 128), momentum=0.01, yaml="configs/cityscapes_hrnet_w18_small_v1.yaml"),
+}
+AUX_WEIGHT = 0.4
+
+
+def _fixture(tag):
+    return np.load(os.path.join(GOLDEN, tag + "_cond.npz"))
+
+
+def _state(tag):
+    keys = json.load(open(os.path.join(GOLDEN, tag + "_state_keys.json")))["keys"]
+    sd = synth.synth_state_dict([(k, tuple(s)) for k, s in keys], seed=0, conditioned=True)
+    g = _fixture(tag)
+    for k in g.files:
+        if k.startswith("calib::"):
+            sd[k[7:]] = torch.from_numpy(g[k])
+    for k in sd:
+        if k.endswith("num_batches_tracked"):
+            sd[k] = torch.zeros((), dtype=torch.long)
+    return sd
+
+
+def _oracle(tag, sd, x, y=None, dtype=torch.float32, training=True):
+    c = CASES[tag]
+    s = {k: (v.to(dtype) if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+    s = torch_ref.clone_state(s, requires_grad=training)
+    net = torch_ref.OracleNet(s, training=training, output_stride=c["os"], aux=c["aux"],
+                              eps_encoder=c.get("eps_enc"), drop_p=0.0, momentum=c.get("momentum"))
+    outs = getattr(net, c["fn"])(x.to(dtype))
+    if not training:
+        return outs, None, None, s
+    loss = torch_ref.mix_softmax_ce(outs, y, aux_weight=AUX_WEIGHT)
+    loss.backward()
+    return outs, loss.item(), {k: v.grad for k, v in s.items() if v.grad is not None}, s
+
+
+def _l2(a, b):
+    return ((a.double() - b.double()).norm() / b.double().norm()).item()
+
+
+def _maxrel(a, b):
+    return ((a.double() - b.double()).abs().max() / b.double().abs().max()).item()
+
+
+# ----------------------------------------------------------------------------- CPU: the fixture
+@pytest.mark.parametrize("tag", list(CASES))
+def test_conditioned_fixture_is_reproduced_by_the_oracle_and_is_conditioned(tag):
+    g = _fixture(tag)
+    c3, c4, c5, c6 = g["conditioning"]
+    assert c3 <= 1e-5 and c4 <= 1.5e-4 and c5 <= 1e-2 and c6 <= 0.1, g["conditioning"]
+    sd = _state(tag)
+    H, W = CASES[tag]["hw"]
+    x = synth.synth_images(2, H, W, seed=0)
+    y = synth.synth_targets(2, H, W, seed=0)
+    with torch.no_grad():
+        outs = _oracle(tag, sd, x, training=False)[0]
+    assert torch.allclose(outs[0], torch.from_numpy(g["eval_logits"]), rtol=1e-4, atol=1e-4)
+    outs, loss, grads, _ = _oracle(tag, sd, x, y)
+    assert abs(loss - float(g["loss"])) < 1e-5
+    assert torch.allclose(outs[0].detach(), torch.from_numpy(g["train_logits"]), rtol=1e-4, atol=1e-4)
+    for k, n in zip([str(k) for k in g["grad_norm_keys"]], g["grad_norms"]):
+        assert abs(float(grads[k].double().norm()) - n) <= 1e-3 * max(n, 1e-6) + 1e-9, k
+
+
+def test_conditioned_state_only_touches_batchnorm_affine_parameters():
+    keys = json.load(open(os.path.join(GOLDEN, "c3_state_keys.json")))["keys"]
+    a = synth.synth_state_dict([(k, tuple(s)) for k, s in keys], seed=0)
+    b = synth.synth_state_dict([(k, tuple(s)) for k, s in keys], seed=0, conditioned=True)
+    changed = [k for k in a if not torch.equal(a[k], b[k])]
+    assert changed and all((k[:k.rfind(".")] + ".running_mean") in a for k in changed)
+    last = [k for k in changed if synth.branch_last_bn(k, set(a))]
+    assert len(last) == 20 and all(k.endswith("sep_conv3.block.bn_point.weight") for k in last)
+    assert all(0.1 <= b[k].min() and b[k].max() <= 0.2 for k in last)
+
+
+# ----------------------------------------------------------------------------- GPU
+def _build_hip(tag, dtype, train):
+    import segmentron_amd
+    from segmentron_amd.config import cfg, reset_cfg
+    c = CASES[tag]
+    reset_cfg()
+    if tag == "c3":
+        cfg.update_from_list(C3_OVERRIDES)
+    else:
+        if "yaml" in c:
+            cfg.update_from_file(os.path.join(ROOT, c["yaml"]))
+        cfg.update_from_list(["DATASET.NAME", "cityscape", "MODEL.MODEL_NAME", c["model"],
+                              "MODEL.BACKBONE", c["backbone"], "MODEL.OUTPUT_STRIDE", str(c["os"]),
+                              "SOLVER.AUX", str(c["aux"]), "SOLVER.AUX_WEIGHT", str(AUX_WEIGHT),
+                              "TRAIN.BACKBONE_PRETRAINED", "False"] + c.get("over", []))
+    cfg.PHASE = "test"
+    cfg.check_and_freeze()
+    segmentron_amd.set_compute_dtype(dtype)
+    model = segmentron_amd.get_segmentation_model()
+    sd = _state(tag)
+    model.load_state_dict(sd, strict=True)
+    if tag == "c3":  # solver/optimizer.py:18-20
+        for _, m in model.encoder.named_modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.eps = 1e-3
+    model = model.cuda().train(train)
+    for m in model.modules():
+        if isinstance(m, (torch.nn.Dropout, torch.nn.Dropout2d)):
+            m.p = 0.0
+        if isinstance(m, torch.nn.BatchNorm2d) and c.get("momentum") is not None:
+            m.momentum = c["momentum"]
+    return model, sd
+
+
+def _hip_step(model, x, y):
+    ce = torch.nn.functional.cross_entropy
+    outs = model(x.cuda())
+    loss = ce(outs[0], y.cuda(), ignore_index=-1)
+    for o in outs[1:]:
+        loss = loss + AUX_WEIGHT * ce(o, y.cuda(), ignore_index=-1)
+    loss.backward()
+    return outs, loss
+
+
+def _grad_stats(params, ref):
+    """-> dict(global_rel, cos, ratio), [(rel, cos, ratio, share, key)] per tensor."""
+    num = den = dot = na = 0.0
+    per = []
+    for k, t in ref.items():
+        assert params[k].grad is not None, k
+        a = params[k].grad.detach().cpu().double()
+        assert torch.isfinite(a).all(), k
+        t = t.double()
+        e, n, m = (a - t).norm().item(), t.norm().item(), a.norm().item()
+        d = (a * t).sum().item()
+        num, den, dot, na = num + e * e, den + n * n, dot + d, na + m * m
+        per.append([e, d / max(m * n, 1e-300), m / max(n, 1e-300), n, k])
+    for p in per:
+        p[3] = p[3] ** 2 / den
+    return dict(global_rel=(num / den) ** 0.5, cos=dot / (na * den) ** 0.5,
+                ratio=(na / den) ** 0.5, norm=den ** 0.5), per
+
+
+def _count_ties(got, ref, what):
+    """arg-max masks identical except where the reference's own top-2 margin is below the 1e-3
+    bar of the logits themselves; returns the number of such tie pixels (printed by callers)."""
+    bad = got.argmax(1) != ref.argmax(1)
+    n = int(bad.sum())
+    if n:
+        top2 = ref.topk(2, dim=1).values
+        gap = (top2[:, 0] - top2[:, 1])[bad]
+        assert gap.max().item() < 1e-3 * ref.abs().max().item(), (what, n, gap.max().item())
+    return n
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", list(CASES))
+def test_fp32_eval_and_train_step_fixed_bars(tag):
+    g = _fixture(tag)
+    H, W = CASES[tag]["hw"]
+    x = synth.synth_images(2, H, W, seed=0)
+    y = synth.synth_targets(2, H, W, seed=0)
+    model, sd = _build_hip(tag, torch.float32, False)
+    with torch.no_grad():
+        got = model(x.cuda())[0].cpu()
+    ref = torch.from_numpy(g["eval_logits"])
+    rel = _maxrel(got, ref)
+    ties = _count_ties(got, ref, tag + " eval")
+    assert rel < 1e-3
+    model.train()
+    outs, loss = _hip_step(model, x, y)
+    rel_t = _maxrel(outs[0].detach().cpu(), torch.from_numpy(g["train_logits"]))
+    assert abs(loss.item() - float(g["loss"])) < 1e-3 * float(g["loss"]) and rel_t < 1e-3
+    msd = model.state_dict()
+    for k in g.files:
+        if k.startswith("stat::"):
+            r = torch.from_numpy(g[k])
+            assert (msd[k[6:]].cpu() - r).abs().max().item() <= 1e-3 * r.abs().max().item() + 1e-6, k
+    _, l64, g64, _ = _oracle(tag, sd, x, y, torch.float64)
+    st, per = _grad_stats(dict(model.named_parameters()), g64)
+    worst = max(per, key=lambda p: p[0] / (1e-2 * (p[3] ** 0.5) * st["norm"] + 1e-5 * st["norm"]))
+    print("PARITY-COND %s fp32: eval max-rel %.2e (%d tie pixels), train logits %.2e, loss %.6f vs "
+          "%.6f | gradients vs fp64 oracle: global rel %.2e cosine %.6f; worst tensor %s rel %.2e"
+          % (tag, rel, ties, rel_t, loss.item(), float(g["loss"]), st["global_rel"], st["cos"],
+             worst[4], worst[0] / max(worst[3] ** 0.5 * st["norm"], 1e-300)))
+    assert st["global_rel"] <= 1e-3
+    for e, cos, ratio, share, k in per:
+        assert e <= 1e-2 * share ** 0.5 * st["norm"] + 1e-5 * st["norm"], (k, e, share)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", list(CASES))
+def test_bf16_eval_and_train_step_vs_oracle_with_the_reference_autocast_yardstick(tag):
+    g = _fixture(tag)
+    ac_eval, ac_argmax, ac_train, ac_loss, ac_cos, ac_ratio = g["ref_autocast_bf16"]
+    H, W = CASES[tag]["hw"]
+    x = synth.synth_images(2, H, W, seed=0)
+    y = synth.synth_targets(2, H, W, seed=0)
+    model, sd = _build_hip(tag, torch.bfloat16, False)
+    with torch.no_grad():
+        got = model(x.cuda())[0].float().cpu()
+    ref = torch.from_numpy(g["eval_logits"])
+    l2e = _l2(got, ref)
+    agree = (got.argmax(1) == ref.argmax(1)).float().mean().item()
+    model.train()
+    outs, loss = _hip_step(model, x, y)
+    _, l64, g64, _ = _oracle(tag, sd, x, y, torch.float64)
+    l2t = _l2(outs[0].detach().float().cpu(), torch.from_numpy(g["train_logits"]))
+    st, per = _grad_stats(dict(model.named_parameters()), g64)
+    print("PARITY-COND %s bf16 vs fp32 fixture / fp64 oracle: eval logits L2-rel %.3e argmax %.4f | "
+          "train logits %.3e loss %.5f vs %.5f | gradients global rel %.3e cosine %.5f norm ratio "
+          "%.4f || reference under CPU bf16 autocast: eval %.3e argmax %.4f train %.3e cosine %.5f"
+          % (tag, l2e, agree, l2t, loss.item(), l64, st["global_rel"], st["cos"], st["ratio"],
+             ac_eval, ac_argmax, ac_train, ac_cos))
+    assert l2e <= max(2e-2, 1.5 * ac_eval) and l2t <= max(2e-2, 1.5 * ac_train)
+    assert agree >= ac_argmax - 0.03
+    assert abs(loss.item() - l64) <= 1e-2 * l64
+    assert st["cos"] >= min(0.99, ac_cos) - 0.03
+    assert abs(st["ratio"] - 1.0) <= 0.10
+
+
+def _emulation_grads(sd, x, y):
+    from oracle.bf16_emulation import Bf16EmuNet
+    s = torch_ref.clone_state(sd, requires_grad=True)
+    net = Bf16EmuNet(s, training=True, accum64=True)
+    out = net.forward(x)
+    loss = torch.nn.functional.cross_entropy(out, y, ignore_index=-1)
+    loss.backward()
+    return out.detach(), loss.item(), {k: v.grad for k, v in s.items()
+                                       if v.is_leaf and v.grad is not None}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hw", [(65, 129), (257, 513)])
+def test_c3_bf16_gradients_match_autograd_of_the_bf16_emulation(hw):
+    """The tight bf16 check: same rounding points in forward (so the same ReLU masks and
+    BatchNorm statistics), exact arithmetic in the emulation's backward."""
+    H, W = hw
+    x = synth.synth_images(2, H, W, seed=0)
+    y = synth.synth_targets(2, H, W, seed=0)
+    model, sd = _build_hip("c3", torch.bfloat16, True)
+    outs, loss = _hip_step(model, x, y)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    eo, el, eg = _emulation_grads(sd, x, y)
+    l2f = _l2(outs[0].detach().float().cpu(), eo)
+    st, per = _grad_stats(dict(model.named_parameters()), eg)
+    heavy = [p for p in per if p[3] >= 1e-4]
+    wc = min(heavy, key=lambda p: p[1])
+    wr = max(heavy, key=lambda p: abs(p[2] - 1.0))
+    print("PARITY-COND c3 bf16 %dx%d vs bf16-emulation autograd: forward L2-rel %.3e, loss %.5f vs "
+          "%.5f | gradients global rel %.3e cosine %.6f ratio %.4f; %d tensors >= 1e-4 of the "
+          "energy: worst cosine %.5f (%s), worst ratio %.4f (%s)"
+          % (H, W, l2f, loss.item(), el, st["global_rel"], st["cos"], st["ratio"], len(heavy),
+             wc[1], wc[4], wr[2], wr[4]))
+    assert l2f <= 1e-2 and abs(loss.item() - el) <= 2e-3 * el
+    assert st["cos"] >= 0.999 and st["global_rel"] <= 5e-2
+    assert wc[1] >= 0.99, wc
+    assert abs(wr[2] - 1.0) <= 0.05, wr
+
+
+@pytest.mark.gpu
+def test_c3_fp32_and_bf16_train_step_513x1025_fixed_bars():
+    """The smallest C3 geometry whose middle flow (2 x 33 x 65 = 4290 pixels) runs the 256-wide
+    direct-to-LDS GEMMs in forward, data gradient and split weight gradient."""
+    H, W = 513, 1025
+    x = synth.synth_images(2, H, W, seed=12)
+    y = synth.synth_targets(2, H, W, seed=12)
+    sd = _state("c3")
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    o64, l64, g64, _ = _oracle("c3", sd, x, y, torch.float64)
+    ref = o64[0].detach()
+    model, _ = _build_hip("c3", torch.float32, True)
+    outs, loss = _hip_step(model, x, y)
+    rel = _maxrel(outs[0].detach().cpu(), ref)
+    st, per = _grad_stats(dict(model.named_parameters()), g64)
+    print("PARITY-COND c3 fp32 513x1025: logits max-rel %.2e loss %.6f vs %.6f | gradients vs fp64 "
+          "oracle: global rel %.2e cosine %.7f" % (rel, loss.item(), l64, st["global_rel"], st["cos"]))
+    assert rel < 1e-3 and abs(loss.item() - l64) < 1e-3 * l64
+    assert st["global_rel"] <= 1e-3
+    del model, outs, loss
+    model, _ = _build_hip("c3", torch.bfloat16, True)
+    outs, loss = _hip_step(model, x, y)
+    l2t = _l2(outs[0].detach().float().cpu(), ref)
+    agree = (outs[0].detach().cpu().argmax(1) == ref.argmax(1)).float().mean().item()
+    st, per = _grad_stats(dict(model.named_parameters()), g64)
+    ac = _fixture("c3")["ref_autocast_bf16"]
+    print("PARITY-COND c3 bf16 513x1025 vs fp64 oracle: logits L2-rel %.3e argmax %.4f loss %.5f vs "
+          "%.5f | gradients global rel %.3e cosine %.5f ratio %.4f"
+          % (l2t, agree, loss.item(), l64, st["global_rel"], st["cos"], st["ratio"]))
+    assert l2t <= max(2e-2, 1.5 * ac[2]) and agree >= ac[1] - 0.03
+    assert abs(loss.item() - l64) <= 1e-2 * l64
+    assert st["cos"] >= min(0.99, ac[4]) - 0.03 and abs(st["ratio"] - 1.0) <= 0.10
+
+
+def _oracle_sgd_steps(sd, x, y, steps, lr, momentum, wd):
+    """`steps` iterations of tools/train.py:135-146 in float64 on the oracle (torch.optim.SGD
+    semantics: g += wd*w; buf = g | momentum*buf + g; w -= lr*buf)."""
+    state = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+    bufs, losses = {}, []
+    for _ in range(steps):
+        outs, loss, grads, s = _oracle("c3", state, x, y, torch.float64)
+        losses.append(loss)
+        nxt = {k: v.detach().clone() for k, v in s.items()}  # running statistics were updated
+        for k, gk in grads.items():
+            gk = gk + wd * s[k].detach()
+            bufs[k] = gk.clone() if k not in bufs else momentum * bufs[k] + gk
+            nxt[k] = s[k].detach() - lr * bufs[k]
+        state = nxt
+    return losses, state
+
+
+@pytest.mark.gpu
+def test_c3_bf16_graphed_train_steps_follow_the_oracle_trajectory():
+    """GraphedTrainStep (forward + loss + backward + FusedSGD in ONE HIP graph), three replays,
+    against three float64 SGD steps of the oracle from the same state.  lr is large enough that
+    the loss moves by several percent per step: a weight pack that is not refreshed inside the
+    graph, or a gradient that is not re-accumulated, leaves the loss flat."""
+    from segmentron_amd.graph import GraphedTrainStep
+    from segmentron_amd.solver.optimizer import FusedSGD
+    H, W = 65, 129
+    lr, mom, wd = 0.005, 0.9, 1e-4  # fp64 oracle: loss 5.30 -> 4.54 -> 4.17 -> 3.87
+    x = synth.synth_images(2, H, W, seed=0)
+    y = synth.synth_targets(2, H, W, seed=0)
+    model, sd = _build_hip("c3", torch.bfloat16, True)
+    w0 = {k: p.detach().cpu().double().clone() for k, p in model.named_parameters()}
+    opt = FusedSGD(model.parameters(), lr=lr, momentum=mom, weight_decay=wd)
+    ce = torch.nn.functional.cross_entropy
+    # warmup=1: ONE real eager step first (it creates the momentum buffers, which must exist
+    # before the capture); the capture itself does not execute, every replay is one real step
+    step = GraphedTrainStep(model, opt, x.cuda(), y.cuda(),
+                            lambda out, t: ce(out[0], t, ignore_index=-1), warmup=1)
+    got = [step().item() for _ in range(3)]
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    want, state = _oracle_sgd_steps(sd, x, y, 4, lr, mom, wd)
+    want = want[1:]
+    dot = na = nb = 0.0
+    for k, p in model.named_parameters():
+        a = p.detach().cpu().double() - w0[k]
+        b = state[k] - w0[k]
+        dot, na, nb = dot + (a * b).sum().item(), na + a.norm().item() ** 2, nb + b.norm().item() ** 2
+    cos = dot / (na * nb) ** 0.5
+    print("PARITY-COND c3 bf16 graphed steps: losses %s vs fp64 oracle %s; weight-update cosine %.5f "
+          "norm ratio %.4f" % (["%.4f" % v for v in got], ["%.4f" % v for v in want], cos,
+                               (na / nb) ** 0.5))
+    assert abs(want[0] - want[2]) > 0.03 * want[0], "lr too small for the check to bite"
+    for a, b in zip(got, want):
+        assert abs(a - b) <= 2e-2 * b, (got, want)
+    assert cos >= 0.9 and abs((na / nb) ** 0.5 - 1.0) <= 0.10
