@@ -420,7 +420,8 @@ def main():
         try:  # segmentron_amd/graph.py: eager warm-up on a side stream, then ONE capture
             if train:
                 graph = SG.GraphedTrainStep(model, opt, images, targets, loss_fn,
-                                            post_backward=post_backward)
+                                            post_backward=post_backward,
+                                            check=getattr(comm, "check", None))
             else:
                 graph = SG.GraphedInference(model, images)
         except Exception as e:  # noqa: BLE001
@@ -505,8 +506,9 @@ def main():
         step()
     torch.cuda.synchronize()
     timer.active = False
-    if os.environ.get("SEG_BENCH_HOST_PROFILE") == "1" and rank == 0:
-        # where the host time of an eager step goes (stderr; diagnostics for the N > 1 path)
+    if os.environ.get("SEG_BENCH_HOST_PROFILE") == "1":
+        # where the host time of an eager step goes (stderr; diagnostics for the N > 1 path).
+        # EVERY rank runs the extra steps (they issue collectives); rank 0 prints.
         import cProfile
         import pstats
         pr = cProfile.Profile()
@@ -515,7 +517,8 @@ def main():
             step()
         torch.cuda.synchronize()
         pr.disable()
-        pstats.Stats(pr, stream=sys.stderr).sort_stats("tottime").print_stats(25)
+        if rank == 0:
+            pstats.Stats(pr, stream=sys.stderr).sort_stats("tottime").print_stats(25)
     # one EAGER step under the profiler (roctracer does not see the nodes of a replayed graph):
     # sum of its kernel durations / the timed ms_per_step -> gpu_busy_frac
     if rank == 0 and world == 1:

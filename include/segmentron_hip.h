@@ -348,14 +348,17 @@ int seg_cca_map(int dtype, const float* wt, const void* b, long ldb, int N, int 
  *   seg_p2p_all_reduce_f64 / _f32: buf[n] <- sum over ranks (added in rank order: bit-identical
  *                          on every rank), on `stream` (capturable); every rank must issue the
  *                          same sequence of calls
- *   seg_p2p_status       : synchronises; 3 = a peer failed to publish within 30 s (the kernel
- *                          stops waiting instead of hanging)                                    */
+ *   seg_p2p_status       : synchronises; 3 = a peer failed to publish within the time limit (the
+ *                          kernel stops waiting instead of hanging, and this and every later
+ *                          exchange returns NaN — the error word is never reset)
+ *   seg_p2p_set_timeout  : bound of one in-kernel wait in seconds (default 600)                 */
 int seg_p2p_create(int rank, int world, long slot_bytes, void** handle_out);
 int seg_p2p_ipc_handle(void* handle, void* out64);
 int seg_p2p_connect(void* handle, const void* handles);
 int seg_p2p_all_reduce_f64(void* handle, void* buf, int n, void* stream);
 int seg_p2p_all_reduce_f32(void* handle, void* buf, int n, void* stream);
 int seg_p2p_status(void* handle);
+int seg_p2p_set_timeout(void* handle, double seconds);
 int seg_p2p_destroy(void* handle);
 /* The BatchNorm finalize steps with the exchange INSIDE the kernel (column sums of this rank's
  * partial rows -> peer writes -> finalize): a SyncBatchNorm then costs the same single launch per

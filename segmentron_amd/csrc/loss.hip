@@ -373,7 +373,10 @@ extern "C" int seg_upsample_ce_bwd(int dtype, const void* lo, long ld, int N, in
   using namespace seg;
   SEG_REQUIRE(dtype == DT_F32 || dtype == DT_BF16, "upsample_ce_bwd: bad dtype %d", dtype);
   const int vec = dtype == DT_BF16 ? 8 : 4;
-  SEG_REQUIRE(C >= 1 && C <= 32 && ld % vec == 0 && lddlo >= C, "upsample_ce_bwd: bad C / pitch");
+  // the per-thread accumulators of ce_bwd_kernel cover LT*LT*32 items: a wider pitch would leave
+  // part of the gradient tile unwritten
+  SEG_REQUIRE(C >= 1 && C <= 32 && ld % vec == 0 && lddlo >= C && lddlo <= 32,
+              "upsample_ce_bwd: bad C / pitch (1 <= C <= lddlo <= 32)");
   SEG_REQUIRE(H >= Hi && W >= Wi, "upsample_ce_bwd: the fused loss is for UP-sampling heads");
   // a low-res tile row is touched by at most HT_MAX output rows / columns up to 4.1x
   const float sh = host_scale(Hi, H, align_corners), sw = host_scale(Wi, W, align_corners);

@@ -16,7 +16,11 @@ namespace seg {
 constexpr int P2P_MAX_WORLD = 16;
 constexpr int P2P_MAX_BLOCKS = 512;
 constexpr int P2P_FLAG_STRIDE = 16;  // u64 per flag of the single-block kernel: one line each
-constexpr unsigned long long P2P_TIMEOUT_TICKS = 30ull * 100000000ull;  // 30 s at 100 MHz
+// default bound of one wait: 600 s of the constant 100 MHz clock (NCCL's own watchdog default is
+// minutes too: a rank that saves a checkpoint, or stalls in its data loader, must not trip it);
+// seg_p2p_set_timeout changes it per mailbox
+constexpr unsigned long long P2P_TICKS_PER_S = 100000000ull;
+constexpr unsigned long long P2P_TIMEOUT_TICKS = 600ull * P2P_TICKS_PER_S;
 
 struct P2PState {
   int rank, world;
@@ -26,7 +30,8 @@ struct P2PState {
   bool opened[P2P_MAX_WORLD];
   unsigned long long* seq;              // device: exchanges completed
   unsigned int* arrive;                 // device: blocks of the running exchange that are done
-  int* err;                             // device: 0 ok, 1 timed out
+  int* err;                             // device: 0 ok, 1 timed out (latched: never reset)
+  unsigned long long timeout_ticks;     // bound of one wait (seg_p2p_set_timeout)
 };
 
 // What a kernel gets (by value).  world == 0: no exchange (single-process BatchNorm).
@@ -35,6 +40,7 @@ struct P2PDev {
   unsigned long long* seq;
   unsigned int* arrive;
   int* err;
+  unsigned long long timeout_ticks;
   long slot_bytes;
   int rank, world;
 };
@@ -43,7 +49,7 @@ inline P2PDev p2p_dev_none() {
   P2PDev d;
   for (int r = 0; r < P2P_MAX_WORLD; ++r) d.peer[r] = nullptr;
   d.seq = nullptr; d.arrive = nullptr; d.err = nullptr;
-  d.slot_bytes = 0; d.rank = 0; d.world = 0;
+  d.slot_bytes = 0; d.rank = 0; d.world = 0; d.timeout_ticks = P2P_TIMEOUT_TICKS;
   return d;
 }
 
@@ -58,6 +64,7 @@ inline bool p2p_dev_of(void* handle, P2PDev& d) {
   }
   d.seq = s->seq; d.arrive = s->arrive; d.err = s->err;
   d.slot_bytes = s->slot_bytes; d.rank = s->rank; d.world = s->world;
+  d.timeout_ticks = s->timeout_ticks;
   return true;
 }
 
@@ -83,23 +90,50 @@ __device__ __forceinline__ unsigned long long* p2p_block_flags(unsigned char* bo
 // __threadfence_system() / release-acquire atomics would add an L2 write-back (buffer_wbl2) of
 // whatever the train step left dirty and an invalidate per poll: measured r03, 91 blocks each
 // doing that turned a 5 us finalize kernel into an 18 us one.
+//
+// -DSEG_P2P_STRICT (make P2P_STRICT=1) builds the by-the-book protocol instead: system-scope
+// release fence before a RELEASE flag store, ACQUIRE flag loads + system-scope acquire fence
+// behind the wait.  Same mailbox layout, same results on one device; kept so that the day a
+// multi-GPU node exists the fast and the safe ordering can be A/B'd from one source tree
+// (SEGMENTRON_HIP_LIB selects the build).
+#ifdef SEG_P2P_STRICT
+#define P2P_FLAG_STORE_ORDER __ATOMIC_RELEASE
+#define P2P_FLAG_LOAD_ORDER __ATOMIC_ACQUIRE
+__device__ __forceinline__ void p2p_stores_done() { __threadfence_system(); }
+__device__ __forceinline__ void p2p_waited() { __threadfence_system(); }
+#else
+#define P2P_FLAG_STORE_ORDER __ATOMIC_RELAXED
+#define P2P_FLAG_LOAD_ORDER __ATOMIC_RELAXED
 __device__ __forceinline__ void p2p_stores_done() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
+__device__ __forceinline__ void p2p_waited() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+#endif
 
-// spin (bounded) until *flag >= seq; on a timeout the error word is raised
+// spin (bounded) until *flag >= seq; on a timeout the error word is raised (and stays raised:
+// every later exchange of this mailbox skips its waits and POISONS its result, see p2p_failed)
 __device__ __forceinline__ void p2p_wait(const unsigned long long* flag, unsigned long long seq,
-                                         int* err) {
+                                         int* err, unsigned long long timeout_ticks) {
   const unsigned long long t0 = wall_clock64();
-  while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+  while (__hip_atomic_load(flag, P2P_FLAG_LOAD_ORDER, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
     __builtin_amdgcn_s_sleep(2);
-    if (wall_clock64() - t0 > P2P_TIMEOUT_TICKS) {
+    if (wall_clock64() - t0 > timeout_ticks) {
       atomicExch(err, 1);
       break;
     }
   }
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  p2p_waited();
+}
+
+// A wait of THIS exchange (or of an earlier one) timed out: the slots may hold stale data.  The
+// callers then return NaN instead of a plausible-looking wrong sum, so that the statistics, the
+// loss and every gradient of the step turn NaN — a stalled peer fails the step visibly even if
+// nobody calls seg_p2p_status.
+__device__ __forceinline__ bool p2p_failed(const int* err) {
+  return __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
 }
 
 // The exchange of one block of a multi-block kernel: block `b` of `nblocks` (the same launch
@@ -135,13 +169,16 @@ __device__ __forceinline__ void p2p_block_exchange(const P2PDev& p, int b, int n
   if (tid < p.world) {
     __hip_atomic_store(p2p_block_flags(p.peer[tid], p.world, p.slot_bytes) +
                            (long)p.rank * P2P_MAX_BLOCKS + b,
-                       seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                       seq, P2P_FLAG_STORE_ORDER, __HIP_MEMORY_SCOPE_SYSTEM);
     if (!s_bad)
       p2p_wait(p2p_block_flags(p.peer[p.rank], p.world, p.slot_bytes) +
-                   (long)tid * P2P_MAX_BLOCKS + b, seq, p.err);
+                   (long)tid * P2P_MAX_BLOCKS + b, seq, p.err, p.timeout_ticks);
   }
   __syncthreads();
-  if (lead) {
+  if (lead && p2p_failed(p.err)) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) v[k] = __longlong_as_double(0x7ff8000000000000ll);
+  } else if (lead) {
 #pragma unroll
     for (int k = 0; k < NV; ++k) v[k] = 0.0;
     for (int r = 0; r < p.world; ++r) {

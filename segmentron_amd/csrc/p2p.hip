@@ -15,8 +15,9 @@
 //   slot — has ended: two parities are enough, no acknowledgements travel back.
 //
 // The exchange number lives in device memory and is advanced by the kernel itself, so the launch
-// can be captured into a HIP graph and replayed.  Waiting is bounded (P2P_TIMEOUT_TICKS of the
-// constant 100 MHz clock): on a timeout the kernel sets the error word, stops waiting in every
+// can be captured into a HIP graph and replayed.  Waiting is bounded (600 s of the constant
+// 100 MHz clock by default, seg_p2p_set_timeout): on a timeout the kernel sets the error word,
+// returns NaN from this and every later exchange (p2p.h p2p_failed), stops waiting in every
 // later exchange and the host reports it (seg_p2p_status) — never a hang.
 #include "p2p.h"
 #include <cstring>
@@ -30,6 +31,7 @@ struct P2PArgs {
   void* buf;
   unsigned long long* seq;
   int* err;
+  unsigned long long timeout_ticks;
   long slot_bytes;
   int n, rank, world;
 };
@@ -69,15 +71,20 @@ __global__ __launch_bounds__(P2P_THREADS) void p2p_allreduce_kernel(const P2PArg
   // 2. publish the exchange number on every rank; 3. wait for every rank's number here
   if (tid < a.world) {
     __hip_atomic_store(p2p_flags(a.peer[tid], a.world, a.slot_bytes) + (long)a.rank * P2P_FLAG_STRIDE,
-                       seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                       seq, P2P_FLAG_STORE_ORDER, __HIP_MEMORY_SCOPE_SYSTEM);
     const unsigned long long* mine =
         p2p_flags(a.peer[a.rank], a.world, a.slot_bytes) + (long)tid * P2P_FLAG_STRIDE;
-    if (!s_bad) p2p_wait(mine, seq, a.err);
+    if (!s_bad) p2p_wait(mine, seq, a.err, a.timeout_ticks);
   }
   __syncthreads();
-  // 4. the sum over ranks, in rank order
+  // 4. the sum over ranks, in rank order (NaN if a wait timed out, now or earlier: p2p.h)
   T* out = reinterpret_cast<T*>(a.buf);
+  const bool failed = p2p_failed(a.err);
   for (int i = tid; i < a.n; i += P2P_THREADS) {
+    if (failed) {
+      out[i] = (T)__longlong_as_double(0x7ff8000000000000ll);
+      continue;
+    }
     T s = (T)0;
     for (int r = 0; r < a.world; ++r) {
       const U* slot = reinterpret_cast<const U*>(
@@ -107,6 +114,7 @@ extern "C" int seg_p2p_create(int rank, int world, long slot_bytes, void** handl
   SEG_REQUIRE(slot_bytes > 0 && slot_bytes % 128 == 0, "p2p_create: slot_bytes must be a multiple of 128");
   P2PState* s = new P2PState();
   s->rank = rank; s->world = world; s->slot_bytes = slot_bytes;
+  s->timeout_ticks = P2P_TIMEOUT_TICKS;
   for (int r = 0; r < P2P_MAX_WORLD; ++r) { s->peer[r] = nullptr; s->opened[r] = false; }
   const long bytes = p2p_box_bytes(world, slot_bytes);
   void* box = nullptr;
@@ -177,7 +185,7 @@ static int p2p_all_reduce(void* handle, void* buf, int n, void* stream) {
   for (int r = 0; r < s->world; ++r)
     SEG_REQUIRE(a.peer[r] != nullptr, "p2p_all_reduce: rank %d is not connected", r);
   a.buf = buf;
-  a.seq = s->seq; a.err = s->err;
+  a.seq = s->seq; a.err = s->err; a.timeout_ticks = s->timeout_ticks;
   a.slot_bytes = s->slot_bytes;
   a.n = n; a.rank = s->rank; a.world = s->world;
   hipLaunchKernelGGL(p2p_allreduce_kernel<T>, dim3(1), dim3(P2P_THREADS), 0, (hipStream_t)stream, a);
@@ -200,9 +208,21 @@ extern "C" int seg_p2p_status(void* handle) {
   P2P_HIP(hipDeviceSynchronize(), "p2p_status: synchronize");
   P2P_HIP(hipMemcpy(&err, s->err, sizeof(int), hipMemcpyDeviceToHost), "p2p_status: read");
   if (err != 0) {
-    set_error("p2p: a peer did not publish its statistics within 30 s");
+    set_error("p2p: a peer did not publish its statistics within %.0f s; every exchange since "
+              "then returned NaN (the error word stays set: rebuild the mailbox to continue)",
+              (double)s->timeout_ticks / (double)P2P_TICKS_PER_S);
     return 3;
   }
+  return 0;
+}
+
+// Bound of one in-kernel wait (default 600 s).  Takes effect for launches issued afterwards; a
+// captured graph keeps the value it was captured with.
+extern "C" int seg_p2p_set_timeout(void* handle, double seconds) {
+  using namespace seg;
+  P2PState* s = static_cast<P2PState*>(handle);
+  SEG_REQUIRE(s != nullptr && seconds > 0.0 && seconds < 1e6, "p2p_set_timeout: %g s", seconds);
+  s->timeout_ticks = (unsigned long long)(seconds * (double)P2P_TICKS_PER_S);
   return 0;
 }
 

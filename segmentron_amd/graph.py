@@ -60,12 +60,17 @@ class GraphedInference:
 class GraphedTrainStep:
     """forward -> loss_fn(outputs, targets) -> backward -> optimizer.step() as one graph."""
 
-    def __init__(self, model, optimizer, images, targets, loss_fn, warmup=3, post_backward=None):
+    def __init__(self, model, optimizer, images, targets, loss_fn, warmup=3, post_backward=None,
+                 check=None, check_every=200):
         """post_backward: called between backward and the optimizer step — the data-parallel
         gradient averaging (`parallel.average_gradients`: direct RCCL calls on the capturing
         stream become nodes of the graph; torch.distributed collectives do NOT survive a capture
-        on this stack, see segmentron_amd/rccl.py)."""
+        on this stack, see segmentron_amd/rccl.py).
+        check: health check of the exchange path (`xgmi.StatsExchange.check`: synchronises and
+        raises when a peer stopped publishing its SyncBatchNorm statistics), called every
+        `check_every` replays — a stalled peer additionally turns the loss NaN at once (p2p.h)."""
         self.images, self.targets = images, targets
+        self._check, self._check_every, self._replays = check, int(check_every), 0
 
         def eager():
             loss = loss_fn(model(self.images), self.targets)
@@ -94,6 +99,10 @@ class GraphedTrainStep:
         if targets is not None:
             self.targets.copy_(targets)
         self.graph.replay()
+        self._replays += 1
+        if self._check is not None and self._check_every > 0 \
+                and self._replays % self._check_every == 0:
+            self._check()
         return self.loss
 
     def release(self):

@@ -42,17 +42,33 @@ def mailbox(group=None):
     was connected over (the default group): a BatchNorm that synchronises over a SUBGROUP
     (nn.SyncBatchNorm(process_group=...)) keeps the all-reduce path."""
     box = getattr(_NATIVE[0], "mailbox", None)
-    if box is not None and group is not None and dist.is_initialized() \
-            and dist.get_world_size(group) != box.world:
+    if box is not None and not _is_world(group):
         return None
     return box
 
 
+def _is_world(group):
+    """Does `group` span the ranks the native communicator / mailbox was built over?"""
+    if group is None or not dist.is_initialized() or group is dist.group.WORLD:
+        return True
+    comm = _NATIVE[0]
+    return dist.get_world_size(group) == getattr(comm, "world", dist.get_world_size())
+
+
 def _all_reduce(t, group):
-    if _NATIVE[0] is not None:
+    """The native communicator spans the default group only: a SyncBatchNorm over a SUBGROUP
+    (nn.SyncBatchNorm(process_group=...)) goes through torch.distributed with its group — eager
+    launches only (ProcessGroupNCCL does not survive a HIP-graph capture on this stack)."""
+    if _NATIVE[0] is not None and _is_world(group):
         _NATIVE[0].all_reduce(t)
-    else:
-        dist.all_reduce(t, group=group)
+        return
+    if _NATIVE[0] is not None:
+        import torch
+        if t.is_cuda and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("SyncBatchNorm over a process subgroup cannot be captured into a "
+                               "HIP graph: the native RCCL communicator spans the default group "
+                               "only (run this model with eager launches)")
+    dist.all_reduce(t, group=group)
 
 
 def average_gradients(params):
@@ -104,14 +120,38 @@ class OverlappedGradientAverager:
                 self._bucket_of[id(p)] = bi
         self._left = [len(b) for b in self.buckets]
         self._launched = [False] * len(self.buckets)
+        self._paused = False
         self._hooks = [p.register_post_accumulate_grad_hook(self._ready) for b in self.buckets
                        for p in b]
 
     def _ready(self, p):
         bi = self._bucket_of[id(p)]
+        if self._launched[bi] or self._left[bi] <= 0:
+            # a second backward before finish(): the bucket's all-reduce already ran on partial
+            # sums (gradient accumulation needs `with averager.no_sync():` around all but the
+            # last backward, like DistributedDataParallel.no_sync)
+            raise RuntimeError("OverlappedGradientAverager: a gradient arrived after its bucket "
+                               "was averaged — call finish() after every backward, or wrap the "
+                               "accumulating backwards in no_sync()")
+        if self._paused:
+            return
         self._left[bi] -= 1
         if self._left[bi] == 0:
             self._launch(bi)
+
+    def no_sync(self):
+        """Context manager: backwards inside it only accumulate (no all-reduce); the first
+        backward outside it averages the accumulated gradients."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def ctx():
+            prev, self._paused = self._paused, True
+            try:
+                yield
+            finally:
+                self._paused = prev
+        return ctx()
 
     def _launch(self, bi):
         import torch

@@ -17,6 +17,7 @@ Reference call sites: tools/train.py:76 (convert_sync_batchnorm), torch's SyncBa
 collectives torch/nn/modules/_functions.py:49-74,140.
 """
 import ctypes
+import os
 import sys
 
 import torch
@@ -40,14 +41,21 @@ class PeerMailbox:
     (rank order) carries the 64-byte IPC handles; default: torch.distributed.all_gather_object
     over the default group.  Every rank must construct it, and issue the same calls."""
 
-    def __init__(self, rank, world, slot_bytes=SLOT_BYTES, gather=None):
+    def __init__(self, rank, world, slot_bytes=SLOT_BYTES, gather=None, timeout_s=None):
+        """timeout_s: bound of one in-kernel wait for a peer (default: SEG_P2P_TIMEOUT_S or the
+        library's 600 s).  When it expires the exchange — and every later one, the error word is
+        latched — returns NaN, so the step fails visibly; `check()` raises."""
         self.rank, self.world, self.slot_bytes = int(rank), int(world), int(slot_bytes)
+        if timeout_s is None and os.environ.get("SEG_P2P_TIMEOUT_S"):
+            timeout_s = float(os.environ["SEG_P2P_TIMEOUT_S"])
         self._h = self.handle = ctypes.c_void_p()
         err, mine = None, b""
         try:
             h = ctypes.c_void_p()
             LIB.call("seg_p2p_create", self.rank, self.world, self.slot_bytes, ctypes.byref(h))
             self._h = self.handle = h  # (`handle`: what the seg_*_sync entry points take)
+            if timeout_s is not None:
+                LIB.call("seg_p2p_set_timeout", self._h, float(timeout_s))
             buf = ctypes.create_string_buffer(_HANDLE_BYTES)
             LIB.call("seg_p2p_ipc_handle", self._h, buf)
             mine = buf.raw
@@ -79,8 +87,13 @@ class PeerMailbox:
                  self._h, t.data_ptr(), t.numel(), torch.cuda.current_stream(t.device).cuda_stream)
         return t
 
+    def set_timeout(self, seconds):
+        """Launches issued from now on wait at most `seconds` (a captured graph keeps its own)."""
+        LIB.call("seg_p2p_set_timeout", self._h, float(seconds))
+
     def check(self):
-        """Synchronises; raises if a peer failed to publish within the kernel's time limit."""
+        """Synchronises; raises if a peer failed to publish within the kernel's time limit (the
+        results since then are NaN; the error is latched — build a new mailbox to go on)."""
         LIB.call("seg_p2p_status", self._h)
 
     def destroy(self):

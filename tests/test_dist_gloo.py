@@ -146,3 +146,96 @@ def test_stats_exchange_routing_and_mailbox_lookup():
         assert parallel.mailbox() is None  # a plain communicator: three-launch exchange path
     finally:
         parallel.use_native_rccl(prev)
+
+
+def _subgroup_worker(rank, world, port, ret):
+    """with a native communicator installed, a SyncBatchNorm over a process SUBGROUP
+    must reduce over that subgroup (torch.distributed), not over the native world communicator
+    or its mailbox; world-wide BatchNorms keep the native path."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from segmentron_amd import parallel
+        groups = [dist.new_group([r]) for r in range(world)]  # collective: every rank, same order
+        calls = []
+
+        class Box:
+            rank, world = 0, 2
+
+        class Native:
+            world, mailbox = 2, Box()
+
+            def all_reduce(self, t, op="sum"):
+                calls.append(t.numel())
+                dist.all_reduce(t)
+                return t
+
+        prev = parallel.use_native_rccl(Native())
+        try:
+            mine = groups[rank]
+            sync = torch.nn.SyncBatchNorm(4, process_group=mine).train()
+            assert parallel.sync_group(sync) is mine
+            assert parallel.mailbox(mine) is None and parallel.mailbox(dist.group.WORLD) is Native.mailbox
+            assert parallel.mailbox(None) is Native.mailbox
+            t = torch.full((6,), float(rank + 1), dtype=torch.float64)
+            sums, cnt = parallel.allreduce_forward_sums(t.clone(), 5, mine)
+            assert calls == [] and torch.equal(sums, t) and float(cnt) == 5.0  # own rank only
+            b = parallel.allreduce_backward_sums(t.clone(), mine)
+            assert calls == [] and torch.equal(b, t)
+            assert parallel.grad_scale(mine) == 1.0
+            sums, cnt = parallel.allreduce_forward_sums(t.clone(), 5, dist.group.WORLD)
+            assert calls == [7] and torch.equal(sums, torch.full((6,), 3.0, dtype=torch.float64))
+            assert float(cnt) == 10.0 and parallel.grad_scale(dist.group.WORLD) == 0.5
+        finally:
+            parallel.use_native_rccl(prev)
+        ret[rank] = 1
+    finally:
+        dist.destroy_process_group()
+
+
+def test_subgroup_syncbn_does_not_use_the_world_communicator():
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_subgroup_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert dict(ret) == {0: 1, 1: 1}
+
+
+def test_overlapped_averager_rejects_a_second_backward_without_finish():
+    """gradient accumulation through the overlapped averager must not silently mix
+    averaged and local gradients."""
+    import pytest
+    from segmentron_amd import parallel
+
+    class FakeStream:
+        def wait_stream(self, s):
+            pass
+
+    calls = []
+
+    class Comm:
+        def all_reduce_many(self, ts, op="sum"):
+            calls.append(len(ts))
+
+    av = parallel.OverlappedGradientAverager.__new__(parallel.OverlappedGradientAverager)
+    ps = [torch.nn.Parameter(torch.zeros(3)) for _ in range(3)]
+    av.comm, av.side = Comm(), FakeStream()
+    av.buckets = [[ps[2], ps[1]], [ps[0]]]
+    av._bucket_of = {id(ps[2]): 0, id(ps[1]): 0, id(ps[0]): 1}
+    av._left, av._launched, av._paused, av._hooks = [2, 1], [False, False], False, []
+    launched = []
+    av._launch = lambda bi: (launched.append(bi), av._launched.__setitem__(bi, True))
+    av._ready(ps[2])
+    av._ready(ps[1])
+    assert launched == [0]
+    with pytest.raises(RuntimeError):
+        av._ready(ps[2])  # second backward before finish()
+    av._left, av._launched = [2, 1], [False, False]
+    with av.no_sync():
+        av._ready(ps[2])
+        av._ready(ps[1])
+    assert launched == [0] and av._left == [2, 1]  # accumulation pass: nothing launched
+    av._ready(ps[2])
+    av._ready(ps[1])
+    assert launched == [0, 0]

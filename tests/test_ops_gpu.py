@@ -429,10 +429,10 @@ def test_bilinear_fwd_bwd(case, dtype):
     assert_close(to_cpu_nchw(y), ref.detach(), dtype, "bilinear fwd")
     g = quant(rnd(tuple(ref.shape), 2), dtype)
     ref.backward(g.double())
-    if Hi > 1:
-        gx = K().bilinear_bwd(to_dev_nhwc(g, dtype, pitch=C + 8), (Hi, Wi), ac)
-        assert_close(to_cpu_nchw(gx), xa.grad, dtype, "bilinear bwd")
-    else:
+    gx = K().bilinear_bwd(to_dev_nhwc(g, dtype, pitch=C + 8), (Hi, Wi), ac)
+    # (a 1x1 source sums Ho*Wo gradients into one bf16 value: the bar scales with the sum)
+    assert_close(to_cpu_nchw(gx), xa.grad, dtype, "bilinear bwd")
+    if Hi == 1:
         # 1x1 source (ASPP image pooling, PSP bin 1): the product path is the autograd function,
         # whose backward is a per-image column sum + the pending BN/ReLU backward
         xr = x.double().requires_grad_()
