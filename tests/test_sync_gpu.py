@@ -345,21 +345,32 @@ def _mailbox_worker(rank, world, port, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4, 8])
-def test_peer_mailbox_processes_exchange_through_hipipc_eager_and_in_a_graph(world):
+@pytest.mark.parametrize("world,strict", [(2, False), (4, False), (8, False), (2, True)])
+def test_peer_mailbox_processes_exchange_through_hipipc_eager_and_in_a_graph(world, strict):
     """csrc/p2p.hip + segmentron_amd/xgmi.py with 2 / 4 / 8 PROCESSES (hipIpc-mapped mailboxes,
     here on one device — the peer pointers then resolve to local HBM instead of an xGMI link;
     the protocol, the IPC plumbing, the flag indexing / parity logic beyond W = 2, rank-order
     sums and graph replay are what is tested): sums are bit-exact, also across 60 replayed
     dependent exchanges; the in-kernel exchange of the BatchNorm finalize with 91 / 256 blocks;
-    a stalled peer poisons the result instead of hanging or passing stale data."""
+    a stalled peer poisons the result instead of hanging or passing stale data.  `strict`: the
+    same through the by-the-book release/acquire build of the protocol (make strict)."""
     ctx = mp.get_context("spawn")
     mgr = ctx.Manager()
     ret = mgr.dict()
     port = _free_port()
-    procs = [ctx.Process(target=_mailbox_worker, args=(r, world, port, ret)) for r in range(world)]
-    for p in procs:
-        p.start()
+    lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                       "segmentron_amd", "libsegmentron_hip_p2pstrict.so")
+    if strict:
+        assert os.path.exists(lib), "build it: make -C segmentron_amd/csrc strict"
+        os.environ["SEGMENTRON_HIP_LIB"] = lib  # the spawned workers load this build
+    try:
+        procs = [ctx.Process(target=_mailbox_worker, args=(r, world, port, ret))
+                 for r in range(world)]
+        for p in procs:
+            p.start()
+    finally:
+        if strict:
+            del os.environ["SEGMENTRON_HIP_LIB"]
     _join_or_kill(procs, 300)
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     assert all(ret[r] == 0.0 for r in range(world))
