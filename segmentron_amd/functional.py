@@ -181,6 +181,87 @@ def bn_input_backward(g, x, bn, relu, chan_mul=None, inplace=False, elem_mul=Non
     return dx, dgamma, dbeta
 
 
+# ----------------------------------------------------------------------------- side lane
+class _Lane:
+    """A second HIP stream for backward work that only the optimizer step consumes (VERDICT r03
+    item 2): the weight gradient of a convolution whose input BatchNorm is NOT folded depends on
+    (dy, x) but nothing downstream of it in backward does — tools/train.py:142-145 orders only
+    backward -> optimizer.step.  Issued on the side lane it overlaps the data-gradient chain of
+    the layers below (fills the CUs a one-round GEMM leaves idle and the ramp / tail of the
+    element-wise kernels).  The lane forks from the compute stream at the point of issue
+    (wait_stream) and joins it when the backward pass ends (an autograd engine callback, run on
+    the stream that called backward()), so the pattern survives a HIP-graph capture: the lane's
+    launches become a parallel branch of the captured graph.
+
+    Folded pointwise convolutions (63 of the 79 GEMM convolutions of C3) do NOT qualify: their
+    BatchNorm-backward correction (c0, c1) is derived from the weight-gradient GEMM's partials
+    (ds = colsum(W o dW')), which puts that GEMM on the critical path of the data gradient.
+
+    SEG_WGRAD_LANE=0 switches the lane off (everything on the compute stream, bit-identical
+    results: the same kernels run on the same operands)."""
+    enabled = os.environ.get("SEG_WGRAD_LANE", "1") != "0"
+    stream = None
+    keep = []          # operands of lane launches: alive until the join (allocator safety)
+    armed = False      # a join callback is queued for the running backward pass
+
+
+def wgrad_lane(enable=None):
+    """Query / switch the side lane; returns the previous setting."""
+    prev = _Lane.enabled
+    if enable is not None:
+        _Lane.enabled = bool(enable)
+    return prev
+
+
+def lane_stream():
+    """The side lane's stream if launches are pending on it (the gradient averager must wait for
+    it before it reads parameter gradients), else None."""
+    return _Lane.stream if _Lane.armed else None
+
+
+def _lane_join():
+    if _Lane.armed and _Lane.stream is not None:
+        torch.cuda.current_stream().wait_stream(_Lane.stream)
+    _Lane.armed = False
+    del _Lane.keep[:]
+
+
+class _on_lane:
+    """`with _on_lane(weight, x, dy) as lane:` — launches inside go to the side lane when
+    `lane` is true (else the block runs on the compute stream as before).  Only when the
+    parameter has no gradient yet: AccumulateGrad then adopts the tensor without a kernel; an
+    in-place accumulation (`grad += dW` on the compute stream) would race with the lane."""
+
+    def __init__(self, param, *operands):
+        self.on = _Lane.enabled and param.grad is None and operands[0].is_cuda
+        self.operands = operands
+        self.ctx = None
+
+    def __enter__(self):
+        if not self.on:
+            return False
+        try:
+            if not _Lane.armed:
+                # joins at the end of THIS backward pass (raises outside of one)
+                torch.autograd.Variable._execution_engine.queue_callback(_lane_join)
+                _Lane.armed = True
+        except RuntimeError:
+            self.on = False
+            return False
+        if _Lane.stream is None:
+            _Lane.stream = torch.cuda.Stream()
+        _Lane.stream.wait_stream(torch.cuda.current_stream())
+        _Lane.keep.extend(self.operands)
+        self.ctx = torch.cuda.stream(_Lane.stream)
+        self.ctx.__enter__()
+        return True
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+        return False
+
+
 # ----------------------------------------------------------------------------- weight packing
 _WCACHE = {}
 
@@ -302,16 +383,20 @@ class _ConvFn(torch.autograd.Function):
             dy_full = dy
         Cx = x.shape[-1]
         Ow = dy_full.shape[-1]  # ragged O: the zero-padded gradient keeps the vector kernels usable
-        dWp = K.conv_wgrad(x, dy_full, Ow, KH, KW, s.stride, s.pad, s.dil, s.pro)[:O]
-        if KH == 1 and KW == 1 and Cx == Cw:
-            dW = dWp.view(O, Cw, 1, 1)
-        else:
-            dW = dWp.view(O, KH, KW, Cx)[..., :Cw].permute(0, 3, 1, 2).contiguous()
-        dbias = None
-        if ctx.has_bias and s.drop_bias:
-            dbias = torch.zeros(O, dtype=torch.float32, device=dy.device)
-        elif ctx.has_bias:
-            dbias = K.bn_bwd_reduce(dy_full, dy_full, (PRO_NONE, None, None))[:O].float()
+        # weight / bias gradient: nothing in backward depends on them -> side lane (see _Lane)
+        with _on_lane(weight, x, dy_full, s.pro[1], s.pro[2]) as lane:
+            dWp = K.conv_wgrad(x, dy_full, Ow, KH, KW, s.stride, s.pad, s.dil, s.pro)[:O]
+            if KH == 1 and KW == 1 and Cx == Cw:
+                dW = dWp.view(O, Cw, 1, 1)
+            else:
+                dW = dWp.view(O, KH, KW, Cx)[..., :Cw].permute(0, 3, 1, 2).contiguous()
+            dbias = None
+            if ctx.has_bias and s.drop_bias:
+                dbias = torch.zeros(O, dtype=torch.float32, device=dy.device)
+            elif ctx.has_bias:
+                dbias = K.bn_bwd_reduce(dy_full, dy_full, (PRO_NONE, None, None))[:O].float()
+        if lane:
+            _Lane.keep.extend((dWp, dW, dbias))
         dx = dgamma = dbeta = None
         if ctx.needs_input_grad[0]:
             Op, dt = dy_full.shape[-1], x.dtype
