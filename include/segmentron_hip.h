@@ -146,6 +146,14 @@ int seg_bn_finalize_p(const float* partial, long R, double count, const float* g
                       const float* beta, float eps, float momentum, float* running_mean,
                       float* running_var, float* mean, float* invstd, float* scale, float* shift,
                       int C, const float* mean_offset, double* ws, void* stream);
+/* The same for a BatchNorm over FEW samples (M = N*H*W <= 4096 rows of the stored NHWC tensor y,
+ * row pitch ldy): two-pass statistics (mean, then sum (x - mean)^2) straight from y — the
+ * single-pass partial sums lose mean^2 / var digits, catastrophic for the 2-sample BatchNorm of
+ * the ASPP image-pooling branch (module.py:52-64) and PSP's pyramid bins (module.py:89-97). */
+int seg_bn_finalize_small(int dtype, const void* y, long ldy, long M, int C, const float* gamma,
+                          const float* beta, float eps, float momentum, float* running_mean,
+                          float* running_var, float* mean, float* invstd, float* scale,
+                          float* shift, const float* mean_offset, void* stream);
 /* eval mode: scale/shift from running statistics. */
 int seg_bn_eval_affine(const float* gamma, const float* beta, const float* rm, const float* rv,
                        float eps, float* scale, float* shift, int C, void* stream);

@@ -26,9 +26,15 @@ Rounding points of the HIP bf16 path (segmentron_amd/csrc):
   * BN finalize in fp64 -> fp32 scale/shift;  act(x) = relu(fma(x, scale, shift)) in fp32
   * materialise / residual add / bilinear / global pool: fp32 math, bf16 store
   * logits upsample: bf16 in, fp32 NCHW out
+  * r04: a BatchNorm over at most 1024 samples (hip_ops.SMALL_BN_ROWS: the ASPP image-pooling
+    branch, PSP's pyramid bins, every layer of a tiny test input) takes its statistics two-pass
+    from the tensor AS STORED (seg_bn_finalize_small), whatever kernel produced it
 """
 import torch
 import torch.nn.functional as F
+
+
+SMALL_BN_ROWS = 1024  # == segmentron_amd.hip_ops.SMALL_BN_ROWS
 
 
 class _R16(torch.autograd.Function):
@@ -120,7 +126,7 @@ class Bf16EmuNet:
                 return _A(r16(y))
             m_ = y.shape[0] * y.shape[2] * y.shape[3]
             px256 = stride == 1 and ((w.shape[0] >= 384 and m_ >= 4096) or (w.shape[0] >= 256 and m_ >= 65536))
-            s, b = self._bn(r16(y) if px256 else y, bnp)
+            s, b = self._bn(r16(y) if (px256 or m_ <= SMALL_BN_ROWS) else y, bnp)
             return _A(r16(y), s, b)
         w = r16(wf)
         if self.accum64:
@@ -140,7 +146,7 @@ class Bf16EmuNet:
         kxk = kh > 1 and stride == 1 and C_ % 32 == 0 and O_ >= 256 and m_ >= 4096 and bias is None
         direct = (kh == 3 and stride == 1 and pad == 1 and dil == 1 and m_ >= 65536
                   and (C_, O_) in ((32, 32), (32, 64), (64, 32)))
-        s, b = self._bn(r16(y) if (fast or kxk or direct) else y, bnp)
+        s, b = self._bn(r16(y) if (fast or kxk or direct or m_ <= SMALL_BN_ROWS) else y, bnp)
         return _A(r16(y), s, b)
 
     def dw(self, a, p, bnp, stride, dil):
@@ -153,7 +159,8 @@ class Bf16EmuNet:
                          groups=c).float()
         else:
             y = F.conv2d(v, self.sd[p + ".weight"], None, stride, dil, dil, groups=c)
-        s, b = self._bn(y, bnp)
+        small = y.shape[0] * y.shape[2] * y.shape[3] <= SMALL_BN_ROWS
+        s, b = self._bn(r16(y) if small else y, bnp)
         return _A(r16(y), s, b)
 
     def sep(self, a, p, stride=1, dil=1, relu_first=True):

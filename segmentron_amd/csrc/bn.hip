@@ -460,6 +460,69 @@ __global__ __launch_bounds__(EW_THREADS) void bn_finalize_p_kernel(
   }
 }
 
+// ---- BatchNorm over a SMALL number of samples (ASPP image pooling: N values per channel,
+// module.py:52-64; PSP's pyramid bins: N*o*o = 2..72, module.py:89-97): statistics taken TWO-PASS
+// from the stored tensor itself — mean first, then sum (x - mean)^2 — like ATen's CPU kernel.
+// The single-pass form var = E[x^2] - mean^2 on fp32 partial sums loses 6e-8 * mean^2 / var:
+// with two samples a, b per channel that is catastrophic as soon as |a - b| << |a| (measured
+// r04 on the conditioned fixture: the one 2-sample BatchNorm of DeepLabv3+ put 2e-4 into the head's
+// activations and, through ReLU-mask flips, 5e-2 into every encoder gradient of the fp32 path).
+template <typename T>
+__global__ __launch_bounds__(EW_THREADS) void bn_finalize_small_kernel(
+    const T* __restrict__ y, long ldy, int M, double count, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float eps, float momentum, float* running_mean,
+    float* running_var, float* mean_o, float* invstd_o, float* scale_o, float* shift_o, int C,
+    const float* __restrict__ mean_offset) {
+  __shared__ double red[32][9];
+  __shared__ double s_mean[8];
+  const int cx = threadIdx.x & 7, ry = threadIdx.x >> 3;
+  const int c = blockIdx.x * 8 + cx;
+  const bool fin = ry == 0 && c < C;
+  float g = 1.f, b = 0.f, rm = 0.f, rv = 0.f, moff = 0.f;
+  if (fin) {
+    if (gamma) g = gamma[c];
+    if (beta) b = beta[c];
+    if (running_mean) { rm = running_mean[c]; rv = running_var[c]; }
+    if (mean_offset) moff = mean_offset[c];
+  }
+  double a = 0.0;
+  if (c < C)
+    for (int m = ry; m < M; m += 32) a += (double)Vec<T>::load1(y + (long)m * ldy + c);
+  red[ry][cx] = a;
+  __syncthreads();
+  if (ry == 0) {
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) s += red[k][cx];
+    s_mean[cx] = s / count;
+  }
+  __syncthreads();
+  const double mean = s_mean[cx];
+  a = 0.0;
+  if (c < C)
+    for (int m = ry; m < M; m += 32) {
+      const double d = (double)Vec<T>::load1(y + (long)m * ldy + c) - mean;
+      a += d * d;
+    }
+  red[ry][cx] = a;
+  __syncthreads();
+  if (!fin) return;
+  double ss = 0.0;
+#pragma unroll
+  for (int k = 0; k < 32; ++k) ss += red[k][cx];
+  const double var = ss / count;
+  const double invstd = 1.0 / sqrt(var + (double)eps);
+  mean_o[c] = (float)mean;
+  invstd_o[c] = (float)invstd;
+  scale_o[c] = (float)((double)g * invstd);
+  shift_o[c] = (float)((double)b - mean * (double)g * invstd);
+  if (running_mean) {
+    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+    running_mean[c] = (float)((1.0 - momentum) * (double)rm + momentum * (mean + (double)moff));
+    running_var[c] = (float)((1.0 - momentum) * (double)rv + momentum * unbiased);
+  }
+}
+
 template <typename TIN>
 __device__ __forceinline__ void bn_bwd_finalize_block(
     const TIN* __restrict__ part, int R, double count, const float* __restrict__ mean,
@@ -785,6 +848,28 @@ extern "C" int seg_bn_finalize_p(const float* partial, long R, double count, con
                        scale, shift, C, mean_offset, p2p_dev_none(), (double*)nullptr);
   }
   return check_launch("bn_finalize_p");
+}
+
+extern "C" int seg_bn_finalize_small(int dtype, const void* y, long ldy, long M, int C,
+                                     const float* gamma, const float* beta, float eps,
+                                     float momentum, float* running_mean, float* running_var,
+                                     float* mean, float* invstd, float* scale, float* shift,
+                                     const float* mean_offset, void* stream) {
+  using namespace seg;
+  SEG_REQUIRE(M >= 1 && M <= 4096 && C >= 1 && ldy >= C, "bn_finalize_small: bad M/C/pitch");
+  SEG_REQUIRE(dtype == DT_F32 || dtype == DT_BF16, "bn_finalize_small: bad dtype");
+  const dim3 grid((C + 7) / 8);
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL((bn_finalize_small_kernel<bf16_t>), grid, dim3(EW_THREADS), 0,
+                       (hipStream_t)stream, (const bf16_t*)y, ldy, (int)M, (double)M, gamma, beta,
+                       eps, momentum, running_mean, running_var, mean, invstd, scale, shift, C,
+                       mean_offset);
+  else
+    hipLaunchKernelGGL((bn_finalize_small_kernel<float>), grid, dim3(EW_THREADS), 0,
+                       (hipStream_t)stream, (const float*)y, ldy, (int)M, (double)M, gamma, beta,
+                       eps, momentum, running_mean, running_var, mean, invstd, scale, shift, C,
+                       mean_offset);
+  return check_launch("bn_finalize_small");
 }
 
 extern "C" int seg_bn_bwd_finalize_p(const float* partial, long R, double count,

@@ -89,10 +89,20 @@ class GradFork:
         return g
 
 
-def finish_bn(bn, partial, count, mean_offset=None):
+def uses_batch_stats(bn):
+    """Training-mode BatchNorm (batch statistics + running-stat update)?  FrozenBatchNorm2d
+    (modules/batch_norm.py) is a constant affine in every mode."""
+    return not getattr(bn, "frozen", False) and (bn.training or bn.running_mean is None)
+
+
+def finish_bn(bn, partial, count, mean_offset=None, y=None):
     """Turn conv-epilogue partials into a BNState (and update running stats like torch does).
-    bn: nn.BatchNorm2d / nn.SyncBatchNorm module — eps / momentum / training read NOW."""
-    use_batch = bn.training or bn.running_mean is None
+    bn: nn.BatchNorm2d / nn.SyncBatchNorm module — eps / momentum / training read NOW.
+    y: the stored raw tensor the partials describe; a single-process BatchNorm over at most
+    hip_ops.SMALL_BN_ROWS samples takes its statistics two-pass from it (seg_bn_finalize_small):
+    E[x^2] - mean^2 on fp32 partial sums is catastrophic for the 2-sample BatchNorm of the ASPP
+    image-pooling branch and PSP's pyramid bins."""
+    use_batch = uses_batch_stats(bn)
     if not use_batch:
         scale, shift = K.bn_eval_affine(bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                         bn.eps)
@@ -107,9 +117,13 @@ def finish_bn(bn, partial, count, mean_offset=None):
     group = _sync_group(bn)
     cnt = float(count)
     momentum = bn.momentum if bn.momentum is not None else 0.1
-    track = bn.training and bn.track_running_stats and bn.running_mean is not None
+    track = bn.training and getattr(bn, "track_running_stats", False) \
+        and bn.running_mean is not None
     rm, rv = (bn.running_mean, bn.running_var) if track else (None, None)
-    if group is None:
+    if group is None and y is not None and count <= K.SMALL_BN_ROWS:
+        mean, invstd, scale, shift = K.bn_finalize_small(y, bn.weight, bn.bias, bn.eps, momentum,
+                                                         rm, rv, mean_offset)
+    elif group is None:
         mean, invstd, scale, shift = K.bn_finalize_p(partial, cnt, bn.weight, bn.bias, bn.eps,
                                                      momentum, rm, rv, mean_offset)
     else:
@@ -179,87 +193,6 @@ def bn_input_backward(g, x, bn, relu, chan_mul=None, inplace=False, elem_mul=Non
     dx = K.bn_bwd_apply(g, x, pro, c0, c1, chan_mul, out=g if inplace else None,
                         elem_mul=elem_mul)
     return dx, dgamma, dbeta
-
-
-# ----------------------------------------------------------------------------- side lane
-class _Lane:
-    """A second HIP stream for backward work that only the optimizer step consumes (VERDICT r03
-    item 2): the weight gradient of a convolution whose input BatchNorm is NOT folded depends on
-    (dy, x) but nothing downstream of it in backward does — tools/train.py:142-145 orders only
-    backward -> optimizer.step.  Issued on the side lane it overlaps the data-gradient chain of
-    the layers below (fills the CUs a one-round GEMM leaves idle and the ramp / tail of the
-    element-wise kernels).  The lane forks from the compute stream at the point of issue
-    (wait_stream) and joins it when the backward pass ends (an autograd engine callback, run on
-    the stream that called backward()), so the pattern survives a HIP-graph capture: the lane's
-    launches become a parallel branch of the captured graph.
-
-    Folded pointwise convolutions (63 of the 79 GEMM convolutions of C3) do NOT qualify: their
-    BatchNorm-backward correction (c0, c1) is derived from the weight-gradient GEMM's partials
-    (ds = colsum(W o dW')), which puts that GEMM on the critical path of the data gradient.
-
-    SEG_WGRAD_LANE=0 switches the lane off (everything on the compute stream, bit-identical
-    results: the same kernels run on the same operands)."""
-    enabled = os.environ.get("SEG_WGRAD_LANE", "1") != "0"
-    stream = None
-    keep = []          # operands of lane launches: alive until the join (allocator safety)
-    armed = False      # a join callback is queued for the running backward pass
-
-
-def wgrad_lane(enable=None):
-    """Query / switch the side lane; returns the previous setting."""
-    prev = _Lane.enabled
-    if enable is not None:
-        _Lane.enabled = bool(enable)
-    return prev
-
-
-def lane_stream():
-    """The side lane's stream if launches are pending on it (the gradient averager must wait for
-    it before it reads parameter gradients), else None."""
-    return _Lane.stream if _Lane.armed else None
-
-
-def _lane_join():
-    if _Lane.armed and _Lane.stream is not None:
-        torch.cuda.current_stream().wait_stream(_Lane.stream)
-    _Lane.armed = False
-    del _Lane.keep[:]
-
-
-class _on_lane:
-    """`with _on_lane(weight, x, dy) as lane:` — launches inside go to the side lane when
-    `lane` is true (else the block runs on the compute stream as before).  Only when the
-    parameter has no gradient yet: AccumulateGrad then adopts the tensor without a kernel; an
-    in-place accumulation (`grad += dW` on the compute stream) would race with the lane."""
-
-    def __init__(self, param, *operands):
-        self.on = _Lane.enabled and param.grad is None and operands[0].is_cuda
-        self.operands = operands
-        self.ctx = None
-
-    def __enter__(self):
-        if not self.on:
-            return False
-        try:
-            if not _Lane.armed:
-                # joins at the end of THIS backward pass (raises outside of one)
-                torch.autograd.Variable._execution_engine.queue_callback(_lane_join)
-                _Lane.armed = True
-        except RuntimeError:
-            self.on = False
-            return False
-        if _Lane.stream is None:
-            _Lane.stream = torch.cuda.Stream()
-        _Lane.stream.wait_stream(torch.cuda.current_stream())
-        _Lane.keep.extend(self.operands)
-        self.ctx = torch.cuda.stream(_Lane.stream)
-        self.ctx.__enter__()
-        return True
-
-    def __exit__(self, *exc):
-        if self.ctx is not None:
-            self.ctx.__exit__(*exc)
-        return False
 
 
 # ----------------------------------------------------------------------------- weight packing
@@ -383,20 +316,16 @@ class _ConvFn(torch.autograd.Function):
             dy_full = dy
         Cx = x.shape[-1]
         Ow = dy_full.shape[-1]  # ragged O: the zero-padded gradient keeps the vector kernels usable
-        # weight / bias gradient: nothing in backward depends on them -> side lane (see _Lane)
-        with _on_lane(weight, x, dy_full, s.pro[1], s.pro[2]) as lane:
-            dWp = K.conv_wgrad(x, dy_full, Ow, KH, KW, s.stride, s.pad, s.dil, s.pro)[:O]
-            if KH == 1 and KW == 1 and Cx == Cw:
-                dW = dWp.view(O, Cw, 1, 1)
-            else:
-                dW = dWp.view(O, KH, KW, Cx)[..., :Cw].permute(0, 3, 1, 2).contiguous()
-            dbias = None
-            if ctx.has_bias and s.drop_bias:
-                dbias = torch.zeros(O, dtype=torch.float32, device=dy.device)
-            elif ctx.has_bias:
-                dbias = K.bn_bwd_reduce(dy_full, dy_full, (PRO_NONE, None, None))[:O].float()
-        if lane:
-            _Lane.keep.extend((dWp, dW, dbias))
+        dWp = K.conv_wgrad(x, dy_full, Ow, KH, KW, s.stride, s.pad, s.dil, s.pro)[:O]
+        if KH == 1 and KW == 1 and Cx == Cw:
+            dW = dWp.view(O, Cw, 1, 1)
+        else:
+            dW = dWp.view(O, KH, KW, Cx)[..., :Cw].permute(0, 3, 1, 2).contiguous()
+        dbias = None
+        if ctx.has_bias and s.drop_bias:
+            dbias = torch.zeros(O, dtype=torch.float32, device=dy.device)
+        elif ctx.has_bias:
+            dbias = K.bn_bwd_reduce(dy_full, dy_full, (PRO_NONE, None, None))[:O].float()
         dx = dgamma = dbeta = None
         if ctx.needs_input_grad[0]:
             Op, dt = dy_full.shape[-1], x.dtype
@@ -953,7 +882,7 @@ def conv_bn(act, conv, bn=None, out=None):
     """conv (nn.Conv2d, groups=1) [+ BatchNorm statistics].  Returns an Act whose BN (if any) and
     ReLU are pending; caller sets ``.relu``."""
     x = act.t
-    batch_stats = bn is not None and (bn.training or bn.running_mean is None)
+    batch_stats = bn is not None and uses_batch_stats(bn)
     spec = ConvSpec(act, conv.stride[0], conv.padding[0], conv.dilation[0], out,
                     want_stats=batch_stats)
     g, b = act.params
@@ -979,18 +908,18 @@ def conv_bn(act, conv, bn=None, out=None):
     if bn is None:
         return Act(y)
     N, Ho, Wo, _ = y.shape
-    return Act(y, finish_bn(bn, spec.partial, N * Ho * Wo, offset))
+    return Act(y, finish_bn(bn, spec.partial, N * Ho * Wo, offset, y=y))
 
 
 def dwconv_bn(act, conv, bn, out=None, fork=None):
     spec = ConvSpec(act, conv.stride[0], conv.padding[0], conv.dilation[0], out,
-                    want_stats=bn.training or bn.running_mean is None)
+                    want_stats=uses_batch_stats(bn))
     spec.fork = fork
     assert conv.padding[0] == conv.dilation[0] and conv.kernel_size[0] == 3
     g, b = act.params
     y = _DwFn.apply(act.t, g, b, conv.weight, spec)
     N, Ho, Wo, _ = y.shape
-    return Act(y, finish_bn(bn, spec.partial, N * Ho * Wo))
+    return Act(y, finish_bn(bn, spec.partial, N * Ho * Wo, y=y))
 
 
 def materialize(act, residual=None, chan_mul=None, post_relu=False, out=None, elem_mul=None,

@@ -109,3 +109,151 @@ class GraphedTrainStep:
         """Call before going back to eager steps: the optimizer stepped inside the graph without
         moving `param._version`, so the cached weight packs are stale."""
         F.clear_weight_cache()
+
+
+# ----------------------------------------------------------------------------- transparent capture
+class _GraphedSegment(torch.autograd.Function):
+    """One captured forward / backward pair as an autograd node (the torch.cuda
+    make_graphed_callables split): forward replays the forward graph and hands out the static
+    low-resolution logits; backward copies their gradients into the static buffers, replays
+    the backward graph and ASSIGNS the static parameter gradients (`p.grad = g`, no
+    AccumulateGrad clone of 440 tensors; an existing different gradient is added to)."""
+
+    @staticmethod
+    def forward(ctx, anchor, seg):
+        seg.fwd.replay()
+        ctx.seg = seg
+        return tuple(t.detach() for t in seg.lo)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        seg = ctx.seg
+        for buf, g in zip(seg.grad_lo, grads):
+            if g is None:
+                buf.zero_()
+            else:
+                buf.copy_(g)
+        seg.bwd.replay()
+        with torch.no_grad():
+            for p, g in zip(seg.params, seg.grads):
+                if g is None:
+                    continue
+                if p.grad is None or p.grad is g:
+                    p.grad = g
+                else:  # gradient accumulation / zero_grad(set_to_none=False) on another tensor
+                    p.grad.add_(g)
+        return None, None
+
+
+class _Segment:
+    __slots__ = ("fwd", "bwd", "x", "lo", "meta", "grad_lo", "params", "grads", "anchor")
+
+
+class TransparentTrainGraph:
+    """HIP-graph execution behind the reference's UNCHANGED train loop (tools/train.py:130-146):
+
+        outputs = self.model(images); loss_dict = self.criterion(outputs, targets); ...
+        self.optimizer.zero_grad(); losses.backward(); self.optimizer.step()
+
+    `install(model)` (done by `get_segmentation_model()` when SEGMENTRON_HIP_GRAPH=1) replaces
+    `model.forward`: in training mode with gradients enabled, the first `warmup` calls with a
+    given input shape run eagerly (they are real steps: allocator, lazy initialisation, weight
+    packs warm up on them); the next call captures TWO graphs keyed on that shape — the forward
+    pass up to the heads' low-resolution logits, and its backward pass down to the parameter
+    gradients — and from then on `model(images)` is one copy + one graph replay and
+    `losses.backward()` one replay.  The criterion (the fused upsample + cross-entropy kernels,
+    through `functional.LogitsView`) and `optimizer.step()` (FusedSGD: 11 launches) stay eager
+    launches: ~15 of the ~1140 launches of a step.  Any other call — evaluation mode, no_grad,
+    a new shape beyond `max_shapes`, a model whose BatchNorms synchronise over torch.distributed
+    — takes the eager path, which stays correct; parameters may be updated by any optimizer
+    (weight packs are re-issued inside the captured forward).  One process per GPU, one stream."""
+
+    def __init__(self, model, warmup=2, max_shapes=2):
+        self.model, self.warmup, self.max_shapes = model, int(warmup), int(max_shapes)
+        self.eager_forward = model.forward
+        self.seen, self.segments, self.disabled = {}, {}, None
+
+    # -- installation
+    @classmethod
+    def install(cls, model, **kw):
+        tg = cls(model, **kw)
+        model.forward = tg.forward          # nn.Module.__call__ -> self.forward
+        model._transparent_graph = tg
+        return tg
+
+    def uninstall(self):
+        self.model.__dict__.pop("forward", None)
+        self.model.__dict__.pop("_transparent_graph", None)
+        self.segments.clear()
+
+    # -- dispatch
+    def _key(self, x):
+        return (tuple(x.shape), x.dtype, x.device.index)
+
+    def _capturable(self, x):
+        import torch.distributed as dist
+        if not (self.model.training and torch.is_grad_enabled() and isinstance(x, torch.Tensor)
+                and x.is_cuda and not x.requires_grad and self.disabled is None):
+            return False
+        if torch.cuda.is_current_stream_capturing():
+            return False  # somebody else (GraphedTrainStep) is capturing the whole step
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            from . import parallel
+            if parallel.native_rccl() is None:
+                return False  # torch.distributed collectives do not survive a capture
+        return True
+
+    def forward(self, x, *args, **kwargs):
+        if args or kwargs or not self._capturable(x):
+            return self.eager_forward(x, *args, **kwargs)
+        key = self._key(x)
+        seg = self.segments.get(key)
+        if seg is None:
+            n = self.seen.get(key, 0)
+            self.seen[key] = n + 1
+            if n < self.warmup or len(self.segments) >= self.max_shapes:
+                return self.eager_forward(x)
+            try:
+                seg = self._capture(x)
+            except Exception as e:  # noqa: BLE001 — eager stays correct; say why, once
+                import sys
+                self.disabled = repr(e)[:300]
+                sys.stderr.write("segmentron_amd.graph: transparent capture failed (%s): eager "
+                                 "launches from here on\n" % self.disabled)
+                torch.cuda.synchronize()
+                F.clear_weight_cache()
+                return self.eager_forward(x)
+            self.segments[key] = seg
+        seg.x.copy_(x)
+        lo = _GraphedSegment.apply(seg.anchor, seg)
+        return tuple(F.LogitsView(t, hw, ac) for t, (hw, ac) in zip(lo, seg.meta))
+
+    # -- capture of one shape
+    def _capture(self, x):
+        model = self.model
+        seg = _Segment()
+        seg.x = x.clone()
+        seg.params = [p for p in model.parameters() if p.requires_grad]
+        seg.anchor = torch.zeros((), device=x.device, requires_grad=True)
+        torch.cuda.synchronize()
+        F.clear_weight_cache()  # the weight packs must be issued INSIDE the captured forward
+        pool = torch.cuda.graph_pool_handle()
+        seg.fwd, seg.bwd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(seg.fwd, pool=pool):
+            outs = self.eager_forward(seg.x)
+        if not all(isinstance(o, F.LogitsView) for o in outs):
+            raise RuntimeError("transparent capture needs LogitsView outputs (training mode)")
+        seg.lo = [o.lo for o in outs]
+        seg.meta = [(o.out_hw, o.align_corners) for o in outs]
+        seg.grad_lo = [torch.zeros_like(t) for t in seg.lo]
+        with torch.cuda.graph(seg.bwd, pool=pool):
+            grads = torch.autograd.grad(seg.lo, seg.params, seg.grad_lo, allow_unused=True)
+        seg.grads = [None if g is None else (g if g.is_contiguous() else g.contiguous())
+                     for g in grads]
+        torch.cuda.synchronize()
+        return seg
+
+
+def transparent_graph_requested():
+    import os
+    return os.environ.get("SEGMENTRON_HIP_GRAPH", "0") == "1"

@@ -424,6 +424,20 @@ def bn_finalize_p(partial, count, gamma, beta, eps, momentum, running_mean, runn
     return out[0], out[1], out[2], out[3]
 
 
+SMALL_BN_ROWS = 1024
+
+
+def bn_finalize_small(y, gamma, beta, eps, momentum, running_mean, running_var, mean_offset=None):
+    """BatchNorm statistics of a SMALL stored tensor y [N,H,W,C] (N*H*W <= 4096 rows), two-pass
+    (mean, then sum (x - mean)^2) -> mean, invstd, scale, shift (+ running-stat update)."""
+    N, H, W, C, ldy = nhwc(y)
+    out = torch.empty((4, C), dtype=torch.float32, device=y.device)
+    LIB.call("seg_bn_finalize_small", _DT[y.dtype], _p(y), ldy, N * H * W, C, _p(gamma), _p(beta),
+             float(eps), float(momentum), _p(running_mean), _p(running_var), _p(out[0]),
+             _p(out[1]), _p(out[2]), _p(out[3]), _p(mean_offset), _stream())
+    return out[0], out[1], out[2], out[3]
+
+
 def bn_finalize_p_sync(box, partial, local_count, gamma, beta, eps, momentum, running_mean,
                        running_var, mean_offset=None):
     """bn_finalize_p for SyncBatchNorm in ONE launch: this rank's partial rows are summed, the

@@ -15,6 +15,11 @@ def get_segmentation_model():
     """Build the model named by cfg.MODEL.MODEL_NAME (case-sensitive, model_zoo.py:22)."""
     model = MODEL_REGISTRY.get(cfg.MODEL.MODEL_NAME)()
     load_model_pretrain(model)
+    from .. import graph
+    if graph.transparent_graph_requested():
+        # SEGMENTRON_HIP_GRAPH=1: train-mode forward / backward replay captured HIP graphs behind
+        # the unchanged tools/train.py loop (segmentron_amd/graph.py TransparentTrainGraph)
+        graph.TransparentTrainGraph.install(model)
     return model
 
 

@@ -166,10 +166,6 @@ class OverlappedGradientAverager:
             return
         main = torch.cuda.current_stream()
         self.side.wait_stream(main)  # the bucket's gradients are complete on the compute stream
-        from . import functional
-        lane = functional.lane_stream()
-        if lane is not None:         # ... or on the weight-gradient side lane
-            self.side.wait_stream(lane)
         with torch.cuda.stream(self.side):
             self.comm.all_reduce_many(grads, "avg")
 

@@ -268,3 +268,43 @@ def test_kernel_selection_queries_of_the_c_library():
     assert q("seg_dwconv3x3_s2_grid_y", 128, 2, 513, 1025) == 768 // 4
     assert q("seg_dwconv_grid_y", BF16, 2048, 2, 65, 129, 1, 18, 0) == min(2 * 18 * 1, 768 // 64)
     assert q("seg_dwconv_grid_y", BF16, 2048, 2, 65, 129, 1, 6, 1) == min(2 * 6 * 1, 768 // 64)
+
+
+def test_frozen_batchnorm_module_contract():
+    """get_norm('FrozenBN') — segmentron/modules/batch_norm.py:10-104,107-132: four BUFFERS, the
+    reference's state_dict keys, its version-3 loading rule, convert_frozen_batchnorm; 'GN' stays
+    outside the hot path."""
+    import pytest
+    from segmentron_amd import functional as F
+    from segmentron_amd.modules.batch_norm import FrozenBatchNorm2d, get_norm
+    assert get_norm("FrozenBN") is FrozenBatchNorm2d
+    with pytest.raises(NotImplementedError):
+        get_norm("GN")
+    m = FrozenBatchNorm2d(6, eps=1e-3)
+    assert list(m.state_dict().keys()) == ["weight", "bias", "running_mean", "running_var"]
+    assert not list(m.parameters()) and not F.uses_batch_stats(m.train())
+    assert torch.allclose(m.running_var, torch.ones(6) - 1e-3)
+    # version < 3 checkpoints stored running_var WITHOUT the eps correction
+    old = {"weight": torch.full((6,), 2.0), "bias": torch.zeros(6), "running_mean": torch.ones(6),
+           "running_var": torch.full((6,), 4.0)}
+    sd = torch.nn.Module.state_dict(m) | {k: v.clone() for k, v in old.items()}
+    md = {"": {"version": 2}}
+    meta = type(m.state_dict())(sd)
+    meta._metadata = md
+    m.load_state_dict(meta)
+    assert torch.allclose(m.running_var, torch.full((6,), 4.0 - 1e-3))
+    # conversion of a BatchNorm tree (running_var + eps is what the frozen module stores)
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 1), torch.nn.BatchNorm2d(4, eps=1e-2))
+    net[1].running_var.fill_(3.0)
+    net[1].weight.data.fill_(0.5)
+    fz = FrozenBatchNorm2d.convert_frozen_batchnorm(net)
+    assert isinstance(fz[1], FrozenBatchNorm2d) and fz[0] is net[0]
+    assert torch.allclose(fz[1].running_var, torch.full((4,), 3.01))
+    assert torch.allclose(fz[1].weight, torch.full((4,), 0.5))
+    # the reference's formula (batch_norm.py:40-45) is what seg_bn_eval_affine computes
+    x = torch.randn(2, 6, 3, 3)
+    scale = m.weight * (m.running_var + m.eps).rsqrt()
+    ref = x * scale.view(1, -1, 1, 1) + (m.bias - m.running_mean * scale).view(1, -1, 1, 1)
+    want = torch.nn.functional.batch_norm(x, m.running_mean, m.running_var, m.weight, m.bias,
+                                          False, 0.0, m.eps)
+    assert torch.allclose(ref, want, atol=1e-6)

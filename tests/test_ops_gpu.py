@@ -363,6 +363,38 @@ def test_bn_finalize_matches_torch_batch_norm():
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+@pytest.mark.parametrize("shape", [(2, 1, 1), (2, 3, 3), (2, 6, 6), (2, 17, 29)])
+def test_bn_finalize_small_two_pass_statistics_with_a_large_mean(shape, dtype):
+    """seg_bn_finalize_small (r04): BatchNorm over few samples whose spread is tiny against
+    their mean — the 2-sample BatchNorm of the ASPP image-pooling branch (module.py:52-64), PSP's
+    pyramid bins (module.py:89-97) — vs torch.batch_norm in float64 on the values as stored.  The
+    single-pass E[x^2] - mean^2 form on fp32 partial sums is off by up to 100 % here."""
+    N, H, W = shape
+    C = 72
+    base = rnd((1, C, 1, 1), 5) * 3 + 20.0                       # |mean| ~ 20
+    x = quant(base + rnd((N, C, H, W), 6) * 0.02, dtype)         # spread 0.02 (bf16: its ulp grid)
+    gamma, beta = torch.rand(C) + 0.5, rnd((C,), 3, 0.2)
+    rm, rv = rnd((C,), 4, 0.1), torch.rand(C) + 0.5
+    rm_ref, rv_ref = rm.double(), rv.double()
+    y_ref = TF.batch_norm(x.double(), rm_ref, rv_ref, gamma.double(), beta.double(), True, 0.1, 1e-5)
+    buf = to_dev_nhwc(x, dtype, pitch=C + 8)                     # a channel slice: pitch != C
+    rmd, rvd, off = rm.to(DEV), rv.to(DEV), rnd((C,), 8, 0.3)
+    mean, invstd, scale, shift = K().bn_finalize_small(buf, gamma.to(DEV), beta.to(DEV), 1e-5, 0.1,
+                                                       rmd, rvd, off.to(DEV))
+    xd = x.double()
+    y = xd * scale.cpu().double().view(1, -1, 1, 1) + shift.cpu().double().view(1, -1, 1, 1)
+    # y = x*scale + shift cancels 20/0.02 = 3 digits of the fp32 scale / shift: 1e-3 of the output
+    err = ((y - y_ref).abs().max() / y_ref.abs().max()).item()
+    assert err < 2e-3, err
+    var_ref = xd.var((0, 2, 3), unbiased=False)
+    got_var = invstd.cpu().double().pow(-2) - 1e-5
+    assert ((got_var - var_ref).abs() <= 1e-4 * var_ref + 1e-9).all()
+    assert_close(mean.cpu(), xd.mean((0, 2, 3)), torch.float32, "mean")
+    assert_close(rmd.cpu(), rm_ref + 0.1 * off.double(), torch.float32, "running_mean (+ offset)")
+    assert_close(rvd.cpu(), rv_ref, torch.float32, "running_var", fac=5)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
 def test_bn_apply_residual_and_channel_mask(dtype):
     N, C, H, W = 2, 72, 7, 9
     x, r = quant(rnd((N, C, H, W), 1), dtype), quant(rnd((N, C, H, W), 2), dtype)
@@ -744,3 +776,41 @@ def test_fused_cross_entropy_all_ignored_is_nan_like_torch():
     assert torch.isnan(loss)
     loss.backward()
     assert torch.isfinite(lo.grad).all() and float(lo.grad.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+def test_frozen_batchnorm_is_a_constant_affine_in_train_mode(dtype):
+    """get_norm('FrozenBN') (segmentron/modules/batch_norm.py:10-104) behind a conv, module in
+    TRAIN mode: y = relu(conv(x) * scale + shift) with the buffers' constant scale / shift, no
+    statistics, no running-stat update; gradients flow to the conv weight and the input."""
+    import torch.nn as nn
+    from segmentron_amd.modules.batch_norm import FrozenBatchNorm2d
+    Fm = F()
+    N, C, O, H, W = 2, 16, 24, 9, 11
+    x = quant(rnd((N, C, H, W), 1), dtype)
+    conv = nn.Conv2d(C, O, 3, padding=1, bias=False)
+    conv.weight.data = quant(rnd((O, C, 3, 3), 2, 0.2), dtype)
+    bn = FrozenBatchNorm2d(O, eps=1e-3).train()
+    bn.weight.copy_(torch.rand(O) + 0.5)
+    bn.bias.copy_(rnd((O,), 3, 0.3))
+    bn.running_mean.copy_(rnd((O,), 4, 0.2))
+    bn.running_var.copy_(torch.rand(O) + 0.5)
+    before = {k: v.clone() for k, v in bn.state_dict().items()}
+    xr = x.double().requires_grad_()
+    wr = conv.weight.detach().double().requires_grad_()
+    scale = bn.weight.double() * (bn.running_var.double() + bn.eps).rsqrt()
+    ref = torch.relu(TF.conv2d(xr, wr, None, 1, 1) * scale.view(1, -1, 1, 1)
+                     + (bn.bias.double() - bn.running_mean.double() * scale).view(1, -1, 1, 1))
+    g = quant(rnd(tuple(ref.shape), 5), dtype)
+    ref.backward(g.double())
+    conv, bn = conv.to(DEV), bn.to(DEV)
+    xd = to_dev_nhwc(x, dtype).requires_grad_()
+    a = Fm.conv_bn(Fm.Act(xd), conv, bn)
+    a.relu = True
+    y = Fm.materialize(a)
+    assert_close(to_cpu_nchw(y), ref.detach(), dtype, "frozen bn fwd", fac=2)
+    y.backward(to_dev_nhwc(g, dtype))
+    assert_close(to_cpu_nchw(xd.grad), xr.grad, dtype, "frozen bn dx", fac=4)
+    assert_close(conv.weight.grad.cpu(), wr.grad, dtype, "frozen bn dW", fac=4)
+    for k, v in bn.state_dict().items():
+        assert torch.equal(v.cpu(), before[k]), k

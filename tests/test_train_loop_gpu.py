@@ -1,0 +1,118 @@
+"""The reference's UNCHANGED training-loop statements (tools/train.py:135-146) on the HIP path,
+eager launches vs SEGMENTRON_HIP_GRAPH=1 (segmentron_amd.graph.TransparentTrainGraph: forward and
+backward replay captured HIP graphs behind `model(images)` / `losses.backward()`).
+
+    outputs = self.model(images)
+    loss_dict = self.criterion(outputs, targets)
+    losses = sum(loss for loss in loss_dict.values())
+    self.optimizer.zero_grad()
+    losses.backward()
+    self.optimizer.step()
+    self.lr_scheduler.step()
+
+Same kernels on the same operands in the same order, fixed-order reductions -> the two modes must
+agree BIT FOR BIT: every loss, every parameter, every BatchNorm buffer after 7 iterations with a
+different batch each (2 eager warm-up calls, the capturing call, 4 replays), with the optimizer
+and scheduler `segmentron.solver` hands to tools/train.py and a criterion of the reference's
+MixSoftmaxCrossEntropyLoss shape (solver/loss.py:16-46: an nn.CrossEntropyLoss subclass that
+returns dict(loss=...))."""
+import os
+
+import pytest
+import torch
+import torch.nn as nn
+
+from conftest import C3_OVERRIDES
+from oracle import synth
+
+pytestmark = pytest.mark.gpu
+
+
+class MixSoftmaxCrossEntropyLoss(nn.CrossEntropyLoss):
+    """Shape of segmentron/solver/loss.py:16-46 (aux outputs weighted by aux_weight)."""
+
+    def __init__(self, aux=False, aux_weight=0.4, ignore_index=-1):
+        super().__init__(ignore_index=ignore_index)
+        self.aux, self.aux_weight = aux, aux_weight
+
+    def forward(self, *inputs, **kwargs):
+        preds, target = tuple(inputs)
+        loss = super().forward(preds[0], target)
+        for p in preds[1:]:
+            loss = loss + self.aux_weight * super().forward(p, target)
+        return dict(loss=loss)
+
+
+def _run_loop(graph, iters, hw, dtype=torch.bfloat16):
+    import segmentron_amd
+    from segmentron_amd.config import cfg, reset_cfg
+    from segmentron_amd.solver.lr_scheduler import get_scheduler
+    from segmentron_amd.solver.optimizer import get_optimizer
+    prev = os.environ.get("SEGMENTRON_HIP_GRAPH")
+    os.environ["SEGMENTRON_HIP_GRAPH"] = "1" if graph else "0"
+    try:
+        reset_cfg()
+        cfg.update_from_list(C3_OVERRIDES + ["SOLVER.LR", "0.002", "SOLVER.AUX", "True"])
+        cfg.PHASE = "train"
+        cfg.check_and_freeze()
+        segmentron_amd.set_compute_dtype(dtype)
+        model = segmentron_amd.get_segmentation_model()
+        assert (getattr(model, "_transparent_graph", None) is not None) == graph
+        sd = synth.synth_like(model.state_dict(), seed=0, conditioned=True)
+        model.load_state_dict(sd)
+        model = model.to("cuda")
+        criterion = MixSoftmaxCrossEntropyLoss(aux=True, aux_weight=cfg.SOLVER.AUX_WEIGHT,
+                                               ignore_index=cfg.DATASET.IGNORE_INDEX).to("cuda")
+        optimizer = get_optimizer(model)
+        lr_scheduler = get_scheduler(optimizer, max_iters=iters, iters_per_epoch=iters)
+        model.train()
+        for m in model.modules():  # RNG-free: graph replays draw their masks differently
+            if isinstance(m, (nn.Dropout, nn.Dropout2d)):
+                m.p = 0.0
+        H, W = hw
+        losses_seen = []
+        for it in range(iters):
+            images = synth.synth_images(2, H, W, seed=100 + it).to("cuda")
+            targets = synth.synth_targets(2, H, W, seed=100 + it).to("cuda")
+            # ---- tools/train.py:135-146, verbatim
+            outputs = model(images)
+            loss_dict = criterion(outputs, targets)
+            losses = sum(loss for loss in loss_dict.values())
+            optimizer.zero_grad()
+            losses.backward()
+            optimizer.step()
+            lr_scheduler.step()
+            # ----
+            losses_seen.append(losses.item())
+        torch.cuda.synchronize()
+        tg = getattr(model, "_transparent_graph", None)
+        if graph:
+            assert tg.disabled is None, tg.disabled
+            assert len(tg.segments) == 1, "the loop did not reach the captured path"
+        state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        lrs = [g["lr"] for g in optimizer.param_groups]
+        # an evaluation pass on the same object still works (eager, eval mode, no_grad)
+        model.eval()
+        with torch.no_grad():
+            ev = model(synth.synth_images(1, H, W, seed=5).to("cuda"))
+        assert isinstance(ev[0], torch.Tensor) and ev[0].shape == (1, 19, H, W)
+        return losses_seen, state, lrs
+    finally:
+        if prev is None:
+            os.environ.pop("SEGMENTRON_HIP_GRAPH", None)
+        else:
+            os.environ["SEGMENTRON_HIP_GRAPH"] = prev
+        reset_cfg()
+
+
+def test_reference_loop_statements_graph_mode_equals_eager_bit_for_bit():
+    iters, hw = 7, (129, 193)
+    le, se, lre = _run_loop(False, iters, hw)
+    lg, sg, lrg = _run_loop(True, iters, hw)
+    print("train-loop losses eager %s\n           graph %s" % (["%.5f" % v for v in le],
+                                                                ["%.5f" % v for v in lg]))
+    assert le == lg
+    assert lre == lrg
+    bad = [k for k in se if not torch.equal(se[k], sg[k])]
+    assert not bad, bad[:5]
+    assert le[-1] < le[0]  # the loop trains
