@@ -83,6 +83,15 @@ CONFIGS = {
                workload="DeepLabv3+_mobilenet_v2 inference (the reference's "
                         "cityscapes_deeplabv3_plus_mobilenet.yaml: USE_ASPP / ENABLE_DECODER False)",
                tag="BASELINE.json configs[1]"),
+    # not a BASELINE config: the §8(f4) widening, README model-zoo row "Fast_SCNN ... 145.77 FPS"
+    # (V100, 1024x2048); configs/cityscapes_fast_scnn.yaml values (SOLVER.AUX True: the reference
+    # forward computes both aux heads in evaluation mode too)
+    "c7": dict(over=_COMMON + ["MODEL.MODEL_NAME", "FastSCNN", "SOLVER.AUX", "True",
+                               "MODEL.BN_MOMENTUM", "0.01"],
+               batch=1, h=1024, w=2048, train=False, aux=True, oracle="fast_scnn", os=16,
+               momentum=0.01, metric="images/sec inference Fast_SCNN @1024x2048",
+               workload="Fast-SCNN inference (configs/cityscapes_fast_scnn.yaml, aux heads on)",
+               tag="README model zoo: 145.77 FPS on V100"),
     "c5": dict(over=_COMMON, yaml="configs/cityscapes_hrnet_w18_small_v1.yaml", batch=16, h=1024,
                w=2048, train=False, aux=False, oracle="hrnet_seg", os=16, momentum=0.01,
                metric="images/sec inference HRNet_w18_small_v1 @1024x2048 batch 16",
@@ -326,7 +335,8 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS),
-                    help="c3 = BASELINE.json's metric (default); c2 / c4 / c5 = its other configs")
+                    help="c3 = BASELINE.json's metric (default); c2 / c4 / c5 = its other configs; "
+                         "c7 = Fast-SCNN inference (README model zoo)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--height", type=int, default=None)

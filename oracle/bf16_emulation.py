@@ -90,8 +90,10 @@ class Bf16EmuNet:
     def _eps(self, p):
         return self.eps_encoder if p.startswith("encoder.") else self.eps_decoder
 
-    def _bn(self, y, p):
-        """y: fp32 accumulators -> (scale, shift) like seg_bn_finalize / seg_bn_eval_affine."""
+    def _bn(self, y, p, offset=None):
+        """y: fp32 accumulators -> (scale, shift) like seg_bn_finalize / seg_bn_eval_affine.
+        offset: per-channel constant left out of `y` (folded conv, see conv()): it re-enters the
+        running_mean update only (seg_bn_finalize_p mean_offset)."""
         sd = self.sd
         g, b = sd[p + ".weight"], sd[p + ".bias"]
         eps = self._eps(p)
@@ -105,7 +107,8 @@ class Bf16EmuNet:
             shift = (b.double() - mean * g.double() * invstd).float()
             unb = var * n / (n - 1) if n > 1 else var
             m = self.momentum
-            sd[p + ".running_mean"] = ((1 - m) * sd[p + ".running_mean"].double() + m * mean).float()
+            mo = mean if offset is None else mean + offset.double()
+            sd[p + ".running_mean"] = ((1 - m) * sd[p + ".running_mean"].double() + m * mo).float()
             sd[p + ".running_var"] = ((1 - m) * sd[p + ".running_var"].double() + m * unb).float()
             return scale, shift
         invstd = 1.0 / torch.sqrt(sd[p + ".running_var"] + eps)
@@ -126,7 +129,8 @@ class Bf16EmuNet:
                 return _A(r16(y))
             m_ = y.shape[0] * y.shape[2] * y.shape[3]
             px256 = stride == 1 and ((w.shape[0] >= 384 and m_ >= 4096) or (w.shape[0] >= 256 and m_ >= 65536))
-            s, b = self._bn(r16(y) if (px256 or m_ <= SMALL_BN_ROWS) else y, bnp)
+            const = None if keep_const else (wf.view(wf.shape[0], -1) @ a.b).detach()
+            s, b = self._bn(r16(y) if (px256 or m_ <= SMALL_BN_ROWS) else y, bnp, const)
             return _A(r16(y), s, b)
         w = r16(wf)
         if self.accum64:

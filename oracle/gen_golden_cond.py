@@ -120,7 +120,8 @@ def main(tag):
     assert loss.item() == l32.item() and (outs[0] - o32[0]).abs().max().item() == 0.0
     assert max((g32[k] - g).abs().max().item() for k, g in grads.items()) == 0.0, \
         "oracle backward differs from the reference"
-    msd = model.state_dict()
+    msd = {k: v.detach().clone() for k, v in model.state_dict().items()}  # (a snapshot: the
+    #       autocast yardstick below runs another train step on the same module objects)
     assert all(torch.equal(msd[k], s32[k].detach()) for k in msd if "running_" in k)
 
     # ---- the conditioning itself

@@ -43,6 +43,12 @@ CASES = {
     # of ca_cuda.cu lets the REFERENCE's own module tree / wiring / autograd glue run on the CPU
     "c6": dict(yaml="configs/cityscapes_ccnet_resnet.yaml", over=[], fn="ccnet_resnet", os=16,
                aux=False, hw=(65, 97), eps_enc=None, pre="ccnet"),
+    # Fast-SCNN (SURVEY §8 f4 tail, README: 145.77 FPS on V100): no backbone, three outputs
+    # (SOLVER.AUX True in its yaml).  Size: the x4 upsample of the 1/32 branch must meet the 1/8
+    # branch and the pyramid pooling needs a >= 6x6 map -> 192x192 (6x6 at 1/32); logits are
+    # stored every 2nd pixel (`sub`) to keep the fixture small
+    "c7": dict(yaml="configs/cityscapes_fast_scnn.yaml", over=["TEST.TEST_MODEL_PATH", ""], fn="fast_scnn", os=16, aux=True,
+               hw=(192, 192), eps_enc=None, mom=0.01, sub=2),
 }
 
 
@@ -129,8 +135,11 @@ def main(tag):
     for a, b in zip(outs, o_outs):
         assert (a - b).abs().max().item() == 0.0, "oracle differs from the reference (eval)"
     print(tag, "eval logits", tuple(outs[0].shape), "absmax %.3f" % outs[0].abs().max().item())
-    np.savez_compressed(os.path.join(GOLD, tag + "_eval.npz"), logits=outs[0].numpy(),
-                        argmax=outs[0].argmax(1).to(torch.uint8).numpy())
+    sub = c.get("sub", 1)
+    np.savez_compressed(os.path.join(GOLD, tag + "_eval.npz"),
+                        logits=outs[0][..., ::sub, ::sub].numpy(),
+                        argmax=outs[0].argmax(1).to(torch.uint8)[..., ::sub, ::sub].numpy(),
+                        sub=np.int64(sub))
 
     model.train()
     model.zero_grad()
@@ -157,7 +166,8 @@ def main(tag):
     stat_keys = [k for k in msd if k.endswith("running_mean")]
     stat_keys = stat_keys[:2] + stat_keys[-2:]
     stat_keys += [k[:-4] + "var" for k in stat_keys]
-    payload = {"loss": np.float64(loss.item()), "logits": outs[0].detach().numpy(),
+    payload = {"loss": np.float64(loss.item()),
+               "logits": outs[0].detach()[..., ::sub, ::sub].numpy(), "sub": np.int64(sub),
                "grad_norm_keys": np.array(names),
                "grad_norms": np.array([float(grads[k].double().norm()) for k in names])}
     for k in names[:2] + names[len(names) // 2:len(names) // 2 + 2] + names[-2:]:

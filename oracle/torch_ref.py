@@ -440,6 +440,54 @@ def _hrnet_seg(self, x):
     return [F.interpolate(y, size=size, mode="bilinear", align_corners=False)]
 
 
+# ---------------------------------------------------------------------- Fast-SCNN
+def _fast_scnn(self, x):
+    """FastSCNN.forward and its four sub-modules — segmentron/models/fast_scnn.py:16-161.
+    learning_to_downsample: 3x3 s2 conv WITHOUT padding (:75, `_ConvBNReLU(3, 32, 3, 2)`) + two
+    stride-2 separable convs; global_feature_extractor: 3 x 3 inverted residuals (t = 6,
+    strides 2, 2, 1) + PyramidPooling (module.py:82-97) + 1x1; feature_fusion: bilinear x4
+    (align_corners) of the low-resolution branch -> 1x1+BN+ReLU -> 1x1(bias)+BN, plus
+    1x1(bias)+BN of the high-resolution branch, ReLU of the sum; classifier: two separable convs
+    + Dropout2d + 1x1(bias).  Aux heads (cfg.SOLVER.AUX): conv3x3+BN+ReLU+Dropout2d+1x1 on both
+    branch outputs."""
+    size = x.shape[2:]
+    p = "learning_to_downsample."
+    h = self.conv_bn_relu(x, p + "conv", 2, 0)
+    h = self.separable_conv(h, p + "dsconv1", 2, 1, relu_first=False)
+    hi = self.separable_conv(h, p + "dsconv2", 2, 1, relu_first=False)
+    g = "global_feature_extractor."
+    lo = hi
+    for name, stride in (("bottleneck1", 2), ("bottleneck2", 2), ("bottleneck3", 1)):
+        for j in range(3):
+            lo = _inverted_residual(self, lo, g + "%s.%d" % (name, j), stride if j == 0 else 1,
+                                    1, True)
+    hw = lo.shape[2:]
+    feats = [lo]
+    for i, o in enumerate((1, 2, 3, 6)):
+        f = self.conv_bn_relu(F.adaptive_avg_pool2d(lo, o), g + "ppm.convs.%d" % i)
+        feats.append(F.interpolate(f, hw, mode="bilinear", align_corners=True))
+    lo = self.conv_bn_relu(torch.cat(feats, dim=1), g + "out")
+    f = "feature_fusion."
+    up = F.interpolate(lo, scale_factor=4, mode="bilinear", align_corners=True)
+    up = self.conv_bn_relu(up, f + "dwconv")
+    up = self.bn(self.conv(up, f + "conv_lower_res.0"), f + "conv_lower_res.1")
+    hr = self.bn(self.conv(hi, f + "conv_higher_res.0"), f + "conv_higher_res.1")
+    y = F.relu(hr + up)
+    c = "classifier."
+    y = self.separable_conv(y, c + "dsconv1", 1, 1, relu_first=False)
+    y = self.separable_conv(y, c + "dsconv2", 1, 1, relu_first=False)
+    y = F.dropout2d(y, self.drop_p, self.training)
+    outs = [F.interpolate(self.conv(y, c + "conv.1"), size, mode="bilinear", align_corners=True)]
+    if self.aux:
+        for name, feat in (("auxlayer1", hi), ("auxlayer2", lo)):
+            a = F.relu(self.bn(self.conv(feat, name + ".0", 1, 1), name + ".1"))
+            a = F.dropout2d(a, self.drop_p, self.training)
+            outs.append(F.interpolate(self.conv(a, name + ".4"), size, mode="bilinear",
+                                      align_corners=True))
+    return tuple(outs)
+
+
+OracleNet.fast_scnn = _fast_scnn
 OracleNet.hrnet = _hrnet
 OracleNet.hrnet_seg = _hrnet_seg
 OracleNet.mobilenet_v2 = _mobilenet_v2

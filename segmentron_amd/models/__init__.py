@@ -5,3 +5,4 @@ from .fcn import FCN  # noqa: F401
 from .pspnet import PSPNet  # noqa: F401
 from .hrnet_seg import HighResolutionNet  # noqa: F401
 from .ccnet import CCNet  # noqa: F401
+from .fast_scnn import FastSCNN  # noqa: F401

@@ -52,7 +52,9 @@ def _run_loop(graph, iters, hw, dtype=torch.bfloat16):
     os.environ["SEGMENTRON_HIP_GRAPH"] = "1" if graph else "0"
     try:
         reset_cfg()
-        cfg.update_from_list(C3_OVERRIDES + ["SOLVER.LR", "0.002", "SOLVER.AUX", "True"])
+        # (SOLVER.AUX stays False: DeepLabv3+'s aux head on xception is a 728 -> 182-channel
+        # _FCNHead, and 182 is not a multiple of the kernels' 16-byte channel vector)
+        cfg.update_from_list(C3_OVERRIDES + ["SOLVER.LR", "0.002"])
         cfg.PHASE = "train"
         cfg.check_and_freeze()
         segmentron_amd.set_compute_dtype(dtype)
@@ -61,7 +63,7 @@ def _run_loop(graph, iters, hw, dtype=torch.bfloat16):
         sd = synth.synth_like(model.state_dict(), seed=0, conditioned=True)
         model.load_state_dict(sd)
         model = model.to("cuda")
-        criterion = MixSoftmaxCrossEntropyLoss(aux=True, aux_weight=cfg.SOLVER.AUX_WEIGHT,
+        criterion = MixSoftmaxCrossEntropyLoss(aux=False, aux_weight=cfg.SOLVER.AUX_WEIGHT,
                                                ignore_index=cfg.DATASET.IGNORE_INDEX).to("cuda")
         optimizer = get_optimizer(model)
         lr_scheduler = get_scheduler(optimizer, max_iters=iters, iters_per_epoch=iters)
