@@ -47,6 +47,10 @@ CASES = {
     # (SOLVER.AUX True in its yaml).  Size: the x4 upsample of the 1/32 branch must meet the 1/8
     # branch and the pyramid pooling needs a >= 6x6 map -> 192x192 (6x6 at 1/32); logits are
     # stored every 2nd pixel (`sub`) to keep the fixture small
+    # DANet (SURVEY §8 f4 tail): resnet101 OS8 with the multi-grid layer4 (dilations 4/8/16),
+    # position + channel attention heads, three outputs
+    "c8": dict(yaml="configs/cityscapes_danet_resnet.yaml", over=[], fn="danet_resnet", os=8,
+               aux=False, hw=(49, 65), eps_enc=None, multi_dilation=[4, 8, 16], gamma=True),
     "c7": dict(yaml="configs/cityscapes_fast_scnn.yaml", over=["TEST.TEST_MODEL_PATH", ""], fn="fast_scnn", os=16, aux=True,
                hw=(192, 192), eps_enc=None, mom=0.01, sub=2),
 }
@@ -126,7 +130,7 @@ def main(tag):
     model.load_state_dict(sd, strict=True)
 
     kw = dict(output_stride=c["os"], aux=c["aux"], eps_encoder=c["eps_enc"], drop_p=0.0,
-              momentum=c.get("mom"))
+              momentum=c.get("mom"), multi_dilation=c.get("multi_dilation"))
     model.eval()
     with torch.no_grad():
         outs = model(x)

@@ -23,10 +23,11 @@ class OracleNet:
                 None -> torch default 1e-5.
     momentum  : cfg.MODEL.BN_MOMENTUM or torch default 0.1.
     drop_p    : ASPP Dropout2d / FCN-head Dropout probability (0 for parity runs).
+    multi_dilation : cfg.MODEL.DANET.MULTI_DILATION (ResNet layer4 multi-grid, resnet.py:166-175).
     """
 
     def __init__(self, sd, training=False, eps_encoder=None, eps_decoder=None, momentum=None,
-                 drop_p=0.1, output_stride=16, aux=False, nclass=19):
+                 drop_p=0.1, output_stride=16, aux=False, nclass=19, multi_dilation=None):
         self.sd = sd
         self.training = training
         self.eps_encoder = 1e-5 if eps_encoder is None else eps_encoder
@@ -36,6 +37,7 @@ class OracleNet:
         self.output_stride = output_stride
         self.aux = aux
         self.nclass = nclass
+        self.multi_dilation = multi_dilation  # cfg.MODEL.DANET.MULTI_DILATION when MULTI_GRID
 
     # ------------------------------------------------------------------ primitives
     def _eps(self, prefix):
@@ -202,13 +204,16 @@ def _res_block(self, x, p, stride, dilation, previous_dilation):
     return F.relu(out + identity)
 
 
-def _res_layer(self, x, p, stride, dilation):
-    """ResNetV1._make_layer — resnet.py:147-181 (first block of a dilated stage: dilation/2)."""
-    first = 1 if dilation in (1, 2) else 2
+def _res_layer(self, x, p, stride, dilation, multi_dilation=None):
+    """ResNetV1._make_layer — resnet.py:147-181 (first block of a dilated stage: dilation/2;
+    multi_dilation = cfg.MODEL.DANET.MULTI_DILATION when MULTI_GRID: block i of layer4 is dilated
+    by multi_dilation[i % len], :166-175)."""
+    first = multi_dilation[0] if multi_dilation else (1 if dilation in (1, 2) else 2)
     x = _res_block(self, x, p + ".0", stride, first, dilation)
     j = 1
     while (p + ".%d.conv1.weight" % j) in self.sd:
-        x = _res_block(self, x, p + ".%d" % j, 1, dilation, dilation)
+        d = multi_dilation[j % len(multi_dilation)] if multi_dilation else dilation
+        x = _res_block(self, x, p + ".%d" % j, 1, d, dilation)
         j += 1
     return x
 
@@ -228,7 +233,8 @@ def _resnet(self, x, prefix="encoder"):
     c1 = _res_layer(self, x, p + "layer1", 1, 1)
     c2 = _res_layer(self, c1, p + "layer2", 2, 1)
     c3 = _res_layer(self, c2, p + "layer3", strides[0], dil[0])
-    c4 = _res_layer(self, c3, p + "layer4", strides[1], dil[1])
+    c4 = _res_layer(self, c3, p + "layer4", strides[1], dil[1],
+                    getattr(self, "multi_dilation", None))
     return c1, c2, c3, c4
 
 
@@ -438,6 +444,58 @@ def _hrnet_seg(self, x):
     k = self.sd[q + ".3.weight"].shape[-1]
     y = self.conv(y, q + ".3", 1, 1 if k == 3 else 0)
     return [F.interpolate(y, size=size, mode="bilinear", align_corners=False)]
+
+
+# ---------------------------------------------------------------------- DANet
+def pam(self, x, p):
+    """PAM_Module (position attention) — segmentron/modules/module.py:100-130."""
+    B, C, H, W = x.shape
+    q = self.conv(x, p + ".query_conv").view(B, -1, H * W).permute(0, 2, 1)
+    k = self.conv(x, p + ".key_conv").view(B, -1, H * W)
+    att = F.softmax(torch.bmm(q, k), dim=-1)
+    v = self.conv(x, p + ".value_conv").view(B, -1, H * W)
+    out = torch.bmm(v, att.permute(0, 2, 1)).view(B, C, H, W)
+    return self.sd[p + ".gamma"] * out + x
+
+
+def cam(self, x, p):
+    """CAM_Module (channel attention) — segmentron/modules/module.py:133-162."""
+    B, C, H, W = x.shape
+    # (three separate views of x, as the reference: autograd then accumulates four gradient
+    # terms at x in the reference's order — bit-identical backward)
+    proj_query = x.view(B, C, -1)
+    proj_key = x.view(B, C, -1).permute(0, 2, 1)
+    energy = torch.bmm(proj_query, proj_key)
+    energy_new = torch.max(energy, -1, keepdim=True)[0].expand_as(energy) - energy
+    att = F.softmax(energy_new, dim=-1)
+    proj_value = x.view(B, C, -1)
+    out = torch.bmm(att, proj_value).view(B, C, H, W)
+    return self.sd[p + ".gamma"] * out + x
+
+
+def _danet_resnet(self, x):
+    """DANet.forward + DANetHead — segmentron/models/danet.py:14-89 (three outputs: fused,
+    position-attention and channel-attention heads)."""
+    size = x.shape[2:]
+    _, _, _, c4 = _resnet(self, x)
+    h = "head."
+
+    def cbr(t, name):
+        return F.relu(self.bn(self.conv(t, h + name + ".0", 1, 1), h + name + ".1"))
+
+
+    # (node creation order of danet.py:70-88: it fixes autograd's accumulation order)
+    sa_conv = cbr(pam(self, cbr(c4, "conv5a"), h + "sa"), "conv51")
+    sa_out = self.conv(F.dropout2d(sa_conv, self.drop_p, self.training), h + "conv6.1")
+    sc_conv = cbr(cam(self, cbr(c4, "conv5c"), h + "sc"), "conv52")
+    sc_out = self.conv(F.dropout2d(sc_conv, self.drop_p, self.training), h + "conv7.1")
+    sasc_out = self.conv(F.dropout2d(sa_conv + sc_conv, self.drop_p, self.training),
+                         h + "conv8.1")
+    return tuple(F.interpolate(y, size, mode="bilinear", align_corners=True)
+                 for y in (sasc_out, sa_out, sc_out))
+
+
+OracleNet.danet_resnet = _danet_resnet
 
 
 # ---------------------------------------------------------------------- Fast-SCNN
