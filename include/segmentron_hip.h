@@ -343,6 +343,18 @@ int seg_cca_map(int dtype, const float* wt, const void* b, long ldb, int N, int 
                 int transposed, const float* gamma, const void* res, long ldres, void* out,
                 long ldo, void* raw, long ldraw, void* stream);
 
+/* ---- DANet position / channel attention (segmentron/modules/module.py:100-162).  The two
+ * torch.bmm of each module are GEMMs on the convolution entry points (seg_conv_gemm_fwd = NT,
+ * seg_conv_gemm_wgrad = TN); the softmax between them (nn.Softmax(dim=-1), module.py:110,141):
+ *   seg_row_softmax     : a[r][j] = softmax_j(sign * e[r][j]) for j < L, 0 for L <= j < Lp
+ *   seg_row_softmax_bwd : de[r][j] = sign * a[r][j] * (g[r][j] - sum_j a[r][j] g[r][j])
+ * e / a / g / de: row-major [R][pitch], element type DT_F32 (0) or DT_BF16 (1) given per operand;
+ * sign = -1 is CAM's softmax(max(energy) - energy) (shift invariance). */
+int seg_row_softmax(const void* e, int dt_in, long lde, void* a, int dt_out, long lda, long R,
+                    int L, int Lp, float sign, void* stream);
+int seg_row_softmax_bwd(const void* a, int dt_a, long lda, const void* g, int dt_g, long ldg,
+                        void* de, int dt_out, long ldde, long R, int L, int Lp, float sign,
+                        void* stream);
 /* ---- SyncBatchNorm statistics exchange: one-hop xGMI peer writes ----------------------------
  * Replaces, for the data-parallel path of tools/train.py:73-79 (convert_sync_batchnorm +
  * DistributedDataParallel), the two collectives per BatchNorm that torch's SyncBatchNorm issues

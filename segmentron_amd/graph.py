@@ -233,24 +233,36 @@ class TransparentTrainGraph:
         model = self.model
         seg = _Segment()
         seg.x = x.clone()
-        seg.params = [p for p in model.parameters() if p.requires_grad]
+        named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+        seg.params = [p for _, p in named]
+        # The captured passes run on fresh LEAF ALIASES of the parameters (same storage, same
+        # version counter).  A parameter's AccumulateGrad node is created once and stays bound to
+        # the stream it was created on for as long as any autograd graph references it — in the
+        # reference loop the previous iteration's `losses` still does at this point — and the
+        # engine then makes THAT stream (the legacy default stream) wait for the capturing one:
+        # the default stream is dragged into the capture, never re-joined, and hipStreamEndCapture
+        # dies (measured r04, AMD_LOG_LEVEL=3: `hipStreamWaitEvent(stream:<null>, ...)` inside the
+        # capture).  The aliases get their gradient edges created inside the capture.
+        leaves = [p.detach().requires_grad_(True) for p in seg.params]
         seg.anchor = torch.zeros((), device=x.device, requires_grad=True)
         torch.cuda.synchronize()
         F.clear_weight_cache()  # the weight packs must be issued INSIDE the captured forward
         pool = torch.cuda.graph_pool_handle()
         seg.fwd, seg.bwd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         with torch.cuda.graph(seg.fwd, pool=pool):
-            outs = self.eager_forward(seg.x)
+            outs = torch.func.functional_call(model, {n: t for (n, _), t in zip(named, leaves)},
+                                              (seg.x,))
         if not all(isinstance(o, F.LogitsView) for o in outs):
             raise RuntimeError("transparent capture needs LogitsView outputs (training mode)")
         seg.lo = [o.lo for o in outs]
         seg.meta = [(o.out_hw, o.align_corners) for o in outs]
         seg.grad_lo = [torch.zeros_like(t) for t in seg.lo]
         with torch.cuda.graph(seg.bwd, pool=pool):
-            grads = torch.autograd.grad(seg.lo, seg.params, seg.grad_lo, allow_unused=True)
+            grads = torch.autograd.grad(seg.lo, leaves, seg.grad_lo, allow_unused=True)
         seg.grads = [None if g is None else (g if g.is_contiguous() else g.contiguous())
                      for g in grads]
         torch.cuda.synchronize()
+        F.clear_weight_cache()  # (entries keyed on the aliases)
         return seg
 
 
