@@ -877,6 +877,128 @@ class _CCAFn(torch.autograd.Function):
         return dq, dk, dv, dx, dgamma
 
 
+def _scaled(t, gamma32, residual=None):
+    """gamma * t (+ residual) on the element-wise HIP kernel (per-channel scale = gamma)."""
+    C = t.shape[-1]
+    sc = gamma32.expand(C).contiguous()
+    zero = torch.zeros(C, dtype=torch.float32, device=t.device)
+    return K.bn_apply(t, (PRO_AFFINE, sc, zero), residual, None if residual is None
+                      else (PRO_NONE, None, None))
+
+
+def _dot(a, b):
+    """<a, b> over all elements -> float32 [1] (column sums of a*b, then a tiny sum)."""
+    C = a.shape[-1]
+    return K.bn_bwd_reduce(a, b, (PRO_NONE, None, None))[C:2 * C].sum().float().view(1)
+
+
+class _PAMFn(torch.autograd.Function):
+    """DANet position attention (segmentron/modules/module.py:100-130) on plain NHWC tensors:
+        out = gamma * (softmax_j(q_p . k_j) @ v) + x,   p, j over the H*W pixels of one image.
+    Both torch.bmm are MFMA GEMMs (K.gemm_nt / K.gemm_tn = the 1x1-convolution kernels), the
+    softmax a row kernel (csrc/attention.hip); per image, the [HW, HW] attention matrix is kept
+    for backward like the reference keeps it.  HW is padded to the channel vector with masked
+    (zero-weight) columns."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, x, gamma):
+        N, H, W, C = x.shape
+        P, dt = H * W, x.dtype
+        vec = K.vec_of(dt)
+        Pp = _round_up(P, vec)
+        g32 = gamma.detach().float().contiguous()
+        raw = torch.empty((N, H, W, C), dtype=dt, device=x.device)
+        atts = []
+        for n in range(N):
+            kp = torch.zeros((Pp, k.shape[-1]), dtype=dt, device=x.device)
+            kp[:P] = k[n].reshape(P, -1)
+            e = K.gemm_nt(q[n].reshape(P, -1).contiguous(), kp)
+            a = K.row_softmax(e, P, dt)
+            vt = torch.zeros((C, Pp), dtype=dt, device=x.device)
+            vt[:, :P] = v[n].reshape(P, C).t()
+            raw[n] = K.gemm_nt(a, vt).view(H, W, C)
+            atts.append(a)
+        ctx.save_for_backward(q, k, v, raw, g32, *atts)
+        return _scaled(raw, g32, x)
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, raw, g32 = ctx.saved_tensors[:5]
+        atts = ctx.saved_tensors[5:]
+        N, H, W, C = raw.shape
+        P, dt = H * W, raw.dtype
+        Pp = atts[0].shape[1]
+        dout = dout.contiguous()
+        dgamma = _dot(dout, raw) if ctx.needs_input_grad[4] else None
+        do = _scaled(dout, g32)
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        for n in range(N):
+            a, don = atts[n], do[n].reshape(P, C)
+            dv[n] = K.gemm_tn(a, don)[:P].to(dt).view(H, W, C)
+            vp = torch.zeros((Pp, C), dtype=dt, device=raw.device)
+            vp[:P] = v[n].reshape(P, C)
+            de = K.row_softmax_bwd(a, K.gemm_nt(don, vp), P, dt)
+            kt = torch.zeros((k.shape[-1], Pp), dtype=dt, device=raw.device)
+            kt[:, :P] = k[n].reshape(P, -1).t()
+            dq[n] = K.gemm_nt(de, kt).view(H, W, -1)
+            dk[n] = K.gemm_tn(de, q[n].reshape(P, -1).contiguous())[:P].to(dt).view(H, W, -1)
+        return dq, dk, dv, dout, dgamma
+
+
+class _CAMFn(torch.autograd.Function):
+    """DANet channel attention (segmentron/modules/module.py:133-162):
+        out = gamma * (softmax_c'(max - X^T X) @ X^T)^T + x  =  gamma * X softmax(-E)^T + x,
+    E = X^T X the [C, C] Gram matrix of one image's [HW, C] features (softmax is shift
+    invariant, so `max(energy) - energy` is softmax(-energy) and the row maximum carries no
+    gradient).  E comes from the TN GEMM in float32, the products with X are NT GEMMs."""
+
+    @staticmethod
+    def forward(ctx, x, gamma):
+        N, H, W, C = x.shape
+        P, dt = H * W, x.dtype
+        g32 = gamma.detach().float().contiguous()
+        raw = torch.empty_like(x)
+        atts = []
+        for n in range(N):
+            xn = x[n].reshape(P, C).contiguous()
+            a = K.row_softmax(K.gemm_tn(xn, xn), C, dt, sign=-1.0)   # [C, C']
+            raw[n] = K.gemm_nt(xn, a).view(H, W, C)                   # sum_c' a[c, c'] x[p, c']
+            atts.append(a)
+        ctx.save_for_backward(x, raw, g32, *atts)
+        return _scaled(raw, g32, x)
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, raw, g32 = ctx.saved_tensors[:3]
+        atts = ctx.saved_tensors[3:]
+        N, H, W, C = x.shape
+        P, dt = H * W, x.dtype
+        dout = dout.contiguous()
+        dgamma = _dot(dout, raw) if ctx.needs_input_grad[1] else None
+        do = _scaled(dout, g32)
+        dx = torch.empty_like(x)
+        for n in range(N):
+            a, xn, don = atts[n], x[n].reshape(P, C).contiguous(), do[n].reshape(P, C)
+            de = K.row_softmax_bwd(a, K.gemm_tn(don, xn), C, torch.float32, sign=-1.0)
+            sym = (de + de.t()).to(dt)                     # d/dX of X^T X: both factors ([C, C])
+            # dX = dO a (through the value product) + X (dE + dE^T) (through the Gram matrix)
+            g1 = K.gemm_nt(don, a.t().contiguous()).view(1, H, W, C)
+            g2 = K.gemm_nt(xn, sym).view(1, H, W, C)
+            K.bn_apply(g1, None, g2, None, out=dx[n:n + 1])
+        dx = K.bn_apply(dx, None, dout, None)              # + the residual path's gradient
+        return dx, dgamma
+
+
+def position_attention(q, k, v, x, gamma):
+    """Plain NHWC tensors -> gamma * PAM(q, k, v) + x (module.py:100-130)."""
+    return _PAMFn.apply(q, k, v, x, gamma)
+
+
+def channel_attention(x, gamma):
+    """Plain NHWC tensor -> gamma * CAM(x) + x (module.py:133-162)."""
+    return _CAMFn.apply(x, gamma)
+
+
 # ----------------------------------------------------------------------------- functional API
 def conv_bn(act, conv, bn=None, out=None):
     """conv (nn.Conv2d, groups=1) [+ BatchNorm statistics].  Returns an Act whose BN (if any) and

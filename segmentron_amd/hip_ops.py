@@ -767,6 +767,44 @@ def metric_update_upsample(lo, target, align_corners, nclass, counters):
     return counters
 
 
+# ----------------------------------------------------------------------------- DANet attention
+def row_softmax(e, L, out_dtype, sign=1.0):
+    """e [R, Lp] (fp32 or bf16, row-major) -> a [R, Lp] in out_dtype: softmax over the first L
+    columns of sign * e, zeros in the padding columns."""
+    R, Lp = e.shape
+    assert e.is_cuda and e.stride(1) == 1
+    a = torch.empty((R, Lp), dtype=out_dtype, device=e.device)
+    LIB.call("seg_row_softmax", _p(e), _DT[e.dtype], e.stride(0), _p(a), _DT[out_dtype], Lp, R, L,
+             Lp, float(sign), _stream())
+    return a
+
+
+def row_softmax_bwd(a, g, L, out_dtype, sign=1.0):
+    """de = sign * a * (g - sum_j a g) over the first L columns (zeros behind)."""
+    R, Lp = a.shape
+    assert a.stride(1) == 1 and g.stride(1) == 1 and tuple(g.shape) == (R, Lp)
+    de = torch.empty((R, Lp), dtype=out_dtype, device=a.device)
+    LIB.call("seg_row_softmax_bwd", _p(a), _DT[a.dtype], a.stride(0), _p(g), _DT[g.dtype],
+             g.stride(0), _p(de), _DT[out_dtype], Lp, R, L, Lp, float(sign), _stream())
+    return de
+
+
+def gemm_nt(a, b):
+    """a [P, K], b [O, K] (both compute dtype, row-major, K and O multiples of the channel
+    vector) -> a @ b.T [P, O] in the compute dtype: a 1x1 convolution of the P "pixels" of a
+    (seg_conv_gemm_fwd — fp32 MFMA accumulation)."""
+    P, Kd = a.shape
+    y, _ = conv_gemm(a.view(1, 1, P, Kd), b, b.shape[0], 1, 1, 1, 0, 1)
+    return y.view(P, b.shape[0])
+
+
+def gemm_tn(a, b):
+    """a [P, M], b [P, K] -> a.T @ b [M, K] float32: the weight-gradient GEMM of a 1x1
+    convolution (seg_conv_gemm_wgrad: sum over the P pixels, fixed-order fp32 partials)."""
+    P, M = a.shape
+    return conv_wgrad(b.view(1, 1, P, b.shape[1]), a.view(1, 1, P, M), M, 1, 1, 1, 0, 1)
+
+
 # ----------------------------------------------------------------------------- criss-cross attention
 def cca_attention(q, k):
     """q, k NHWC [N,H,W,C'] -> fp32 attention [N,H,W,W+H-1] = softmax over the criss-cross set."""

@@ -6,3 +6,4 @@ from .pspnet import PSPNet  # noqa: F401
 from .hrnet_seg import HighResolutionNet  # noqa: F401
 from .ccnet import CCNet  # noqa: F401
 from .fast_scnn import FastSCNN  # noqa: F401
+from .danet import DANet  # noqa: F401

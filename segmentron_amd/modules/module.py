@@ -8,7 +8,7 @@ from .. import functional as F
 from ..config import cfg
 from .basic import SeparableConv2d, _ConvBNReLU
 
-__all__ = ["_ASPP", "_FCNHead", "PyramidPooling"]
+__all__ = ["_ASPP", "_FCNHead", "PyramidPooling", "PAM_Module", "CAM_Module"]
 
 
 class _FCNHead(nn.Module):
@@ -133,3 +133,38 @@ class _ASPP(nn.Module):
             keep = torch.rand((N, oc), device=x.device) >= p
             mul = keep.float() / (1.0 - p)
         return y, mul
+
+
+class PAM_Module(nn.Module):
+    """Position attention module (module.py:100-130): out = gamma * (V softmax(Q^T K)^T) + x.
+    Parameter container with the reference's names; forward on functional.position_attention
+    (MFMA GEMMs + the row-softmax kernel).  Takes / returns plain NHWC tensors."""
+
+    def __init__(self, in_dim):
+        super().__init__()
+        self.chanel_in = in_dim
+        self.query_conv = nn.Conv2d(in_channels=in_dim, out_channels=in_dim // 8, kernel_size=1)
+        self.key_conv = nn.Conv2d(in_channels=in_dim, out_channels=in_dim // 8, kernel_size=1)
+        self.value_conv = nn.Conv2d(in_channels=in_dim, out_channels=in_dim, kernel_size=1)
+        self.gamma = nn.Parameter(torch.zeros(1))
+        self.softmax = nn.Softmax(dim=-1)
+
+    def forward(self, x):
+        xa = F.Act(x)
+        q = F.conv_bn(xa, self.query_conv).t
+        k = F.conv_bn(xa, self.key_conv).t
+        v = F.conv_bn(xa, self.value_conv).t
+        return F.position_attention(q, k, v, x, self.gamma)
+
+
+class CAM_Module(nn.Module):
+    """Channel attention module (module.py:133-162): out = gamma * (softmax(max - X X^T) X) + x."""
+
+    def __init__(self, in_dim):
+        super().__init__()
+        self.chanel_in = in_dim
+        self.gamma = nn.Parameter(torch.zeros(1))
+        self.softmax = nn.Softmax(dim=-1)
+
+    def forward(self, x):
+        return F.channel_attention(x, self.gamma)

@@ -29,6 +29,11 @@ CASES = {
     # stood in by the oracle's restatement of ca_cuda.cu (oracle/gen_golden_more.py c6)
     "c6": dict(model="CCNet", backbone="resnet101", os=16, aux=False, fn="ccnet_resnet",
                hw=(65, 97), aux_weight=0.4),
+    # DANet (SURVEY §8 f4 tail; configs/cityscapes_danet_resnet.yaml: OS8, multi-grid layer4):
+    # three outputs (fused / position / channel heads), all weighted into the loss
+    "c8": dict(model="DANet", backbone="resnet101", os=8, aux=False, fn="danet_resnet",
+               hw=(49, 65), aux_weight=0.4, nout=3, multi_dilation=[4, 8, 16],
+               over=["MODEL.DANET.MULTI_GRID", "True", "MODEL.DANET.MULTI_DILATION", "[4, 8, 16]"]),
     # Fast-SCNN (SURVEY §8 f4 tail; configs/cityscapes_fast_scnn.yaml: AUX True, BN momentum 0.01)
     "c7": dict(model="FastSCNN", backbone="", os=16, aux=True, fn="fast_scnn", hw=(192, 192),
                aux_weight=0.4, momentum=0.01, tie_delta=1e-5),
@@ -101,7 +106,7 @@ def _oracle_impl(tag, sd, x, training, dtype=torch.float32, y=None):
     s = {k: (v.to(dtype) if v.is_floating_point() else v.clone()) for k, v in sd.items()}
     s = torch_ref.clone_state(s, requires_grad=training)
     net = torch_ref.OracleNet(s, training=training, output_stride=c["os"], aux=c["aux"], drop_p=0.0,
-                              momentum=c.get("momentum"))
+                              momentum=c.get("momentum"), multi_dilation=c.get("multi_dilation"))
     outs = getattr(net, c["fn"])(x.to(dtype))
     if not training:
         return outs, None, None
@@ -184,7 +189,7 @@ def test_hip_eval_fp32_matches_reference_fixture(tag):
     x = synth.synth_images(2, H, W, seed=0)
     with torch.no_grad():
         outs = model(x.cuda())
-    assert len(outs) == ((3 if tag == "c7" else 2) if CASES[tag]["aux"] else 1)
+    assert len(outs) == CASES[tag].get("nout", (3 if tag == "c7" else 2) if CASES[tag]["aux"] else 1)
     g = np.load(os.path.join(GOLDEN, tag + "_eval.npz"))
     logits = _sub(outs[0].cpu(), g)
     rel = _rel(logits, torch.from_numpy(g["logits"]))

@@ -814,3 +814,52 @@ def test_frozen_batchnorm_is_a_constant_affine_in_train_mode(dtype):
     assert_close(conv.weight.grad.cpu(), wr.grad, dtype, "frozen bn dW", fac=4)
     for k, v in bn.state_dict().items():
         assert torch.equal(v.cpu(), before[k]), k
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+@pytest.mark.parametrize("hw", [(7, 9), (8, 8)])
+def test_danet_position_and_channel_attention_fwd_bwd(hw, dtype):
+    """functional.position_attention / channel_attention (DANet PAM / CAM,
+    segmentron/modules/module.py:100-162) vs the reference formulas in float64: torch.bmm ->
+    softmax -> torch.bmm, gamma * out + x; forward and every gradient.  H*W = 63 exercises the
+    masked padding columns of the attention matrix."""
+    Fm = F()
+    N, C, D = 2, 32, 8
+    H, W = hw
+    fac = 3 if dtype == torch.float32 else 6
+    x = quant(rnd((N, C, H, W), 1, 0.7), dtype)
+    q, k = quant(rnd((N, D, H, W), 2, 0.8), dtype), quant(rnd((N, D, H, W), 3, 0.8), dtype)
+    v = quant(rnd((N, C, H, W), 4), dtype)
+    gamma = torch.tensor([0.7])
+    g = quant(rnd((N, C, H, W), 5), dtype)
+    # ---- PAM
+    leaves = [t.double().requires_grad_() for t in (q, k, v, x, gamma)]
+    qr, kr, vr, xr, gr = leaves
+    pq = qr.view(N, -1, H * W).permute(0, 2, 1)
+    att = torch.softmax(torch.bmm(pq, kr.view(N, -1, H * W)), dim=-1)
+    ref = gr * torch.bmm(vr.view(N, -1, H * W), att.permute(0, 2, 1)).view(N, C, H, W) + xr
+    ref.backward(g.double())
+    dev = [to_dev_nhwc(t, dtype).requires_grad_() for t in (q, k, v, x)]
+    gd = gamma.to(DEV).requires_grad_()
+    y = Fm.position_attention(*dev, gd)
+    assert_close(to_cpu_nchw(y), ref.detach(), dtype, "PAM fwd", fac=fac)
+    y.backward(to_dev_nhwc(g, dtype))
+    for name, d, r in zip("qkvx", dev, leaves):
+        assert_close(to_cpu_nchw(d.grad), r.grad, dtype, "PAM d" + name, fac=fac)
+    # (d gamma = <dout, raw>: ONE scalar out of a cancelling sum over N*H*W*C bf16 products)
+    assert_close(gd.grad.cpu(), gr.grad, dtype, "PAM dgamma", fac=fac * 5)
+    # ---- CAM
+    xr = (x * 0.5).double().requires_grad_()
+    gr = gamma.double().requires_grad_()
+    pq = xr.view(N, C, -1)
+    energy = torch.bmm(pq, pq.permute(0, 2, 1))
+    att = torch.softmax(energy.max(-1, keepdim=True)[0].expand_as(energy) - energy, dim=-1)
+    ref = gr * torch.bmm(att, pq).view(N, C, H, W) + xr
+    ref.backward(g.double())
+    xd = to_dev_nhwc(quant(x * 0.5, dtype), dtype).requires_grad_()
+    gd = gamma.to(DEV).requires_grad_()
+    y = Fm.channel_attention(xd, gd)
+    assert_close(to_cpu_nchw(y), ref.detach(), dtype, "CAM fwd", fac=fac)
+    y.backward(to_dev_nhwc(g, dtype))
+    assert_close(to_cpu_nchw(xd.grad), xr.grad, dtype, "CAM dx", fac=fac)
+    assert_close(gd.grad.cpu(), gr.grad, dtype, "CAM dgamma", fac=fac * 5)
