@@ -163,15 +163,22 @@ class TransparentTrainGraph:
     gradients — and from then on `model(images)` is one copy + one graph replay and
     `losses.backward()` one replay.  The criterion (the fused upsample + cross-entropy kernels,
     through `functional.LogitsView`) and `optimizer.step()` (FusedSGD: 11 launches) stay eager
-    launches: ~15 of the ~1140 launches of a step.  Any other call — evaluation mode, no_grad,
-    a new shape beyond `max_shapes`, a model whose BatchNorms synchronise over torch.distributed
-    — takes the eager path, which stays correct; parameters may be updated by any optimizer
-    (weight packs are re-issued inside the captured forward).  One process per GPU, one stream."""
+    launches: ~15 of the ~1140 launches of a step.  EVALUATION-mode forwards under
+    `torch.no_grad()` (tools/eval.py:70-78 -> `SegBaseModel.evaluate` -> `self.forward`, and the
+    validation pass of tools/train.py:170-190) are captured the same way, one forward graph per
+    input shape (up to `max_eval_shapes`: multi-scale testing feeds a few), and return COPIES of
+    the static outputs (`evaluate` adds the flipped pass to the unflipped one, segbase.py:69-72).
+    Any other call — gradients enabled in evaluation mode, a new shape beyond the limits, a
+    model whose BatchNorms synchronise over torch.distributed — takes the eager path, which
+    stays correct; parameters may be updated by any optimizer (weight packs are re-issued inside
+    the captured forward).  One process per GPU, one stream."""
 
-    def __init__(self, model, warmup=2, max_shapes=2):
+    def __init__(self, model, warmup=2, max_shapes=2, max_eval_shapes=6):
         self.model, self.warmup, self.max_shapes = model, int(warmup), int(max_shapes)
+        self.max_eval_shapes = int(max_eval_shapes)
         self.eager_forward = model.forward
         self.seen, self.segments, self.disabled = {}, {}, None
+        self.eval_segments = {}
 
     # -- installation
     @classmethod
@@ -185,6 +192,7 @@ class TransparentTrainGraph:
         self.model.__dict__.pop("forward", None)
         self.model.__dict__.pop("_transparent_graph", None)
         self.segments.clear()
+        self.eval_segments.clear()
 
     # -- dispatch
     def _key(self, x):
@@ -203,7 +211,49 @@ class TransparentTrainGraph:
                 return False  # torch.distributed collectives do not survive a capture
         return True
 
+    def _eval_capturable(self, x):
+        return (not self.model.training and not torch.is_grad_enabled()
+                and isinstance(x, torch.Tensor) and x.is_cuda and self.disabled is None
+                and not torch.cuda.is_current_stream_capturing()
+                and not F.lazy_eval_logits())
+
+    def _eval_forward(self, x):
+        key = self._key(x)
+        seg = self.eval_segments.get(key)
+        if seg is None:
+            n = self.seen.get(("eval",) + key, 0)
+            self.seen[("eval",) + key] = n + 1
+            if n < self.warmup or len(self.eval_segments) >= self.max_eval_shapes:
+                return self.eager_forward(x)
+            try:
+                seg = _Segment()
+                seg.x = x.clone()
+                torch.cuda.synchronize()
+                F.clear_weight_cache()  # packs inside the graph: replays follow the optimizer
+                seg.fwd = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(seg.fwd):
+                    outs = self.eager_forward(seg.x)
+                if not all(isinstance(o, torch.Tensor) for o in outs):
+                    raise RuntimeError("evaluation capture needs tensor outputs")
+                seg.lo = list(outs)
+                torch.cuda.synchronize()
+                F.clear_weight_cache()
+            except Exception as e:  # noqa: BLE001
+                import sys
+                self.disabled = repr(e)[:300]
+                sys.stderr.write("segmentron_amd.graph: evaluation capture failed (%s): eager "
+                                 "launches from here on\n" % self.disabled)
+                torch.cuda.synchronize()
+                F.clear_weight_cache()
+                return self.eager_forward(x)
+            self.eval_segments[key] = seg
+        seg.x.copy_(x)
+        seg.fwd.replay()
+        return tuple(t.clone() for t in seg.lo)
+
     def forward(self, x, *args, **kwargs):
+        if not args and not kwargs and self._eval_capturable(x):
+            return self._eval_forward(x)
         if args or kwargs or not self._capturable(x):
             return self.eager_forward(x, *args, **kwargs)
         key = self._key(x)

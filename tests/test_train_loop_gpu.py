@@ -118,3 +118,37 @@ def test_reference_loop_statements_graph_mode_equals_eager_bit_for_bit():
     bad = [k for k in se if not torch.equal(se[k], sg[k])]
     assert not bad, bad[:5]
     assert le[-1] < le[0]  # the loop trains
+
+
+def test_evaluate_graph_mode_equals_eager_bit_for_bit():
+    """tools/eval.py:70-78 / tools/train.py:170-190: `model.evaluate(image)` (multi-scale, flip,
+    pad — segbase.py:44-79) with SEGMENTRON_HIP_GRAPH=1: every evaluation-mode forward of a shape
+    replays a captured graph from its third call on (copies of the static outputs are returned:
+    evaluate() adds the flipped pass to the unflipped one).  Bit-identical to eager launches."""
+    import test_model_gpu as M
+    extra = ["TEST.SCALES", "[0.75, 1.0]", "TEST.FLIP", "True", "TEST.CROP_SIZE", "(81, 145)"]
+    xs = [synth.synth_images(1, 65, 129, seed=40 + i).cuda() for i in range(5)]
+
+    def run(graph):
+        prev = os.environ.get("SEGMENTRON_HIP_GRAPH")
+        os.environ["SEGMENTRON_HIP_GRAPH"] = "1" if graph else "0"
+        try:
+            model, _ = M._build_eval(extra)
+            tg = getattr(model, "_transparent_graph", None)
+            assert (tg is not None) == graph
+            with torch.no_grad():
+                outs = [model.evaluate(x).clone() for x in xs]
+            if graph:
+                assert tg.disabled is None, tg.disabled
+                assert len(tg.eval_segments) == 2 and not tg.segments  # the two scales' shapes
+            return outs
+        finally:
+            if prev is None:
+                os.environ.pop("SEGMENTRON_HIP_GRAPH", None)
+            else:
+                os.environ["SEGMENTRON_HIP_GRAPH"] = prev
+
+    a, b = run(False), run(True)
+    for i, (u, v) in enumerate(zip(a, b)):
+        assert torch.equal(u, v), i
+    assert not torch.equal(a[0], a[1])
