@@ -154,6 +154,11 @@ int seg_bn_finalize_small(int dtype, const void* y, long ldy, long M, int C, con
                           const float* beta, float eps, float momentum, float* running_mean,
                           float* running_var, float* mean, float* invstd, float* scale,
                           float* shift, const float* mean_offset, void* stream);
+/* y = xs[0] + ... + xs[n-1] (2 <= n <= 8 NHWC operands of M rows x C channels, row pitches lds[],
+ * host arrays of device pointers / pitches), fp32 accumulation in index order, one rounding: the
+ * gradient of an activation with several consumers (torch autograd: n-1 `add` launches). */
+int seg_sum_n(int dtype, int n, const void* const* xs, const long* lds, void* y, long ldy, long M,
+              int C, void* stream);
 /* eval mode: scale/shift from running statistics. */
 int seg_bn_eval_affine(const float* gamma, const float* beta, const float* rm, const float* rv,
                        float eps, float* scale, float* shift, int C, void* stream);

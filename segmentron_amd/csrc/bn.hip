@@ -696,6 +696,51 @@ extern "C" int seg_bn_eval_affine(const float* gamma, const float* beta, const f
   return check_launch("bn_eval_affine");
 }
 
+namespace seg {
+// ---- n-ary sum: y = x_0 + x_1 + ... + x_{n-1} (2 <= n <= 8), fp32 accumulation in index order,
+// ONE rounding — the gradient of an activation with several consumers (the five ASPP branches of
+// c4, module.py:52-70; shortcut + first separable conv of a conv-skip block, xception.py:36-40),
+// which torch autograd would accumulate with n-1 element-wise `add` launches.
+constexpr int SUMN_MAX = 8;
+struct SumNArgs {
+  const void* x[SUMN_MAX];
+  long ld[SUMN_MAX];
+  void* y;
+  long ldy, M;
+  int n, CV, cvb_log2;
+};
+
+template <typename T>
+__global__ __launch_bounds__(EW_THREADS) void sum_n_kernel(const SumNArgs a) {
+  constexpr int VEC = Vec<T>::N;
+  const int cvb = 1 << a.cvb_log2;
+  const int cx = threadIdx.x & (cvb - 1), sy = threadIdx.x >> a.cvb_log2;
+  const int rpb = EW_THREADS >> a.cvb_log2;
+  const int cv = blockIdx.x * cvb + cx;
+  if (cv >= a.CV) return;
+  const int c0 = cv * VEC;
+  T* __restrict__ Y = reinterpret_cast<T*>(a.y);
+  const int M = (int)a.M, step = gridDim.y * rpb;
+  for (int row = blockIdx.y * rpb + sy; row < M; row += step) {
+    uint4 r[SUMN_MAX];
+#pragma unroll
+    for (int k = 0; k < SUMN_MAX; ++k)
+      if (k < a.n) r[k] = ldg16(reinterpret_cast<const T*>(a.x[k]) + (long)row * a.ld[k] + c0);
+    float acc[VEC];
+    Vec<T>::unpack(r[0], acc);
+#pragma unroll
+    for (int k = 1; k < SUMN_MAX; ++k)
+      if (k < a.n) {
+        float f[VEC];
+        Vec<T>::unpack(r[k], f);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[i] += f[i];
+      }
+    stg16(Y + (long)row * a.ldy + c0, Vec<T>::pack(acc));
+  }
+}
+}  // namespace seg
+
 // y = post_relu?( act_x(x) * chan_mul + act_r(r) )
 extern "C" int seg_bn_apply(int dtype, const void* x, long ldx, int mode_x, const float* sx,
                             const float* tx, const void* r, long ldr, int mode_r, const float* sr,
@@ -725,6 +770,28 @@ extern "C" int seg_bn_apply(int dtype, const void* x, long ldx, int mode_x, cons
     hipLaunchKernelGGL((bn_apply_kernel<float>), grid, dim3(EW_THREADS), 0,
                        (hipStream_t)stream, a);
   return check_launch("bn_apply");
+}
+
+extern "C" int seg_sum_n(int dtype, int n, const void* const* xs, const long* lds, void* y, long ldy,
+                         long M, int C, void* stream) {
+  using namespace seg;
+  const int vec = dtype == DT_BF16 ? 8 : 4;
+  SEG_REQUIRE(dtype == DT_F32 || dtype == DT_BF16, "sum_n: bad dtype %d", dtype);
+  SEG_REQUIRE(n >= 2 && n <= SUMN_MAX, "sum_n: 2..%d operands", SUMN_MAX);
+  SEG_REQUIRE(C % vec == 0 && ldy % vec == 0 && M >= 1 && M < (1L << 31), "sum_n: C/ld/M");
+  SumNArgs a;
+  for (int k = 0; k < SUMN_MAX; ++k) {
+    a.x[k] = k < n ? xs[k] : nullptr;
+    a.ld[k] = k < n ? lds[k] : 0;
+    SEG_REQUIRE(k >= n || (xs[k] != nullptr && lds[k] % vec == 0 && lds[k] >= C), "sum_n: operand %d", k);
+  }
+  a.y = y; a.ldy = ldy; a.M = M; a.n = n; a.CV = C / vec;
+  const dim3 grid = ew_grid2(a.CV, M, a.cvb_log2);
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL((sum_n_kernel<bf16_t>), grid, dim3(EW_THREADS), 0, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL((sum_n_kernel<float>), grid, dim3(EW_THREADS), 0, (hipStream_t)stream, a);
+  return check_launch("sum_n");
 }
 
 extern "C" int seg_bn_bwd_grid_y(int dtype, int C, long M) {

@@ -877,6 +877,36 @@ class _CCAFn(torch.autograd.Function):
         return dq, dk, dv, dx, dgamma
 
 
+class _ForkFn(torch.autograd.Function):
+    """One activation, n consumers: hands out n aliases and sums their gradients with ONE
+    n-ary kernel (seg_sum_n: fp32 accumulation, one rounding) instead of autograd's n-1
+    element-wise `add` launches (the five consumers of c4 in the ASPP, module.py:52-70; the
+    shortcut + first separable conv of the conv-skip Xception blocks, xception.py:36-40; the
+    low-level feature's two consumers)."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        return tuple(x.view(x.shape) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        gs = [g for g in grads if g is not None]
+        if not gs:
+            return None, None
+        if len(gs) == 1:
+            return gs[0], None
+        vec = K.vec_of(gs[0].dtype)
+        gs = [g if (K.nhwc(g)[4] % vec == 0) else g.contiguous() for g in gs]
+        return K.sum_n(gs), None
+
+
+def fork(t, n):
+    """n aliases of the plain NHWC tensor `t` whose gradients meet in one n-ary sum."""
+    if n <= 1 or not (torch.is_grad_enabled() and t.requires_grad):
+        return (t,) * n
+    return _ForkFn.apply(t, n)
+
+
 def _scaled(t, gamma32, residual=None):
     """gamma * t (+ residual) on the element-wise HIP kernel (per-channel scale = gamma)."""
     C = t.shape[-1]

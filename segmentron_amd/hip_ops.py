@@ -363,6 +363,24 @@ def bn_apply(x, pro_x=None, r=None, pro_r=None, chan_mul=None, post_relu=False, 
     return out
 
 
+def sum_n(tensors):
+    """NHWC tensors of one shape / dtype -> their sum (fp32 accumulation in list order, one
+    rounding): ONE launch for up to 8 operands (more: in groups)."""
+    import ctypes
+    ts = list(tensors)
+    while len(ts) > 1:
+        group, ts = ts[:8], ts[8:]
+        N, H, W, C, _ = nhwc(group[0])
+        lds = [nhwc(t)[4] for t in group]
+        assert all(t.shape == group[0].shape and t.dtype == group[0].dtype for t in group)
+        out = torch.empty((N, H, W, C), dtype=group[0].dtype, device=group[0].device)
+        n = len(group)
+        LIB.call("seg_sum_n", _DT[out.dtype], n, (ctypes.c_void_p * n)(*[t.data_ptr() for t in group]),
+                 (ctypes.c_long * n)(*lds), _p(out), C, N * H * W, C, _stream())
+        ts.insert(0, out)
+    return ts[0]
+
+
 def nearest_add(x, pro_x, r, pro_r, shift, post_relu=False, out=None):
     """y = post_relu?(act_x(x) + act_r(nearest_upsample_{2^shift}(r)))  (hrnet.py:186,215-229)"""
     N, H, W, C, ldx = nhwc(x)

@@ -45,17 +45,27 @@ class XceptionBlock(nn.Module):
         if (self.skip_connection_type == "sum" and self.relu_first and inputs.bn is None
                 and not inputs.relu and torch.is_grad_enabled() and inputs.t.requires_grad):
             fork = F.GradFork()
+        skip_in = inputs
+        if self.skip_connection_type == "conv":
+            # two consumers (first separable conv, shortcut conv): one 2-ary gradient sum on the
+            # HIP kernel instead of autograd's `add` (functional.fork)
+            t = F.fork(inputs.t, 2)
+            inputs, skip_in = F.Act(t[0], inputs.bn, inputs.relu), F.Act(t[1], inputs.bn, inputs.relu)
         sc1 = self.sep_conv1(inputs, fork=fork) if fork is not None else self.sep_conv1(inputs)
         sc2 = self.sep_conv2(sc1)
+        low = sc2
+        if self.low_feat:  # the low-level feature leaves the block AND feeds sep_conv3
+            t = F.fork(sc2.t, 2)
+            sc2, low = F.Act(t[0], sc2.bn, sc2.relu), F.Act(t[1], sc2.bn, sc2.relu)
         residual = self.sep_conv3(sc2)
         if self.skip_connection_type == "conv":
-            shortcut = F.conv_bn(inputs, self.conv, self.bn)
+            shortcut = F.conv_bn(skip_in, self.conv, self.bn)
             outputs = F.Act(F.materialize(residual, residual=shortcut))
         elif self.skip_connection_type == "sum":
             outputs = F.Act(F.materialize(residual, residual=inputs, fork=fork))
         else:
             outputs = residual
-        return (outputs, sc2) if self.low_feat else outputs
+        return (outputs, low) if self.low_feat else outputs
 
 
 class Xception65(nn.Module):

@@ -112,18 +112,20 @@ class _ASPP(nn.Module):
         x = F.materialize(c4)
         N, H, W, _ = x.shape
         oc = self.out_channels
-        xa = F.Act(x)
+        # five consumers of one tensor: their gradients meet in ONE n-ary sum (functional.fork)
+        xs = F.fork(x, 5)
         buf = torch.empty((N, H, W, 5 * oc), dtype=x.dtype, device=x.device)
         # image pooling: gap -> 1x1 -> BN (statistics over the batch) -> ReLU -> broadcast
-        pooled = F.conv_bn(F.Act(F.global_avg_pool(x)), self.image_pooling.conv,
+        pooled = F.conv_bn(F.Act(F.global_avg_pool(xs[0])), self.image_pooling.conv,
                            self.image_pooling.bn)
         pooled.relu = True
         parts = [F.bilinear(pooled, (H, W), out=buf[..., 0:oc])]
-        b0 = F.conv_bn(xa, self.aspp0.conv, self.aspp0.bn)
+        b0 = F.conv_bn(F.Act(xs[1]), self.aspp0.conv, self.aspp0.bn)
         b0.relu = True
         parts.append(F.materialize(b0, out=buf[..., oc:2 * oc]))
         for i, branch in enumerate((self.aspp1, self.aspp2, self.aspp3)):
-            parts.append(F.materialize(branch(xa), out=buf[..., (2 + i) * oc:(3 + i) * oc]))
+            parts.append(F.materialize(branch(F.Act(xs[2 + i])),
+                                       out=buf[..., (2 + i) * oc:(3 + i) * oc]))
         cat = F.concat_alias(buf, parts)
         y = F.conv_bn(F.Act(cat), self.conv, self.bn)
         y.relu = True

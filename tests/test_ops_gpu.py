@@ -863,3 +863,33 @@ def test_danet_position_and_channel_attention_fwd_bwd(hw, dtype):
     y.backward(to_dev_nhwc(g, dtype))
     assert_close(to_cpu_nchw(xd.grad), xr.grad, dtype, "CAM dx", fac=fac)
     assert_close(gd.grad.cpu(), gr.grad, dtype, "CAM dgamma", fac=fac * 5)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+@pytest.mark.parametrize("n", [2, 3, 5, 8, 11])
+def test_sum_n_and_fork_gradient(n, dtype):
+    """seg_sum_n / functional.fork: the gradients of an activation's n consumers meet in one
+    n-ary sum (fp32 accumulation in list order, one rounding) — what torch autograd does with
+    n-1 element-wise adds (module.py:52-70, xception.py:36-40)."""
+    Fm = F()
+    N, C, H, W = 2, 40, 7, 9
+    xs = [quant(rnd((N, C, H, W), 10 + i), dtype) for i in range(n)]
+    devs = [to_dev_nhwc(t, dtype, pitch=C + 8 if i % 2 else None) for i, t in enumerate(xs)]
+    got = K().sum_n(devs)
+    acc = xs[0].float().clone()
+    chunks = [xs[:8], xs[8:]] if n > 8 else [xs]
+    ref = None
+    for ch in chunks:  # groups of 8, each rounded once (the wrapper's grouping)
+        terms = ([ref] if ref is not None else []) + ch
+        acc = terms[0].float().clone()
+        for t in terms[1:]:
+            acc = acc + t.float()
+        ref = quant(acc, dtype)
+    assert torch.equal(to_cpu_nchw(got), ref)
+    # autograd: n consumers with different weights
+    t = to_dev_nhwc(xs[0], dtype).requires_grad_()
+    parts = Fm.fork(t, n)
+    ws = [0.25 * (i + 1) for i in range(n)]
+    sum((p * w).sum() for p, w in zip(parts, ws)).backward()
+    want = torch.full((N, C, H, W), sum(ws))
+    assert_close(to_cpu_nchw(t.grad), want, dtype, "fork gradient")
