@@ -316,6 +316,13 @@ int seg_sgd_multi_tensor(int ntensors, const void* const* params, const void* co
                          const void* const* bufs, const long* numel, const int* group,
                          const float* lr_dev, const float* wd_dev, float momentum, int first,
                          void* stream);
+/* Multi-tensor weight packing (r04): njobs jobs "fp32 [O][C] contiguous -> dtype [O][C]
+ * (transpose = 0) or [C][O] (transpose = 1)" in as few launches as the 32-job / 1024-tile
+ * argument block allows: the GEMM operands of the non-folded 1x1 convolutions, re-made once per
+ * optimizer step (torch: one cast / transposing copy per tensor and direction).  srcs / dsts / O /
+ * C / transpose: HOST arrays. */
+int seg_pack_multi(int dtype, int njobs, const void* const* srcs, const void* const* dsts,
+                   const int* O, const int* C, const int* transpose, void* stream);
 
 /* ---- pixAcc / mIoU counters ------------------------------------------------------------------
  * Replaces segmentron/utils/score.py:83-113 (batch_pix_accuracy: argmax of the logits TRUNCATED

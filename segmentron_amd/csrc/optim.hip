@@ -113,3 +113,102 @@ extern "C" int seg_sgd_multi_tensor(int ntensors, const void* const* params,
   }
   return flush();
 }
+
+
+// ---- multi-tensor weight packing: the fp32 master weights of the 1x1 convolutions whose input
+// BatchNorm is NOT folded (fold.hip packs the folded ones) become compute-dtype GEMM operands
+// once per optimizer step — `[O][C]` as stored (forward / weight-gradient operand) and `[C][O]`
+// (data-gradient operand).  torch did this with one cast / transposing-copy launch per tensor and
+// direction (~40 launches of 5-9 us per DeepLabv3+ step); here up to 32 (tensor, direction) jobs
+// share one launch: a block owns four consecutive 64x64 tiles of one job, the job table travels in the kernel
+// argument block (as in sgd_multi_tensor above).  Same round-to-nearest-even as torch's `.to()`.
+namespace seg {
+
+constexpr int PK_JOBS = 32, PK_BLOCKS = 480, PK_TILE = 64, PK_THREADS = 256;
+constexpr int PK_SPAN = 4;  // consecutive 64x64 tiles per block (the argument block stays < 4 KB)
+
+struct PackArgs {
+  const float* src[PK_JOBS];
+  void* dst[PK_JOBS];
+  int O[PK_JOBS], C[PK_JOBS];         // source is [O][C] fp32, contiguous
+  unsigned char transpose[PK_JOBS];   // destination [C][O] instead of [O][C]
+  unsigned char blk_job[PK_BLOCKS];
+  int blk_tile[PK_BLOCKS];            // first tile (row-major over the job's tile grid)
+  int dtype;
+};
+
+template <typename T>
+__global__ __launch_bounds__(PK_THREADS) void pack_multi_kernel(const PackArgs a) {
+  __shared__ float tile[PK_TILE][PK_TILE + 1];
+  const int j = a.blk_job[blockIdx.x];
+  const int O = a.O[j], C = a.C[j];
+  const int tc = (C + PK_TILE - 1) / PK_TILE, ntiles = ((O + PK_TILE - 1) / PK_TILE) * tc;
+  const float* __restrict__ src = a.src[j];
+  T* __restrict__ dst = reinterpret_cast<T*>(a.dst[j]);
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4
+  const bool tr = a.transpose[j] != 0;
+  for (int t = a.blk_tile[blockIdx.x]; t < min(ntiles, a.blk_tile[blockIdx.x] + PK_SPAN); ++t) {
+    const int o0 = (t / tc) * PK_TILE, c0 = (t % tc) * PK_TILE;
+    if (!tr) {
+      for (int r = ty; r < PK_TILE; r += 4) {
+        const int o = o0 + r, c = c0 + tx;
+        if (o < O && c < C) Vec<T>::store1(dst + (long)o * C + c, src[(long)o * C + c]);
+      }
+      continue;
+    }
+    __syncthreads();  // the previous tile has been read out
+    for (int r = ty; r < PK_TILE; r += 4) {
+      const int o = o0 + r, c = c0 + tx;
+      tile[r][tx] = (o < O && c < C) ? src[(long)o * C + c] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < PK_TILE; r += 4) {
+      const int c = c0 + r, o = o0 + tx;
+      if (c < C && o < O) Vec<T>::store1(dst + (long)c * O + o, tile[tx][r]);
+    }
+  }
+}
+
+}  // namespace seg
+
+// srcs / dsts: HOST arrays of `njobs` device pointers; O / C / transpose: host arrays.
+extern "C" int seg_pack_multi(int dtype, int njobs, const void* const* srcs, const void* const* dsts,
+                              const int* O, const int* C, const int* transpose, void* stream) {
+  using namespace seg;
+  SEG_REQUIRE(dtype == DT_F32 || dtype == DT_BF16, "pack_multi: bad dtype %d", dtype);
+  PackArgs a;
+  a.dtype = dtype;
+  int nj = 0, nb = 0;
+  auto flush = [&]() -> int {
+    if (nb == 0) { nj = 0; return 0; }
+    if (dtype == DT_BF16)
+      hipLaunchKernelGGL((pack_multi_kernel<bf16_t>), dim3(nb), dim3(PK_THREADS), 0,
+                         (hipStream_t)stream, a);
+    else
+      hipLaunchKernelGGL((pack_multi_kernel<float>), dim3(nb), dim3(PK_THREADS), 0,
+                         (hipStream_t)stream, a);
+    nj = nb = 0;
+    return check_launch("pack_multi");
+  };
+  for (int i = 0; i < njobs; ++i) {
+    SEG_REQUIRE(srcs[i] && dsts[i] && O[i] >= 1 && C[i] >= 1, "pack_multi: bad job %d", i);
+    const long to = (O[i] + PK_TILE - 1) / PK_TILE, tc = (C[i] + PK_TILE - 1) / PK_TILE;
+    SEG_REQUIRE(to * tc < (1L << 30), "pack_multi: job %d too large", i);
+    long t = 0;
+    while (t < to * tc) {
+      if (nj == PK_JOBS || nb == PK_BLOCKS) {
+        const int rc = flush();
+        if (rc) return rc;
+      }
+      a.src[nj] = (const float*)srcs[i]; a.dst[nj] = const_cast<void*>(dsts[i]);
+      a.O[nj] = O[i]; a.C[nj] = C[i]; a.transpose[nj] = transpose[i] ? 1 : 0;
+      while (t < to * tc && nb < PK_BLOCKS) {
+        a.blk_job[nb] = (unsigned char)nj;
+        a.blk_tile[nb] = (int)t;
+        ++nb; t += PK_SPAN;
+      }
+      ++nj;
+    }
+  }
+  return flush();
+}

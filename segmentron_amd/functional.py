@@ -216,8 +216,46 @@ def cached_pack(param, kind, builder):
 def clear_weight_cache():
     """Drop every packed weight (HIP-graph capture needs the pack launches re-issued inside the
     captured region; after replaying a graph that steps the optimizer the cached packs no longer
-    match the parameters although `_version` did not move)."""
+    match the parameters although `_version` did not move).  The PLAN of pointwise packs
+    (`packed_pointwise`) survives: the next request re-packs all of them in one launch."""
     _WCACHE.clear()
+
+
+# (id(param), transpose, dtype) -> weakref(param): every plain 1x1 pack requested so far
+_PACK_PLAN = {}
+# id(alias) -> parameter: graph.TransparentTrainGraph captures on leaf aliases of the parameters
+_PARAM_ALIAS = {}
+
+
+def packed_pointwise(param, transpose, dtype):
+    """[O, C, 1, 1] fp32 parameter -> [O, C] (`transpose` False) or [C, O] in `dtype`, cached on
+    the parameter's version like `cached_pack`.  All such packs of a step go stale together (the
+    optimizer bumps every parameter), so the first miss re-packs EVERY planned entry in one
+    multi-tensor launch (csrc/optim.hip seg_pack_multi) instead of one torch cast / transposing
+    copy per tensor and direction (~40 launches per DeepLabv3+ step)."""
+    param = _PARAM_ALIAS.get(id(param), param)
+    key = (id(param), ("pw", bool(transpose), dtype))
+    ent = _WCACHE.get(key)
+    ver, ptr = param._version, param.data_ptr()
+    if ent is not None and ent[0] == ver and ent[1] == ptr and ent[2]() is param:
+        return ent[3]
+    _PACK_PLAN[(id(param), bool(transpose), dtype)] = weakref.ref(param)
+    todo = []
+    for (pid, tr, dt), ref in list(_PACK_PLAN.items()):
+        p = ref()
+        if p is None or id(p) != pid:
+            del _PACK_PLAN[(pid, tr, dt)]
+            continue
+        if dt != dtype or p.device != param.device:
+            continue
+        e = _WCACHE.get((pid, ("pw", tr, dt)))
+        if e is not None and e[0] == p._version and e[1] == p.data_ptr() and e[2]() is p:
+            continue
+        todo.append((p, tr))
+    outs = K.pack_multi([(p.detach().view(p.shape[0], p.shape[1]), tr) for p, tr in todo], dtype)
+    for (p, tr), val in zip(todo, outs):
+        _WCACHE[(id(p), ("pw", tr, dtype))] = (p._version, p.data_ptr(), weakref.ref(p), val)
+    return _WCACHE[key][3]
 
 
 def pack_conv_weight(w, cx, dtype):
@@ -290,7 +328,10 @@ class _ConvFn(torch.autograd.Function):
     def forward(ctx, x, in_gamma, in_beta, weight, bias, spec):
         O, Cw, KH, KW = weight.shape
         cx, dt = x.shape[-1], x.dtype
-        wp = cached_pack(weight, ("fwd", cx, dt), lambda: pack_conv_weight(weight, cx, dt))
+        if KH == 1 and KW == 1 and cx == Cw and weight.dtype == torch.float32:
+            wp = packed_pointwise(weight, False, dt)
+        else:
+            wp = cached_pack(weight, ("fwd", cx, dt), lambda: pack_conv_weight(weight, cx, dt))
         # conv bias followed by a training-mode BatchNorm (hrnet_seg.py:22-29): the statistics
         # come from the accumulators, so the bias is left out of the stored tensor — BN cancels
         # it exactly; it only re-enters running_mean (finish_bn mean_offset), its gradient is 0
@@ -329,8 +370,11 @@ class _ConvFn(torch.autograd.Function):
         dx = dgamma = dbeta = None
         if ctx.needs_input_grad[0]:
             Op, dt = dy_full.shape[-1], x.dtype
-            wt = cached_pack(weight, ("dgrad", Op, dt),
-                             lambda: pack_conv_weight_dgrad(weight, Op, dt))
+            if KH == 1 and KW == 1 and Op == O and weight.dtype == torch.float32:
+                wt = packed_pointwise(weight, True, dt)
+            else:
+                wt = cached_pack(weight, ("dgrad", Op, dt),
+                                 lambda: pack_conv_weight_dgrad(weight, Op, dt))
             if s.stride == 1:
                 g, _ = K.conv_gemm(dy_full, wt, Cw, KH, KW, 1, s.dil * (KH - 1) - s.pad, s.dil)
             elif KH == 1 and KW == 1 and s.pad == 0:

@@ -299,6 +299,9 @@ class TransparentTrainGraph:
         F.clear_weight_cache()  # the weight packs must be issued INSIDE the captured forward
         pool = torch.cuda.graph_pool_handle()
         seg.fwd, seg.bwd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        # (the aliases resolve to their parameters in functional.packed_pointwise: one
+        # multi-tensor pack launch for the whole model instead of one per alias)
+        F._PARAM_ALIAS.update({id(a): p for a, p in zip(leaves, seg.params)})
         with torch.cuda.graph(seg.fwd, pool=pool):
             outs = torch.func.functional_call(model, {n: t for (n, _), t in zip(named, leaves)},
                                               (seg.x,))
@@ -312,6 +315,8 @@ class TransparentTrainGraph:
         seg.grads = [None if g is None else (g if g.is_contiguous() else g.contiguous())
                      for g in grads]
         torch.cuda.synchronize()
+        for a in leaves:
+            F._PARAM_ALIAS.pop(id(a), None)
         F.clear_weight_cache()  # (entries keyed on the aliases)
         return seg
 

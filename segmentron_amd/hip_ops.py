@@ -730,6 +730,24 @@ def sgd_check(p, g, b):
         raise RuntimeError("segmentron_amd SGD: size mismatch")
 
 
+def pack_multi(jobs, dtype):
+    """jobs: [(src fp32 [O, C] contiguous, transpose)] -> list of packed tensors in `dtype`
+    ([O, C] or [C, O]) written by as few seg_pack_multi launches as possible."""
+    import ctypes
+    n = len(jobs)
+    outs = []
+    for src, tr in jobs:
+        assert src.dtype == torch.float32 and src.is_cuda and src.is_contiguous() and src.dim() == 2
+        O, C = src.shape
+        outs.append(torch.empty((C, O) if tr else (O, C), dtype=dtype, device=src.device))
+    vp = ctypes.c_void_p * n
+    ci = ctypes.c_int * n
+    LIB.call("seg_pack_multi", _DT[dtype], n, vp(*[j[0].data_ptr() for j in jobs]),
+             vp(*[o.data_ptr() for o in outs]), ci(*[j[0].shape[0] for j in jobs]),
+             ci(*[j[0].shape[1] for j in jobs]), ci(*[1 if j[1] else 0 for j in jobs]), _stream())
+    return outs
+
+
 def sgd_plan(params, bufs, groups):
     """The per-step-invariant half of a multi-tensor SGD launch: ctypes arrays of the parameter /
     buffer pointers, sizes and group indices (440 tensors: rebuilt only when they change)."""

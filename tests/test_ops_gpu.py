@@ -893,3 +893,31 @@ def test_sum_n_and_fork_gradient(n, dtype):
     sum((p * w).sum() for p, w in zip(parts, ws)).backward()
     want = torch.full((N, C, H, W), sum(ws))
     assert_close(to_cpu_nchw(t.grad), want, dtype, "fork gradient")
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+def test_pack_multi_matches_torch_casts_and_transposes(dtype):
+    """seg_pack_multi / functional.packed_pointwise: the GEMM operands of the non-folded 1x1
+    convolutions, re-made once per optimizer step in one multi-tensor launch — bit-identical to
+    torch's `.to(dtype)` / transposing copy; the cache follows the parameter version."""
+    Fm = F()
+    shapes = [(19, 256), (256, 304), (48, 256), (1536, 2048), (130, 70)] + [(64, 64)] * 40
+    srcs = [rnd(s, 30 + i).to(DEV) for i, s in enumerate(shapes)]
+    jobs = [(t, bool(i % 2)) for i, t in enumerate(srcs)] + [(srcs[3], True), (srcs[4], True)]
+    outs = K().pack_multi(jobs, dtype)
+    for (t, tr), o in zip(jobs, outs):
+        want = (t.t() if tr else t).to(dtype).contiguous()
+        assert torch.equal(o, want), (tuple(t.shape), tr)
+    # cache: same object until the parameter changes, then ALL planned packs are re-made
+    w1 = torch.nn.Parameter(rnd((32, 16, 1, 1), 1).to(DEV))
+    w2 = torch.nn.Parameter(rnd((24, 32, 1, 1), 2).to(DEV))
+    a, b = Fm.packed_pointwise(w1, False, dtype), Fm.packed_pointwise(w2, True, dtype)
+    assert Fm.packed_pointwise(w1, False, dtype) is a and tuple(b.shape) == (32, 24)
+    with torch.no_grad():
+        w1.mul_(2.0)
+        w2.add_(1.0)
+    a2 = Fm.packed_pointwise(w1, False, dtype)
+    assert a2 is not a and torch.equal(a2, w1.detach().view(32, 16).to(dtype))
+    b2 = Fm._WCACHE[(id(w2), ("pw", True, dtype))][3]  # re-made by the same launch
+    assert torch.equal(b2, w2.detach().view(24, 32).t().to(dtype).contiguous())
+    assert Fm.packed_pointwise(w2, True, dtype) is b2
