@@ -197,6 +197,22 @@ def bn_input_backward(g, x, bn, relu, chan_mul=None, inplace=False, elem_mul=Non
 
 # ----------------------------------------------------------------------------- weight packing
 _WCACHE = {}
+_EPOCH = [1]  # bumped by clear_weight_cache(): names the capture an entry was made in
+
+
+def _scope():
+    """0 for eager launches, the current epoch inside a HIP-graph capture.  A pack issued inside a
+    capture is only WRITTEN when the graph replays: its cache entry is valid for later requests
+    of the same capture and for nothing else (an eager step — of this or of another model whose
+    parameters were re-packed by the same multi-tensor launch — must not read it); an eagerly
+    made entry is not valid inside a capture (the launch has to be part of the graph)."""
+    return _EPOCH[0] if (torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()) \
+        else 0
+
+
+def _hit(ent, param, scope):
+    return (ent is not None and ent[0] == param._version and ent[1] == param.data_ptr()
+            and ent[2]() is param and ent[4] == scope)
 
 
 def cached_pack(param, kind, builder):
@@ -205,20 +221,20 @@ def cached_pack(param, kind, builder):
     step share them, and inference packs once."""
     key = (id(param), kind)
     ent = _WCACHE.get(key)
-    ver, ptr = param._version, param.data_ptr()
-    if ent is not None and ent[0] == ver and ent[1] == ptr and ent[2]() is param:
+    scope = _scope()
+    if _hit(ent, param, scope):
         return ent[3]
     val = builder()
-    _WCACHE[key] = (ver, ptr, weakref.ref(param), val)
+    _WCACHE[key] = (param._version, param.data_ptr(), weakref.ref(param), val, scope)
     return val
 
 
 def clear_weight_cache():
-    """Drop every packed weight (HIP-graph capture needs the pack launches re-issued inside the
-    captured region; after replaying a graph that steps the optimizer the cached packs no longer
-    match the parameters although `_version` did not move).  The PLAN of pointwise packs
+    """Drop every packed weight and open a new epoch (call it right before a HIP-graph capture:
+    the pack launches are re-issued inside the captured region).  The PLAN of pointwise packs
     (`packed_pointwise`) survives: the next request re-packs all of them in one launch."""
     _WCACHE.clear()
+    _EPOCH[0] += 1
 
 
 # (id(param), transpose, dtype) -> weakref(param): every plain 1x1 pack requested so far
@@ -235,9 +251,9 @@ def packed_pointwise(param, transpose, dtype):
     copy per tensor and direction (~40 launches per DeepLabv3+ step)."""
     param = _PARAM_ALIAS.get(id(param), param)
     key = (id(param), ("pw", bool(transpose), dtype))
+    scope = _scope()
     ent = _WCACHE.get(key)
-    ver, ptr = param._version, param.data_ptr()
-    if ent is not None and ent[0] == ver and ent[1] == ptr and ent[2]() is param:
+    if _hit(ent, param, scope):
         return ent[3]
     _PACK_PLAN[(id(param), bool(transpose), dtype)] = weakref.ref(param)
     todo = []
@@ -248,13 +264,12 @@ def packed_pointwise(param, transpose, dtype):
             continue
         if dt != dtype or p.device != param.device:
             continue
-        e = _WCACHE.get((pid, ("pw", tr, dt)))
-        if e is not None and e[0] == p._version and e[1] == p.data_ptr() and e[2]() is p:
+        if _hit(_WCACHE.get((pid, ("pw", tr, dt))), p, scope):
             continue
         todo.append((p, tr))
     outs = K.pack_multi([(p.detach().view(p.shape[0], p.shape[1]), tr) for p, tr in todo], dtype)
     for (p, tr), val in zip(todo, outs):
-        _WCACHE[(id(p), ("pw", tr, dtype))] = (p._version, p.data_ptr(), weakref.ref(p), val)
+        _WCACHE[(id(p), ("pw", tr, dtype))] = (p._version, p.data_ptr(), weakref.ref(p), val, scope)
     return _WCACHE[key][3]
 
 
