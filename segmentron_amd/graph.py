@@ -18,9 +18,33 @@ steps are direct RCCL calls (`parallel.use_native_rccl`, `GraphedTrainStep(post_
 DistributedDataParallel / torch.distributed collectives stay eager (ProcessGroupNCCL's watchdog
 aborts on events recorded in a capturing stream — measured r03).
 """
+import contextlib
+import gc
+
 import torch
 
 from . import functional as F
+
+
+@contextlib.contextmanager
+def capture(graph, **kw):
+    """`torch.cuda.graph(graph, **kw)` with Python's cyclic garbage collector out of the way.
+    A collection that runs DURING a capture may finalize a dead object that owns device resources
+    — a discarded model whose TransparentTrainGraph (a reference cycle with the model) still holds
+    captured graphs: destroying a hipGraph / releasing its pool inside another capture is an
+    illegal call in global capture mode and the C++ destructor aborts the process (measured r04:
+    two graph-mode models built one after the other).  torch >= 2.10 no longer collects on entry
+    (torch.compiler.config.force_cudagraph_gc), so: collect BEFORE, keep the collector off until
+    the capture has ended (reference-counted frees go through the caching allocator as usual)."""
+    gc.collect()
+    was_enabled = gc.isenabled()
+    gc.disable()
+    try:
+        with torch.cuda.graph(graph, **kw):
+            yield
+    finally:
+        if was_enabled:
+            gc.enable()
 
 
 def _warm(fn, n=3):
@@ -43,7 +67,7 @@ class GraphedInference:
             _warm(lambda: self.model(self.x), warmup)
             F.clear_weight_cache()  # the weight packs must be issued INSIDE the capture
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
+            with capture(self.graph):
                 self.out = self.model(self.x)
         torch.cuda.synchronize()
 
@@ -85,7 +109,7 @@ class GraphedTrainStep:
         F.clear_weight_cache()
         optimizer.zero_grad(set_to_none=True)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with capture(self.graph):
             self.loss = loss_fn(model(self.images), self.targets)
             self.loss.backward()
             if post_backward is not None:
@@ -133,8 +157,16 @@ class _GraphedSegment(torch.autograd.Function):
                 buf.zero_()
             else:
                 buf.copy_(g)
-        seg.bwd.replay()
         with torch.no_grad():
+            # `p.grad` still IS the static buffer of the previous backward and nobody wrote to it
+            # since (zero_grad(set_to_none=False) / clipping bump its version counter, a replay
+            # does not): the caller accumulates gradients over several backward calls — keep
+            # the old values, the replay overwrites the buffers
+            held = [(g, g.clone()) for p, g, v in zip(seg.params, seg.grads, seg.gver)
+                    if g is not None and p.grad is g and g._version == v]
+            seg.bwd.replay()
+            for g, old in held:
+                g.add_(old)
             for p, g in zip(seg.params, seg.grads):
                 if g is None:
                     continue
@@ -142,11 +174,12 @@ class _GraphedSegment(torch.autograd.Function):
                     p.grad = g
                 else:  # gradient accumulation / zero_grad(set_to_none=False) on another tensor
                     p.grad.add_(g)
+            seg.gver = [None if g is None else g._version for g in seg.grads]
         return None, None
 
 
 class _Segment:
-    __slots__ = ("fwd", "bwd", "x", "lo", "meta", "grad_lo", "params", "grads", "anchor")
+    __slots__ = ("fwd", "bwd", "x", "lo", "meta", "grad_lo", "params", "grads", "gver", "anchor")
 
 
 class TransparentTrainGraph:
@@ -231,7 +264,7 @@ class TransparentTrainGraph:
                 torch.cuda.synchronize()
                 F.clear_weight_cache()  # packs inside the graph: replays follow the optimizer
                 seg.fwd = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(seg.fwd):
+                with capture(seg.fwd):
                     outs = self.eager_forward(seg.x)
                 if not all(isinstance(o, torch.Tensor) for o in outs):
                     raise RuntimeError("evaluation capture needs tensor outputs")
@@ -297,27 +330,35 @@ class TransparentTrainGraph:
         seg.anchor = torch.zeros((), device=x.device, requires_grad=True)
         torch.cuda.synchronize()
         F.clear_weight_cache()  # the weight packs must be issued INSIDE the captured forward
-        pool = torch.cuda.graph_pool_handle()
+        # Two PRIVATE memory pools.  With one shared pool (the make_graphed_callables recipe) a
+        # parameter gradient may be placed in memory a forward activation occupied until the
+        # backward pass freed it: `p.grad` (the static buffer itself) would then be destroyed by
+        # the NEXT forward replay — fine for forward/backward/step, wrong as soon as gradients
+        # are accumulated over several forward/backward pairs (measured r04: 339 of 440 tensors).
+        # Memory of the backward pool is only ever written by backward replays.
         seg.fwd, seg.bwd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         # (the aliases resolve to their parameters in functional.packed_pointwise: one
         # multi-tensor pack launch for the whole model instead of one per alias)
         F._PARAM_ALIAS.update({id(a): p for a, p in zip(leaves, seg.params)})
-        with torch.cuda.graph(seg.fwd, pool=pool):
-            outs = torch.func.functional_call(model, {n: t for (n, _), t in zip(named, leaves)},
-                                              (seg.x,))
-        if not all(isinstance(o, F.LogitsView) for o in outs):
-            raise RuntimeError("transparent capture needs LogitsView outputs (training mode)")
-        seg.lo = [o.lo for o in outs]
-        seg.meta = [(o.out_hw, o.align_corners) for o in outs]
-        seg.grad_lo = [torch.zeros_like(t) for t in seg.lo]
-        with torch.cuda.graph(seg.bwd, pool=pool):
-            grads = torch.autograd.grad(seg.lo, leaves, seg.grad_lo, allow_unused=True)
-        seg.grads = [None if g is None else (g if g.is_contiguous() else g.contiguous())
-                     for g in grads]
-        torch.cuda.synchronize()
-        for a in leaves:
-            F._PARAM_ALIAS.pop(id(a), None)
-        F.clear_weight_cache()  # (entries keyed on the aliases)
+        try:
+            with capture(seg.fwd):
+                outs = torch.func.functional_call(
+                    model, {n: t for (n, _), t in zip(named, leaves)}, (seg.x,))
+            if not all(isinstance(o, F.LogitsView) for o in outs):
+                raise RuntimeError("transparent capture needs LogitsView outputs (training mode)")
+            seg.lo = [o.lo for o in outs]
+            seg.meta = [(o.out_hw, o.align_corners) for o in outs]
+            seg.grad_lo = [torch.zeros_like(t) for t in seg.lo]
+            with capture(seg.bwd):
+                grads = torch.autograd.grad(seg.lo, leaves, seg.grad_lo, allow_unused=True)
+            seg.grads = [None if g is None else (g if g.is_contiguous() else g.contiguous())
+                         for g in grads]
+            seg.gver = [None] * len(seg.grads)
+            torch.cuda.synchronize()
+        finally:  # (ids of dead aliases would be recycled by unrelated tensors)
+            for a in leaves:
+                F._PARAM_ALIAS.pop(id(a), None)
+            F.clear_weight_cache()  # (entries keyed on the aliases)
         return seg
 
 

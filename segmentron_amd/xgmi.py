@@ -156,6 +156,7 @@ def connect(comm, rank, world, gather=None, rounds=4, log=sys.stderr):
                             (SLOT_BYTES // 4, torch.float32)) for _ in range(rounds)]
     src = torch.randn(1457, dtype=torch.float64, device=dev, generator=gen)
     got, a, bad = [], torch.zeros_like(src), 0.0
+    from .graph import capture  # (torch.cuda.graph with the garbage collector held off)
     try:
         for x in inputs:
             got.append(box.all_reduce(x.clone()))
@@ -167,7 +168,7 @@ def connect(comm, rank, world, gather=None, rounds=4, log=sys.stderr):
             a.copy_(src)
             box.all_reduce(a)
             torch.cuda.synchronize()
-            with torch.cuda.graph(graph, stream=side):
+            with capture(graph, stream=side):
                 a.copy_(src)
                 box.all_reduce(a)
                 box.all_reduce(a)
@@ -193,7 +194,7 @@ def connect(comm, rank, world, gather=None, rounds=4, log=sys.stderr):
             side2.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side2):
                 torch.cuda.synchronize()
-                with torch.cuda.graph(g2, stream=side2):
+                with capture(g2, stream=side2):
                     mean_g, _, _, _, cnt_g = K.bn_finalize_p_sync(box, part, 10.0 + rank, ones,
                                                                   zeros, 1e-5, 0.1, None, None)
             torch.cuda.current_stream().wait_stream(side2)

@@ -275,7 +275,8 @@ def _mailbox_worker(rank, world, port, ret):
             box.all_reduce(y)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=side):
+            from segmentron_amd.graph import capture
+            with capture(g, stream=side):
                 y.copy_(x)
                 box.all_reduce(y)
                 y.mul_(0.5)
@@ -305,7 +306,8 @@ def _mailbox_worker(rank, world, port, ret):
             g2 = torch.cuda.CUDAGraph()
             with torch.cuda.stream(side2):
                 torch.cuda.synchronize()
-                with torch.cuda.graph(g2, stream=side2):
+                from segmentron_amd.graph import capture
+                with capture(g2, stream=side2):
                     mean_g, _, _, _, cnt_g = K.bn_finalize_p_sync(box, mine, 10.0 + rank, ones,
                                                                   zeros, 1e-5, 0.1, None, None)
             torch.cuda.current_stream().wait_stream(side2)
@@ -445,7 +447,8 @@ def test_native_rccl_communicator_one_rank_eager_and_inside_a_hip_graph():
             comm.all_reduce(y)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=s):
+            from segmentron_amd.graph import capture
+            with capture(g, stream=s):
                 y = x * 2
                 comm.all_reduce(y)
                 z = y + 1

@@ -43,7 +43,7 @@ class MixSoftmaxCrossEntropyLoss(nn.CrossEntropyLoss):
         return dict(loss=loss)
 
 
-def _run_loop(graph, iters, hw, dtype=torch.bfloat16):
+def _run_loop(graph, iters, hw, dtype=torch.bfloat16, micro=1):
     import segmentron_amd
     from segmentron_amd.config import cfg, reset_cfg
     from segmentron_amd.solver.lr_scheduler import get_scheduler
@@ -74,6 +74,21 @@ def _run_loop(graph, iters, hw, dtype=torch.bfloat16):
         H, W = hw
         losses_seen = []
         for it in range(iters):
+            if micro > 1:
+                # gradient accumulation over `micro` batches (not in the reference's loop; a
+                # common edit of it): zero_grad once, several forward/backward pairs, one step
+                optimizer.zero_grad()
+                for k in range(micro):
+                    images = synth.synth_images(2, H, W, seed=100 + it * micro + k).to("cuda")
+                    targets = synth.synth_targets(2, H, W, seed=100 + it * micro + k).to("cuda")
+                    outputs = model(images)
+                    loss_dict = criterion(outputs, targets)
+                    losses = sum(loss for loss in loss_dict.values())
+                    losses.backward()
+                    losses_seen.append(losses.item())
+                optimizer.step()
+                lr_scheduler.step()
+                continue
             images = synth.synth_images(2, H, W, seed=100 + it).to("cuda")
             targets = synth.synth_targets(2, H, W, seed=100 + it).to("cuda")
             # ---- tools/train.py:135-146, verbatim
@@ -118,6 +133,20 @@ def test_reference_loop_statements_graph_mode_equals_eager_bit_for_bit():
     bad = [k for k in se if not torch.equal(se[k], sg[k])]
     assert not bad, bad[:5]
     assert le[-1] < le[0]  # the loop trains
+
+
+def test_gradient_accumulation_graph_mode_equals_eager_bit_for_bit():
+    """Three forward/backward pairs per optimizer step, no zero_grad in between: the first
+    iteration mixes eager backward passes with the capturing one (the static gradients are ADDED
+    to the accumulated tensors), the later ones accumulate INTO the static buffers (the replay
+    overwrites them: _GraphedSegment.backward keeps the old values when nobody has written to
+    `p.grad` since the previous backward)."""
+    iters, hw = 3, (65, 129)
+    le, se, _ = _run_loop(False, iters, hw, micro=3)
+    lg, sg, _ = _run_loop(True, iters, hw, micro=3)
+    assert le == lg
+    bad = [k for k in se if not torch.equal(se[k], sg[k])]
+    assert not bad, bad[:5]
 
 
 def test_evaluate_graph_mode_equals_eager_bit_for_bit():

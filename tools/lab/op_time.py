@@ -13,6 +13,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from segmentron_amd import hip_ops as K  # noqa: E402
+from segmentron_amd.graph import capture  # noqa: E402
 
 DEV = "cuda"
 
@@ -29,7 +30,7 @@ def timeit(fn, iters):
     with torch.cuda.stream(side):
         fn()
         torch.cuda.synchronize()
-        with torch.cuda.graph(graph, stream=side):
+        with capture(graph, stream=side):
             for _ in range(iters):
                 fn()
     torch.cuda.synchronize()
