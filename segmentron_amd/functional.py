@@ -11,6 +11,7 @@ deferred tensor sum correctly under plain torch autograd.
 Host code here is plumbing (allocation, weight packing, torch.autograd, torch.distributed);
 all arithmetic on activations is done by libsegmentron_hip.so.
 """
+import contextlib
 import dataclasses
 import os
 import weakref
@@ -239,6 +240,24 @@ def clear_weight_cache():
 
 # (id(param), transpose, dtype) -> weakref(param): every plain 1x1 pack requested so far
 _PACK_PLAN = {}
+# ids of the parameters a HIP-graph capture may pack (None: no restriction), see restrict_pack_plan
+_PLAN_FILTER = [None]
+
+
+@contextlib.contextmanager
+def restrict_pack_plan(params):
+    """Inside: `packed_pointwise` re-packs only planned entries of `params`.  Every capture of a
+    model runs under it (segmentron_amd/graph.py): the multi-tensor pack launch of a captured
+    pass must not take ANOTHER model's parameters along — their addresses would be baked into
+    this model's graph and replays would read freed memory once that model is gone (measured
+    r04: an eager PSPNet discarded before a graph-mode PSPNet was built, memory access fault on
+    the first replay after torch.cuda.empty_cache())."""
+    prev = _PLAN_FILTER[0]
+    _PLAN_FILTER[0] = {id(p) for p in params}
+    try:
+        yield
+    finally:
+        _PLAN_FILTER[0] = prev
 # id(alias) -> parameter: graph.TransparentTrainGraph captures on leaf aliases of the parameters
 _PARAM_ALIAS = {}
 
@@ -263,6 +282,8 @@ def packed_pointwise(param, transpose, dtype):
             del _PACK_PLAN[(pid, tr, dt)]
             continue
         if dt != dtype or p.device != param.device:
+            continue
+        if _PLAN_FILTER[0] is not None and pid not in _PLAN_FILTER[0] and p is not param:
             continue
         if _hit(_WCACHE.get((pid, ("pw", tr, dt))), p, scope):
             continue

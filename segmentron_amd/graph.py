@@ -67,7 +67,7 @@ class GraphedInference:
             _warm(lambda: self.model(self.x), warmup)
             F.clear_weight_cache()  # the weight packs must be issued INSIDE the capture
             self.graph = torch.cuda.CUDAGraph()
-            with capture(self.graph):
+            with F.restrict_pack_plan(self.model.parameters()), capture(self.graph):
                 self.out = self.model(self.x)
         torch.cuda.synchronize()
 
@@ -109,7 +109,7 @@ class GraphedTrainStep:
         F.clear_weight_cache()
         optimizer.zero_grad(set_to_none=True)
         self.graph = torch.cuda.CUDAGraph()
-        with capture(self.graph):
+        with F.restrict_pack_plan(model.parameters()), capture(self.graph):
             self.loss = loss_fn(model(self.images), self.targets)
             self.loss.backward()
             if post_backward is not None:
@@ -179,7 +179,8 @@ class _GraphedSegment(torch.autograd.Function):
 
 
 class _Segment:
-    __slots__ = ("fwd", "bwd", "x", "lo", "meta", "grad_lo", "params", "grads", "gver", "anchor")
+    __slots__ = ("fwd", "bwd", "x", "lo", "meta", "grad_lo", "params", "grads", "gver", "anchor",
+                 "container")
 
 
 class TransparentTrainGraph:
@@ -204,7 +205,15 @@ class TransparentTrainGraph:
     Any other call — gradients enabled in evaluation mode, a new shape beyond the limits, a
     model whose BatchNorms synchronise over torch.distributed — takes the eager path, which
     stays correct; parameters may be updated by any optimizer (weight packs are re-issued inside
-    the captured forward).  One process per GPU, one stream."""
+    the captured forward).  One process per GPU, one stream.
+
+    What a loop may rely on (tests/test_train_loop_gpu.py, all bit-identical to eager launches):
+    gradient accumulation over several forward/backward pairs without zero_grad; training,
+    validation (model.eval() under no_grad) and training again on the same object; every model
+    of the zoo (LogitsView outputs, HRNet's materialised tensor, lists and tuples, aux heads).
+    What it may NOT do, as with torch.cuda.make_graphed_callables: keep a training-mode output
+    across the next training forward of the same shape (static tensors), or run two forwards
+    before their two backwards."""
 
     def __init__(self, model, warmup=2, max_shapes=2, max_eval_shapes=6):
         self.model, self.warmup, self.max_shapes = model, int(warmup), int(max_shapes)
@@ -264,7 +273,7 @@ class TransparentTrainGraph:
                 torch.cuda.synchronize()
                 F.clear_weight_cache()  # packs inside the graph: replays follow the optimizer
                 seg.fwd = torch.cuda.CUDAGraph()
-                with capture(seg.fwd):
+                with F.restrict_pack_plan(self.model.parameters()), capture(seg.fwd):
                     outs = self.eager_forward(seg.x)
                 if not all(isinstance(o, torch.Tensor) for o in outs):
                     raise RuntimeError("evaluation capture needs tensor outputs")
@@ -309,7 +318,8 @@ class TransparentTrainGraph:
             self.segments[key] = seg
         seg.x.copy_(x)
         lo = _GraphedSegment.apply(seg.anchor, seg)
-        return tuple(F.LogitsView(t, hw, ac) for t, (hw, ac) in zip(lo, seg.meta))
+        return seg.container(t if m is None else F.LogitsView(t, m[0], m[1])
+                             for t, m in zip(lo, seg.meta))
 
     # -- capture of one shape
     def _capture(self, x):
@@ -341,15 +351,19 @@ class TransparentTrainGraph:
         # multi-tensor pack launch for the whole model instead of one per alias)
         F._PARAM_ALIAS.update({id(a): p for a, p in zip(leaves, seg.params)})
         try:
-            with capture(seg.fwd):
+            with F.restrict_pack_plan(seg.params), capture(seg.fwd):
                 outs = torch.func.functional_call(
                     model, {n: t for (n, _), t in zip(named, leaves)}, (seg.x,))
-            if not all(isinstance(o, F.LogitsView) for o in outs):
-                raise RuntimeError("transparent capture needs LogitsView outputs (training mode)")
-            seg.lo = [o.lo for o in outs]
-            seg.meta = [(o.out_hw, o.align_corners) for o in outs]
+            # outputs: LogitsView (low-resolution logits, upsampled inside the fused loss) or a
+            # materialised tensor (HRNet's align_corners=False boundary)
+            if not all(isinstance(o, (F.LogitsView, torch.Tensor)) for o in outs):
+                raise RuntimeError("transparent capture needs tensor / LogitsView outputs")
+            seg.container = list if isinstance(outs, list) else tuple
+            seg.lo = [o.lo if isinstance(o, F.LogitsView) else o for o in outs]
+            seg.meta = [(o.out_hw, o.align_corners) if isinstance(o, F.LogitsView) else None
+                        for o in outs]
             seg.grad_lo = [torch.zeros_like(t) for t in seg.lo]
-            with capture(seg.bwd):
+            with F.restrict_pack_plan(seg.params), capture(seg.bwd):
                 grads = torch.autograd.grad(seg.lo, leaves, seg.grad_lo, allow_unused=True)
             seg.grads = [None if g is None else (g if g.is_contiguous() else g.contiguous())
                          for g in grads]

@@ -181,3 +181,76 @@ def test_evaluate_graph_mode_equals_eager_bit_for_bit():
     for i, (u, v) in enumerate(zip(a, b)):
         assert torch.equal(u, v), i
     assert not torch.equal(a[0], a[1])
+
+
+def _train_validate_train(tag, graph, hw, epochs=2, iters=4):
+    """tools/train.py's epoch structure: `iters` loop iterations, then `validation()`
+    (train.py:173-199: model.eval(), `model(image)[0]` under no_grad per sample), `model.train()`,
+    and on."""
+    import segmentron_amd
+    import test_more_models as MM
+    from segmentron_amd.config import cfg, reset_cfg
+    from segmentron_amd.solver.lr_scheduler import get_scheduler
+    from segmentron_amd.solver.optimizer import get_optimizer
+    prev = os.environ.get("SEGMENTRON_HIP_GRAPH")
+    os.environ["SEGMENTRON_HIP_GRAPH"] = "1" if graph else "0"
+    try:
+        model, _ = MM._build_hip(tag, torch.bfloat16, True)
+        tg = getattr(model, "_transparent_graph", None)
+        assert (tg is not None) == graph
+        criterion = MixSoftmaxCrossEntropyLoss(aux=True, aux_weight=0.4, ignore_index=-1).cuda()
+        optimizer = get_optimizer(model)
+        lr_scheduler = get_scheduler(optimizer, max_iters=epochs * iters, iters_per_epoch=iters)
+        H, W = hw
+        losses_seen, val_seen = [], []
+        for ep in range(epochs):
+            for it in range(iters):
+                images = synth.synth_images(2, H, W, seed=300 + ep * iters + it).cuda()
+                targets = synth.synth_targets(2, H, W, seed=300 + ep * iters + it).cuda()
+                outputs = model(images)
+                loss_dict = criterion(outputs, targets)
+                losses = sum(loss for loss in loss_dict.values())
+                optimizer.zero_grad()
+                losses.backward()
+                optimizer.step()
+                lr_scheduler.step()
+                losses_seen.append(losses.item())
+            model.eval()
+            for i in range(3):
+                image = synth.synth_images(1, H, W, seed=900 + i).cuda()
+                with torch.no_grad():
+                    output = model(image)[0]
+                val_seen.append(output.float().clone())
+            model.train()
+        torch.cuda.synchronize()
+        if graph:
+            assert tg.disabled is None, tg.disabled
+            assert len(tg.segments) == 1 and len(tg.eval_segments) == 1, \
+                (len(tg.segments), len(tg.eval_segments))
+        state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        return losses_seen, val_seen, state
+    finally:
+        if prev is None:
+            os.environ.pop("SEGMENTRON_HIP_GRAPH", None)
+        else:
+            os.environ["SEGMENTRON_HIP_GRAPH"] = prev
+        reset_cfg()
+
+
+@pytest.mark.parametrize("tag", ["c4", "c5", "c7", "c8", "c6"])
+def test_train_validate_train_graph_mode_equals_eager_bit_for_bit(tag):
+    """PSPNet (aux head), HRNet, Fast-SCNN (two aux heads), DANet (three outputs), CCNet through
+    the epoch structure of tools/train.py with SEGMENTRON_HIP_GRAPH=1: the training graphs keep
+    replaying after the evaluation-mode graph of the validation pass was captured between them,
+    validation reads the running statistics the training replays wrote.  Bit-identical to eager
+    launches: every loss, every validation output, every parameter and buffer."""
+    import test_more_models as MM
+    hw = MM.CASES[tag]["hw"]
+    le, ve, se = _train_validate_train(tag, False, hw)
+    lg, vg, sg = _train_validate_train(tag, True, hw)
+    assert le == lg, (le, lg)
+    for i, (a, b) in enumerate(zip(ve, vg)):
+        assert torch.equal(a, b), ("validation output", i)
+    bad = [k for k in se if not torch.equal(se[k], sg[k])]
+    assert not bad, bad[:5]
+    assert not torch.equal(ve[0], ve[3])  # the second epoch validates an updated model
