@@ -227,7 +227,21 @@ def cached_pack(param, kind, builder):
         return ent[3]
     val = builder()
     _WCACHE[key] = (param._version, param.data_ptr(), weakref.ref(param), val, scope)
+    _note_miss()
     return val
+
+
+_MISSES = [0]
+
+
+def _note_miss(every=256):
+    """Entries are keyed on `id(param)`: those of parameters that no longer exist (a discarded
+    model) would keep their packed copies alive until an unrelated tensor happens to reuse the
+    id.  Every `every` misses (one optimizer step of a large model) the dead ones are dropped."""
+    _MISSES[0] += 1
+    if _MISSES[0] % every == 0:
+        for k in [k for k, ent in _WCACHE.items() if ent[2]() is None]:
+            del _WCACHE[k]
 
 
 def clear_weight_cache():
@@ -291,6 +305,7 @@ def packed_pointwise(param, transpose, dtype):
     outs = K.pack_multi([(p.detach().view(p.shape[0], p.shape[1]), tr) for p, tr in todo], dtype)
     for (p, tr), val in zip(todo, outs):
         _WCACHE[(id(p), ("pw", tr, dtype))] = (p._version, p.data_ptr(), weakref.ref(p), val, scope)
+        _note_miss()
     return _WCACHE[key][3]
 
 

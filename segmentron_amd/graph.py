@@ -36,6 +36,7 @@ def capture(graph, **kw):
     two graph-mode models built one after the other).  torch >= 2.10 no longer collects on entry
     (torch.compiler.config.force_cudagraph_gc), so: collect BEFORE, keep the collector off until
     the capture has ended (reference-counted frees go through the caching allocator as usual)."""
+    F.flush_bn_counters()  # (left pending by a forward that raised: not this capture's business)
     gc.collect()
     was_enabled = gc.isenabled()
     gc.disable()

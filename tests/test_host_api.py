@@ -308,3 +308,52 @@ def test_frozen_batchnorm_module_contract():
     want = torch.nn.functional.batch_norm(x, m.running_mean, m.running_var, m.weight, m.bias,
                                           False, 0.0, m.eps)
     assert torch.allclose(ref, want, atol=1e-6)
+
+
+def test_weight_cache_bookkeeping_on_the_host():
+    """functional.cached_pack / packed-weight plan, the parts that need no device: entries of
+    parameters that no longer exist are dropped (every 256th miss), a hit needs the same object,
+    version and storage, and `restrict_pack_plan` names the parameters a capture may pack."""
+    import gc
+
+    import torch
+    from segmentron_amd import functional as F
+    F.clear_weight_cache()
+    keep = torch.nn.Parameter(torch.ones(4, 4))
+    calls = []
+
+    def builder(p):
+        def make():
+            calls.append(1)
+            return p.detach().clone()
+        return make
+    a = F.cached_pack(keep, "k", builder(keep))
+    assert F.cached_pack(keep, "k", builder(keep)) is a and len(calls) == 1      # hit
+    with torch.no_grad():
+        keep.add_(1.0)                                                           # version bump
+    b = F.cached_pack(keep, "k", builder(keep))
+    assert b is not a and len(calls) == 2 and float(b[0, 0]) == 2.0
+    # a discarded model's entries go away without an explicit clear
+    dead = [torch.nn.Parameter(torch.zeros(8)) for _ in range(40)]
+    for p in dead:
+        F.cached_pack(p, "k", builder(p))
+    n_before = len(F._WCACHE)
+    assert n_before >= 41
+    del dead, p
+    gc.collect()
+    for _ in range(256):  # misses on a live parameter: the purge runs at least once
+        with torch.no_grad():
+            keep.add_(1.0)
+        F.cached_pack(keep, "k", builder(keep))
+    assert len(F._WCACHE) <= 2, len(F._WCACHE)
+    assert (id(keep), "k") in F._WCACHE
+    # the capture-time restriction of the multi-tensor pack plan
+    assert F._PLAN_FILTER[0] is None
+    other = torch.nn.Parameter(torch.ones(2))
+    with F.restrict_pack_plan([keep]):
+        assert id(keep) in F._PLAN_FILTER[0] and id(other) not in F._PLAN_FILTER[0]
+        with F.restrict_pack_plan([other]):
+            assert id(other) in F._PLAN_FILTER[0] and id(keep) not in F._PLAN_FILTER[0]
+        assert id(keep) in F._PLAN_FILTER[0]
+    assert F._PLAN_FILTER[0] is None
+    F.clear_weight_cache()
