@@ -119,7 +119,7 @@ int main(int argc, char** argv) {
       CK(hipMemcpy(a.data(), g[0], elems * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(b.data(), g[1], elems * 2, hipMemcpyDeviceToHost));
       const long dgb = count_diff(a, b, md); const double mdb = md;
       // reduced partials (the partial-row counts of the two builds may differ): column sums in fp64
-      auto colsum = [&](float* dev, long R, int L_) { std::vector<float> h(R * L_); hipMemcpy(h.data(), dev, R * L_ * 4, hipMemcpyDeviceToHost);
+      auto colsum = [&](float* dev, long R, int L_) { std::vector<float> h(R * L_); (void)hipMemcpy(h.data(), dev, R * L_ * 4, hipMemcpyDeviceToHost);
         std::vector<float> o(L_); for (int c = 0; c < L_; ++c) { double s = 0; for (long r = 0; r < R; ++r) s += h[r * L_ + c]; o[c] = (float)s; } return o; };
       double m1, m2, m3;
       const long d1 = count_diff_f(colsum(sp[0], gy[0][0], 2 * C), colsum(sp[1], gy[1][0], 2 * C), m1);
@@ -129,10 +129,10 @@ int main(int argc, char** argv) {
       printf("  mode %d  fwd %7.2f -> %7.2f us (%5.0f -> %5.0f GB/s)   bwd %7.2f -> %7.2f us   | y diff %ld (max %.3g)  g diff %ld (max %.3g)"
              "  stats %ld (%.3g)  dW %ld (%.3g)  bn sums %ld (%.3g)\n", mode, us[0][0], us[1][0], gb / us[0][0], gb / us[1][0],
              us[0][1], us[1][1], dyf, mdf, dgb, mdb, d1, m1, d2, m2, d3, m3);
-      for (int k = 0; k < 2; ++k) { hipFree(sp[k]); hipFree(pw[k]); hipFree(pb[k]); }
+      for (int k = 0; k < 2; ++k) { (void)hipFree(sp[k]); (void)hipFree(pw[k]); (void)hipFree(pb[k]); }
     }
-    hipFree(x); hipFree(dy); hipFree(w); hipFree(sc); hipFree(shf);
-    for (int k = 0; k < 2; ++k) { hipFree(y[k]); hipFree(g[k]); }
+    (void)hipFree(x); (void)hipFree(dy); (void)hipFree(w); (void)hipFree(sc); (void)hipFree(shf);
+    for (int k = 0; k < 2; ++k) { (void)hipFree(y[k]); (void)hipFree(g[k]); }
   }
   printf("per-step estimate (launch counts of C3, 2/3 of the launches with the affine prologue): forward %.2f -> %.2f ms, fused backward %.2f -> %.2f ms\n",
          tot[0][0] / 1e3, tot[1][0] / 1e3, tot[0][1] / 1e3, tot[1][1] / 1e3);
