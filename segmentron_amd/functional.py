@@ -388,6 +388,7 @@ class _ConvFn(torch.autograd.Function):
         # it exactly; it only re-enters running_mean (finish_bn mean_offset), its gradient is 0
         y, spec.partial = K.conv_gemm(x, wp, O, KH, KW, spec.stride, spec.pad, spec.dil, spec.pro,
                                       None if spec.drop_bias else bias, spec.out, spec.want_stats)
+        spec.out = None  # (it IS y: kept, ctx -> spec -> y -> grad_fn -> ctx would be a cycle)
         ctx.spec = spec
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
@@ -468,6 +469,7 @@ class _FoldConvFn(torch.autograd.Function):
         bias = None if spec.drop_const else bp
         y, spec.partial = K.conv_gemm(x, wp, O, 1, 1, spec.stride, 0, 1, None, bias, spec.out,
                                       spec.want_stats)
+        spec.out = None  # (it IS y: kept, ctx -> spec -> y -> grad_fn -> ctx would be a cycle)
         ctx.spec = spec
         ctx.wpt = wpt
         ctx.save_for_backward(x, weight)
@@ -527,6 +529,7 @@ class _DwFn(torch.autograd.Function):
             w = cached_pack(weight, "dw", lambda: pack_dw_weight(weight))
         y, spec.partial = K.dwconv(x, w, spec.stride, spec.dil, spec.pro, spec.out,
                                    spec.want_stats)
+        spec.out = None  # (it IS y: kept, ctx -> spec -> y -> grad_fn -> ctx would be a cycle)
         ctx.spec = spec
         ctx.save_for_backward(x, weight)
         return y
@@ -636,6 +639,7 @@ class _ApplyFn(torch.autograd.Function):
     def forward(ctx, x, gx, bx, r, gr, br, spec):
         y = K.bn_apply(x, spec.pro_x, r, spec.pro_r, spec.chan_mul, spec.post_relu, spec.out,
                        spec.elem_mul)
+        spec.out = None  # (it IS y: kept, ctx -> spec -> y -> grad_fn -> ctx would be a cycle)
         ctx.spec = spec
         ctx.has_r = r is not None
         if spec.post_relu:
@@ -677,6 +681,7 @@ class _AddUpFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gx, bx, r, gr, br, spec):
         y = K.nearest_add(x, spec.pro_x, r, spec.pro_r, spec.shift, spec.post_relu, spec.out)
+        spec.out = None  # (it IS y: kept, ctx -> spec -> y -> grad_fn -> ctx would be a cycle)
         ctx.spec = spec
         if spec.post_relu:
             ctx.save_for_backward(x, r, y)
@@ -713,6 +718,7 @@ class _BilinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, spec):
         y = K.bilinear(x, spec.out_hw, spec.pro, spec.chan_mul, spec.align, spec.out)
+        spec.out = None  # (it IS y: kept, ctx -> spec -> y -> grad_fn -> ctx would be a cycle)
         ctx.spec = spec
         ctx.save_for_backward(x)
         return y
