@@ -154,6 +154,19 @@ int seg_bn_finalize_small(int dtype, const void* y, long ldy, long M, int C, con
                           const float* beta, float eps, float momentum, float* running_mean,
                           float* running_var, float* mean, float* invstd, float* scale,
                           float* shift, const float* mean_offset, void* stream);
+/* ... under SyncBatchNorm (torch.nn.SyncBatchNorm / the reference's NaiveSyncBatchNorm,
+ * segmentron/modules/batch_norm.py:135-176): every rank takes ITS rows' two-pass moments and the
+ * ranks merge them as float64 sums (n*mean_r, M2_r + n*mean_r^2, n).  seg_bn_moments_small writes
+ * those 2C + 1 doubles for a torch.distributed all-reduce followed by seg_bn_finalize;
+ * seg_bn_finalize_small_sync merges them through the peer mailbox inside the launch (count_out =
+ * the global element count, as seg_bn_finalize_p_sync). */
+int seg_bn_moments_small(int dtype, const void* y, long ldy, long M, int C, double* moments,
+                         void* stream);
+int seg_bn_finalize_small_sync(void* p2p, int dtype, const void* y, long ldy, long M, int C,
+                               const float* gamma, const float* beta, float eps, float momentum,
+                               float* running_mean, float* running_var, float* mean, float* invstd,
+                               float* scale, float* shift, const float* mean_offset,
+                               double* count_out, void* stream);
 /* y = xs[0] + ... + xs[n-1] (2 <= n <= 8 NHWC operands of M rows x C channels, row pitches lds[],
  * host arrays of device pointers / pitches), fp32 accumulation in index order, one rounding: the
  * gradient of an activation with several consumers (torch autograd: n-1 `add` launches). */

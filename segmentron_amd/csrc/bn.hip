@@ -472,7 +472,8 @@ __global__ __launch_bounds__(EW_THREADS) void bn_finalize_small_kernel(
     const T* __restrict__ y, long ldy, int M, double count, const float* __restrict__ gamma,
     const float* __restrict__ beta, float eps, float momentum, float* running_mean,
     float* running_var, float* mean_o, float* invstd_o, float* scale_o, float* shift_o, int C,
-    const float* __restrict__ mean_offset) {
+    const float* __restrict__ mean_offset, const P2PDev p2p, double* count_out,
+    double* moments_out) {
   __shared__ double red[32][9];
   __shared__ double s_mean[8];
   const int cx = threadIdx.x & 7, ry = threadIdx.x >> 3;
@@ -506,19 +507,43 @@ __global__ __launch_bounds__(EW_THREADS) void bn_finalize_small_kernel(
     }
   red[ry][cx] = a;
   __syncthreads();
-  if (!fin) return;
   double ss = 0.0;
+  if (ry == 0) {
 #pragma unroll
-  for (int k = 0; k < 32; ++k) ss += red[k][cx];
-  const double var = ss / count;
+    for (int k = 0; k < 32; ++k) ss += red[k][cx];
+  }
+  double mean_g = mean, var = ss / count;
+  if (p2p.world || moments_out) {
+    // SyncBatchNorm over a small tensor: this rank's TWO-PASS moments (mean_r, M2_r) are turned
+    // into float64 sums (n*mean_r, M2_r + n*mean_r^2) and merged over the ranks — the parallel
+    // (Chan) update in sum form; in float64 its cancellation is 1e-16 * mean^2, not the
+    // 6e-8 * mean^2 of fp32 partial rows (the synchronised path kept E[x^2] - mean^2
+    // on fp32 partials where the single-process path already took the statistics two-pass)
+    double v[3] = {count * mean, ss + count * mean * mean, count};
+    if (moments_out) {  // torch.distributed path: the all-reduce and seg_bn_finalize follow
+      if (fin) {
+        moments_out[c] = v[0];
+        moments_out[C + c] = v[1];
+      }
+      if (blockIdx.x == 0 && threadIdx.x == 0) moments_out[2 * C] = count;
+      return;
+    }
+    p2p_block_exchange<3>(p2p, blockIdx.x, gridDim.x, ry == 0, cx, 8, v);
+    count = v[2];
+    mean_g = v[0] / count;
+    var = v[1] / count - mean_g * mean_g;
+    if (var < 0.0) var = 0.0;
+    if (count_out && blockIdx.x == 0 && threadIdx.x == 0) *count_out = count;
+  }
+  if (!fin) return;
   const double invstd = 1.0 / sqrt(var + (double)eps);
-  mean_o[c] = (float)mean;
+  mean_o[c] = (float)mean_g;
   invstd_o[c] = (float)invstd;
   scale_o[c] = (float)((double)g * invstd);
-  shift_o[c] = (float)((double)b - mean * (double)g * invstd);
+  shift_o[c] = (float)((double)b - mean_g * (double)g * invstd);
   if (running_mean) {
     const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-    running_mean[c] = (float)((1.0 - momentum) * (double)rm + momentum * (mean + (double)moff));
+    running_mean[c] = (float)((1.0 - momentum) * (double)rm + momentum * (mean_g + (double)moff));
     running_var[c] = (float)((1.0 - momentum) * (double)rv + momentum * unbiased);
   }
 }
@@ -917,26 +942,65 @@ extern "C" int seg_bn_finalize_p(const float* partial, long R, double count, con
   return check_launch("bn_finalize_p");
 }
 
-extern "C" int seg_bn_finalize_small(int dtype, const void* y, long ldy, long M, int C,
-                                     const float* gamma, const float* beta, float eps,
-                                     float momentum, float* running_mean, float* running_var,
-                                     float* mean, float* invstd, float* scale, float* shift,
-                                     const float* mean_offset, void* stream) {
+static int launch_bn_finalize_small(const char* what, int dtype, const void* y, long ldy, long M,
+                                    int C, const float* gamma, const float* beta, float eps,
+                                    float momentum, float* running_mean, float* running_var,
+                                    float* mean, float* invstd, float* scale, float* shift,
+                                    const float* mean_offset, const seg::P2PDev& d,
+                                    double* count_out, double* moments_out, void* stream) {
   using namespace seg;
-  SEG_REQUIRE(M >= 1 && M <= 4096 && C >= 1 && ldy >= C, "bn_finalize_small: bad M/C/pitch");
-  SEG_REQUIRE(dtype == DT_F32 || dtype == DT_BF16, "bn_finalize_small: bad dtype");
+  SEG_REQUIRE(M >= 1 && M <= 4096 && C >= 1 && ldy >= C, "%s: bad M/C/pitch", what);
+  SEG_REQUIRE(dtype == DT_F32 || dtype == DT_BF16, "%s: bad dtype", what);
   const dim3 grid((C + 7) / 8);
   if (dtype == DT_BF16)
     hipLaunchKernelGGL((bn_finalize_small_kernel<bf16_t>), grid, dim3(EW_THREADS), 0,
                        (hipStream_t)stream, (const bf16_t*)y, ldy, (int)M, (double)M, gamma, beta,
                        eps, momentum, running_mean, running_var, mean, invstd, scale, shift, C,
-                       mean_offset);
+                       mean_offset, d, count_out, moments_out);
   else
     hipLaunchKernelGGL((bn_finalize_small_kernel<float>), grid, dim3(EW_THREADS), 0,
                        (hipStream_t)stream, (const float*)y, ldy, (int)M, (double)M, gamma, beta,
                        eps, momentum, running_mean, running_var, mean, invstd, scale, shift, C,
-                       mean_offset);
-  return check_launch("bn_finalize_small");
+                       mean_offset, d, count_out, moments_out);
+  return check_launch(what);
+}
+
+extern "C" int seg_bn_finalize_small(int dtype, const void* y, long ldy, long M, int C,
+                                     const float* gamma, const float* beta, float eps,
+                                     float momentum, float* running_mean, float* running_var,
+                                     float* mean, float* invstd, float* scale, float* shift,
+                                     const float* mean_offset, void* stream) {
+  return launch_bn_finalize_small("bn_finalize_small", dtype, y, ldy, M, C, gamma, beta, eps,
+                                  momentum, running_mean, running_var, mean, invstd, scale, shift,
+                                  mean_offset, seg::p2p_dev_none(), nullptr, nullptr, stream);
+}
+
+// SyncBatchNorm over a small tensor, torch.distributed path: this rank's two-pass moments as
+// float64 sums [2C + 1] = (n*mean_r | M2_r + n*mean_r^2 | n) — all-reduce, then seg_bn_finalize.
+extern "C" int seg_bn_moments_small(int dtype, const void* y, long ldy, long M, int C,
+                                    double* moments, void* stream) {
+  SEG_REQUIRE(moments != nullptr, "bn_moments_small: no output");
+  return launch_bn_finalize_small("bn_moments_small", dtype, y, ldy, M, C, nullptr, nullptr, 0.f,
+                                  0.f, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                  nullptr, seg::p2p_dev_none(), nullptr, moments, stream);
+}
+
+// ... peer-mailbox path: moments merged inside the launch (as seg_bn_finalize_p_sync)
+extern "C" int seg_bn_finalize_small_sync(void* p2p, int dtype, const void* y, long ldy, long M,
+                                          int C, const float* gamma, const float* beta, float eps,
+                                          float momentum, float* running_mean, float* running_var,
+                                          float* mean, float* invstd, float* scale, float* shift,
+                                          const float* mean_offset, double* count_out,
+                                          void* stream) {
+  using namespace seg;
+  P2PDev d;
+  if (!p2p_dev_of(p2p, d)) return 2;
+  const int nb = (C + 7) / 8;
+  SEG_REQUIRE(nb <= P2P_MAX_BLOCKS && (long)nb * 8 * 3 * 8 <= d.slot_bytes,
+              "bn_finalize_small_sync: C=%d exceeds the mailbox", C);
+  return launch_bn_finalize_small("bn_finalize_small_sync", dtype, y, ldy, M, C, gamma, beta, eps,
+                                  momentum, running_mean, running_var, mean, invstd, scale, shift,
+                                  mean_offset, d, count_out, nullptr, stream);
 }
 
 extern "C" int seg_bn_bwd_finalize_p(const float* partial, long R, double count,

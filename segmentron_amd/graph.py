@@ -36,7 +36,8 @@ def capture(graph, **kw):
     two graph-mode models built one after the other).  torch >= 2.10 no longer collects on entry
     (torch.compiler.config.force_cudagraph_gc), so: collect BEFORE, keep the collector off until
     the capture has ended (reference-counted frees go through the caching allocator as usual)."""
-    F.flush_bn_counters()  # (left pending by a forward that raised: not this capture's business)
+    # (BatchNorm counter increments are owned by functional.bn_counter_scope: nothing can be
+    # pending between two model forwards, so a capture neither flushes nor drops anything)
     gc.collect()
     was_enabled = gc.isenabled()
     gc.disable()
@@ -159,15 +160,16 @@ class _GraphedSegment(torch.autograd.Function):
             else:
                 buf.copy_(g)
         with torch.no_grad():
-            # `p.grad` still IS the static buffer of the previous backward and nobody wrote to it
-            # since (zero_grad(set_to_none=False) / clipping bump its version counter, a replay
-            # does not): the caller accumulates gradients over several backward calls — keep
-            # the old values, the replay overwrites the buffers
-            held = [(g, g.clone()) for p, g, v in zip(seg.params, seg.grads, seg.gver)
-                    if g is not None and p.grad is g and g._version == v]
+            # `p.grad` still IS the static buffer of an earlier backward: the caller accumulates
+            # gradients over several backward calls (or scaled / clipped / zeroed them in place —
+            # a version counter cannot tell these apart, so nothing is inferred from it): keep
+            # the current values, the replay overwrites the buffers, add them back.  The
+            # reference's loop (zero_grad() -> set_to_none) never takes this path.
+            held = [g for p, g in zip(seg.params, seg.grads) if g is not None and p.grad is g]
+            old = [g.clone() for g in held]
             seg.bwd.replay()
-            for g, old in held:
-                g.add_(old)
+            if held:
+                torch._foreach_add_(held, old)
             for p, g in zip(seg.params, seg.grads):
                 if g is None:
                     continue
@@ -175,12 +177,11 @@ class _GraphedSegment(torch.autograd.Function):
                     p.grad = g
                 else:  # gradient accumulation / zero_grad(set_to_none=False) on another tensor
                     p.grad.add_(g)
-            seg.gver = [None if g is None else g._version for g in seg.grads]
         return None, None
 
 
 class _Segment:
-    __slots__ = ("fwd", "bwd", "x", "lo", "meta", "grad_lo", "params", "grads", "gver", "anchor",
+    __slots__ = ("fwd", "bwd", "x", "lo", "meta", "grad_lo", "params", "grads", "anchor",
                  "container")
 
 
@@ -366,9 +367,11 @@ class TransparentTrainGraph:
             seg.grad_lo = [torch.zeros_like(t) for t in seg.lo]
             with F.restrict_pack_plan(seg.params), capture(seg.bwd):
                 grads = torch.autograd.grad(seg.lo, leaves, seg.grad_lo, allow_unused=True)
-            seg.grads = [None if g is None else (g if g.is_contiguous() else g.contiguous())
-                         for g in grads]
-            seg.gver = [None] * len(seg.grads)
+            # (a .contiguous() copy taken here would NOT be a node of the graph: replays would
+            # never refresh it)
+            if any(g is not None and not g.is_contiguous() for g in grads):
+                raise RuntimeError("transparent capture needs contiguous parameter gradients")
+            seg.grads = list(grads)
             torch.cuda.synchronize()
         finally:  # (ids of dead aliases would be recycled by unrelated tensors)
             for a in leaves:

@@ -456,6 +456,28 @@ def bn_finalize_small(y, gamma, beta, eps, momentum, running_mean, running_var, 
     return out[0], out[1], out[2], out[3]
 
 
+def bn_moments_small(y):
+    """This rank's two-pass moments of a small stored tensor as float64 sums [2C + 1] =
+    (n*mean | M2 + n*mean^2 | n): the SyncBatchNorm forward message of a small BatchNorm."""
+    N, H, W, C, ldy = nhwc(y)
+    out = torch.empty(2 * C + 1, dtype=torch.float64, device=y.device)
+    LIB.call("seg_bn_moments_small", _DT[y.dtype], _p(y), ldy, N * H * W, C, _p(out), _stream())
+    return out
+
+
+def bn_finalize_small_sync(box, y, gamma, beta, eps, momentum, running_mean, running_var,
+                           mean_offset=None):
+    """bn_finalize_small for SyncBatchNorm through the peer mailbox (one launch) -> mean, invstd,
+    scale, shift, global count (float64 [1])."""
+    N, H, W, C, ldy = nhwc(y)
+    out = torch.empty((4, C), dtype=torch.float32, device=y.device)
+    cnt = torch.empty(1, dtype=torch.float64, device=y.device)
+    LIB.call("seg_bn_finalize_small_sync", box.handle, _DT[y.dtype], _p(y), ldy, N * H * W, C,
+             _p(gamma), _p(beta), float(eps), float(momentum), _p(running_mean), _p(running_var),
+             _p(out[0]), _p(out[1]), _p(out[2]), _p(out[3]), _p(mean_offset), _p(cnt), _stream())
+    return out[0], out[1], out[2], out[3], cnt
+
+
 def bn_finalize_p_sync(box, partial, local_count, gamma, beta, eps, momentum, running_mean,
                        running_var, mean_offset=None):
     """bn_finalize_p for SyncBatchNorm in ONE launch: this rank's partial rows are summed, the

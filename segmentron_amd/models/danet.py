@@ -28,7 +28,6 @@ class DANet(SegBaseModel):
         lazy = F.want_lazy_logits(self.training)
         _, _, _, c4 = self.encoder(x)
         outs = self.head(c4)
-        F.flush_bn_counters()
         return tuple(F.logits_to_nchw(y, size, align_corners=True, lazy=lazy) for y in outs)
 
 

@@ -36,7 +36,6 @@ class DeepLabV3Plus(SegBaseModel):
         outputs = [F.logits_to_nchw(y, size, align_corners=True, lazy=lazy)]
         if self.aux:
             outputs.append(F.logits_to_nchw(self.auxlayer(c3), size, align_corners=True, lazy=lazy))
-        F.flush_bn_counters()
         return tuple(outputs)
 
 

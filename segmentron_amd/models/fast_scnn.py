@@ -74,7 +74,6 @@ class FastSCNN(SegBaseModel):
                 a = _dropout2d(a, head[3], self.training)
                 outputs.append(F.logits_to_nchw(_logits(a, head[4], self.nclass), size,
                                                 align_corners=True, lazy=lazy))
-        F.flush_bn_counters()
         return tuple(outputs)
 
 

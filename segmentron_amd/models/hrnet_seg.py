@@ -24,7 +24,6 @@ class HighResolutionNet(SegBaseModel):
         feats = self.encoder(x)
         logits = self.hrnet_head(feats)
         out = F.logits_to_nchw(logits, shape, align_corners=False)
-        F.flush_bn_counters()
         return [out]
 
 

@@ -29,7 +29,6 @@ class PSPNet(SegBaseModel):
         outputs = [F.logits_to_nchw(self.head(c4), size, align_corners=True, lazy=lazy)]
         if self.aux:
             outputs.append(F.logits_to_nchw(self.auxlayer(c3), size, align_corners=True, lazy=lazy))
-        F.flush_bn_counters()
         return tuple(outputs)
 
 

@@ -1,10 +1,12 @@
 """SegBaseModel — contract of segmentron/models/segbase.py:16-79."""
+import functools
 import math
 
 import torch
 import torch.nn as nn
 import torch.nn.functional as TF
 
+from .. import functional as F
 from ..config import cfg
 from ..data.dataloader import datasets
 from ..modules import get_norm
@@ -14,6 +16,22 @@ __all__ = ["SegBaseModel"]
 
 
 class SegBaseModel(nn.Module):
+    def __init_subclass__(cls, **kw):
+        """Every model's own `forward` runs inside a functional.bn_counter_scope: the
+        `num_batches_tracked` increments of its BatchNorms (torch nn.BatchNorm2d semantics, e.g.
+        reference ccnet.py:57-86) are applied as one launch when the forward returns and dropped
+        when it raises — whether it is entered through `model(x)`, `evaluate()`'s
+        `self.forward(x)` or a graph capture.  No model file carries the flush itself."""
+        super().__init_subclass__(**kw)
+        fwd = cls.__dict__.get("forward")
+        if fwd is not None and not getattr(fwd, "_bn_counter_scoped", False):
+            @functools.wraps(fwd)
+            def forward(self, *args, **kwargs):
+                with F.bn_counter_scope():
+                    return fwd(self, *args, **kwargs)
+            forward._bn_counter_scoped = True
+            cls.forward = forward
+
     def __init__(self, need_backbone=True):
         super().__init__()
         self.nclass = datasets[cfg.DATASET.NAME].NUM_CLASS

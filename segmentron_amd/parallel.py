@@ -236,6 +236,14 @@ def allreduce_forward_sums(partial2d, local_count, group):
     return buf[:n], buf[n:]
 
 
+def allreduce_moments(buf, group):
+    """buf: float64 [2C + 1] = this rank's (n*mean | M2 + n*mean^2 | n) of a SMALL BatchNorm
+    (hip_ops.bn_moments_small) -> (global sums [2C], global count [1]), in place."""
+    _all_reduce(buf, group)
+    n = buf.numel() - 1
+    return buf[:n], buf[n:]
+
+
 def allreduce_backward_sums(sums, group):
     """sums: [2C] local (sum g', sum g'*x) or (ds, dt) -> global, in place."""
     _all_reduce(sums, group)

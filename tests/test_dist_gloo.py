@@ -77,6 +77,28 @@ def _worker(rank, world, port, ret):
         avg /= world  # DDP averages
         assert torch.allclose(avg[0], gamma.grad / world, rtol=1e-9, atol=1e-11)
         assert torch.allclose(avg[1], beta.grad / world, rtol=1e-9, atol=1e-11)
+        # ---- SMALL SyncBatchNorm (ASPP image pooling: a few samples per rank with a mean far
+        # from zero): per-rank two-pass moments merged as float64 sums (what
+        # seg_bn_moments_small / seg_bn_finalize_small_sync compute) reproduce the full-batch
+        # two-pass variance where fp32 (sum x, sum x^2) rows lose it entirely
+        base = torch.full((C,), 37.5, dtype=torch.float64)
+        small = (base.view(1, C) + torch.randn(N, C, dtype=torch.float64) * 1e-3).float().double()
+        part = small[lo:hi]
+        n_r = float(part.shape[0])
+        m_r = part.mean(0)
+        m2_r = ((part - m_r) ** 2).sum(0)
+        buf = torch.cat([n_r * m_r, m2_r + n_r * m_r * m_r, torch.tensor([n_r], dtype=torch.float64)])
+        msum, mcnt = parallel.allreduce_moments(buf, group)
+        assert float(mcnt) == N
+        gmean = msum[:C] / mcnt
+        gvar = msum[C:] / mcnt - gmean * gmean
+        want_var = small.var(0, unbiased=False)
+        assert torch.allclose(gmean, small.mean(0), rtol=1e-14, atol=0)
+        assert (gvar - want_var).abs().max() < 1e-3 * want_var.min() + 1e-12, \
+            (gvar - want_var).abs().max()
+        f32 = small.float()
+        bad_var = (f32 * f32).sum(0) / N - (f32.sum(0) / N) ** 2  # the fp32 single-pass form
+        assert (bad_var.double() - want_var).abs().max() > 10 * want_var.max()
         # ---- the reference's own NaiveSyncBatchNorm (modules/batch_norm.py:150-183): an
         # nn.BatchNorm2d that syncs when training on > 1 rank, biased running_var, no counter
         from segmentron_amd.modules.batch_norm import NaiveSyncBatchNorm

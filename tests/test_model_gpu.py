@@ -106,7 +106,11 @@ def test_train_step_fp32_matches_reference_fixture():
     assert int(msd["encoder.bn1.num_batches_tracked"]) == 1
 
     torch.set_num_threads(min(16, os.cpu_count()))
-    _, l64, g64, _ = _oracle_train(sd, x, y, torch.float64)
+    _, l64, g64, ostate = _oracle_train(sd, x, y, torch.float64)
+    # every BatchNorm counter against the oracle's (torch nn.BatchNorm2d: +1 per training forward)
+    counters = [k for k in msd if k.endswith("num_batches_tracked")]
+    bad = [(k, int(msd[k]), int(ostate[k])) for k in counters if int(msd[k]) != int(ostate[k])]
+    assert counters and not bad, bad[:5]
     _, l32, g32, _ = _oracle_train(sd, x, y, torch.float32)
     params = dict(model.named_parameters())
     num_h = num_c = den = 0.0

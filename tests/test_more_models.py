@@ -235,6 +235,14 @@ def test_hip_train_fp32_matches_reference(tag):
         if k.startswith("stat::"):
             ref = torch.from_numpy(t[k])
             assert (msd[k[6:]].cpu() - ref).abs().max().item() <= 1e-3 * ref.abs().max().item() + 1e-6, k
+    # torch nn.BatchNorm2d: every training forward advances num_batches_tracked of every BatchNorm
+    # it ran (CCNet's never did) — EVERY counter against the oracle's own
+    counters = [k for k in msd if k.endswith("num_batches_tracked")]
+    assert counters and any(int(ostate[k]) == 1 for k in counters)
+    bad = [(k, int(msd[k]), int(ostate[k])) for k in counters if int(msd[k]) != int(ostate[k])]
+    assert not bad, bad[:5]
+    from segmentron_amd import functional as HF
+    assert not HF._PENDING_COUNTERS and HF._COUNTER_SCOPE[0] == 0
     params = dict(model.named_parameters())
     # Near-tie ReLUs: a pre-activation within fp32 rounding of zero may land on the other side in
     # a different (equally valid) fp32 evaluation order; one flip at HRNet's 4x8 / 2x4 branches

@@ -177,21 +177,15 @@ def _worker(rank, world, port, ret, naive=False, native=False, case="c5"):
 def test_syncbn_ddp_two_ranks_match_full_batch(naive, native, case):
     world = 2
     # single-process full batch: plain BatchNorm (a lone NaiveSyncBatchNorm process IS plain BN).
-    # The synchronised path sums (sum x, sum x^2) over the ranks; the single-process path takes
-    # the statistics of SMALL tensors two-pass instead (hip_ops.SMALL_BN_ROWS, r04) — switched
-    # off for this reference run so that both sides do the same arithmetic and the comparison
-    # isolates the exchange (the default synth state amplifies a 2e-5 forward difference to
-    # 1.6e-2 in the gradients)
-    from segmentron_amd import hip_ops
+    # SMALL BatchNorms (hip_ops.SMALL_BN_ROWS: ASPP image pooling, pyramid bins) take their
+    # statistics two-pass on BOTH sides since r05 — per rank, merged as float64 moments under a
+    # group (seg_bn_finalize_small_sync / seg_bn_moments_small) — so the default setting is
+    # compared with the default setting.
     model = _build(naive, case)
     x, y = _data(world)
-    small, hip_ops.SMALL_BN_ROWS = hip_ops.SMALL_BN_ROWS, 0
-    try:
-        out = model(x.cuda())
-        loss = torch.nn.functional.cross_entropy(out[0], y.cuda())
-        loss.backward()
-    finally:
-        hip_ops.SMALL_BN_ROWS = small
+    out = model(x.cuda())
+    loss = torch.nn.functional.cross_entropy(out[0], y.cuda())
+    loss.backward()
     ref_logits = out[0].detach().cpu()
     ref_grads = {k: p.grad.detach().cpu() for k, p in model.named_parameters()
                  if p.grad is not None}  # (ResNet's unused classifier `fc` has none)

@@ -228,6 +228,14 @@ def _train_validate_train(tag, graph, hw, epochs=2, iters=4):
             assert len(tg.segments) == 1 and len(tg.eval_segments) == 1, \
                 (len(tg.segments), len(tg.eval_segments))
         state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        # the KNOWN iteration count, not only eager == graph (r04: both sides were equally wrong):
+        # every BatchNorm that runs in a training forward has counted every one of them
+        counters = {k: int(v) for k, v in state.items() if k.endswith("num_batches_tracked")}
+        assert counters and set(counters.values()) <= {0, epochs * iters}, \
+            sorted(set(counters.values()))
+        assert sum(v == epochs * iters for v in counters.values()) >= len(counters) // 2
+        from segmentron_amd import functional as HF
+        assert not HF._PENDING_COUNTERS and HF._COUNTER_SCOPE[0] == 0
         return losses_seen, val_seen, state
     finally:
         if prev is None:
