@@ -192,6 +192,17 @@ int seg_bn_bwd_reduce(int dtype, const void* g, long ldg, const void* x, long ld
                       const float* scale, const float* shift, const float* chan_mul,
                       long rows_per_n, const void* elem_mul, long ldm, long M, int C,
                       float* partial, int grid_y, void* stream);
+/* BatchNorm backward of a SMALL tensor (M = N*H*W <= 4096 rows; same layers as
+ * seg_bn_finalize_small) in ONE launch with float64 arithmetic: g' = g * chan_mul * elem_mul *
+ * relu_mask, dx = gamma*invstd*(g' - mean(g') - xhat*mean(g'*xhat)) (training = 1) or
+ * scale*g' (training = 0), dgamma = sum g'*xhat, dbeta = sum g'.  dx may alias g.  Replaces
+ * seg_bn_bwd_reduce + seg_bn_bwd_finalize_p + seg_bn_bwd_apply there: with a handful of samples
+ * per channel dx is the remainder of cancelling terms, which fp32 `scale*g' - c0 - c1*x` loses. */
+int seg_bn_bwd_small(int dtype, const void* g, long ldg, const void* x, long ldx, void* dx,
+                     long lddx, long M, int C, int mode, const float* scale, const float* shift,
+                     const float* mean, const float* invstd, const float* gamma,
+                     const float* chan_mul, long rows_per_n, const void* elem_mul, long ldm,
+                     double count, int training, float* dgamma, float* dbeta, void* stream);
 int seg_bn_bwd_finalize(const double* sums, double count, const double* count_dev,
                         const float* mean, const float* invstd, const float* gamma, float* dgamma, float* dbeta, float* c0, float* c1,
                         int C, void* stream);

@@ -548,6 +548,85 @@ __global__ __launch_bounds__(EW_THREADS) void bn_finalize_small_kernel(
   }
 }
 
+// ---- BatchNorm BACKWARD over a small number of samples (the same layers as
+// bn_finalize_small_kernel), the whole of it in one launch and in float64:
+//   g'  = g * chan_mul * elem_mul * relu_mask          (the mask from the fp32 forward value)
+//   dx  = gamma * invstd * (g' - mean(g') - xhat * mean(g' * xhat)),  xhat = (x - mean) * invstd
+// With two samples per channel xhat = +-1 up to eps and dx is the small remainder of three terms
+// that cancel: the general path's fp32 `scale*g' - c0 - c1*x` keeps 6e-8 * |terms| of it — on the
+// 513x1025 conditioned C3 step that one BatchNorm (ASPP image pooling, module.py:52-64) put
+// 4.6e-3 into the weight gradient of its convolution and made up 94 % of the whole model's fp32
+// gradient distance to the float64 oracle (profiles/r05_parity.txt).
+template <typename T>
+__global__ __launch_bounds__(EW_THREADS) void bn_bwd_small_kernel(
+    const T* __restrict__ g, long ldg, const T* __restrict__ x, long ldx, T* __restrict__ dx,
+    long lddx, int M, int C, int mode, const float* __restrict__ scale,
+    const float* __restrict__ shift, const float* __restrict__ mean,
+    const float* __restrict__ invstd, const float* __restrict__ gamma,
+    const float* __restrict__ chan_mul, int rows_per_n, const T* __restrict__ elem_mul, long ldm,
+    double count, int training, float* dgamma, float* dbeta) {
+  __shared__ double red[2][32][9];
+  __shared__ double s_m[2][8];
+  const int cx = threadIdx.x & 7, ry = threadIdx.x >> 3;
+  const int c = blockIdx.x * 8 + cx;
+  const bool live = c < C;
+  float sc = 1.f, sh = 0.f, gm = 1.f;
+  double mu = 0.0, is = 1.0;
+  if (live) {
+    if (mode & PRO_AFFINE) { sc = scale[c]; sh = shift[c]; }
+    if (gamma) gm = gamma[c];
+    mu = mean[c];
+    is = invstd[c];
+  }
+  auto masked = [&](int m, double& xh) -> double {
+    const float xv = Vec<T>::load1(x + (long)m * ldx + c);
+    double gv = (double)Vec<T>::load1(g + (long)m * ldg + c);
+    if (chan_mul) gv *= (double)chan_mul[(long)(m / rows_per_n) * C + c];
+    if (elem_mul) gv *= (double)Vec<T>::load1(elem_mul + (long)m * ldm + c);
+    if (mode & PRO_RELU) {
+      const float y = (mode & PRO_AFFINE) ? fmaf(xv, sc, sh) : xv;
+      const bool on = y > 0.f && (!(mode & PRO_CLAMP6) || y < 6.f);
+      gv = on ? gv : 0.0;
+    }
+    xh = ((double)xv - mu) * is;
+    return gv;
+  };
+  double a0 = 0.0, a1 = 0.0;
+  if (live)
+    for (int m = ry; m < M; m += 32) {
+      double xh;
+      const double gv = masked(m, xh);
+      a0 += gv;
+      a1 += gv * xh;
+    }
+  red[0][ry][cx] = a0;
+  red[1][ry][cx] = a1;
+  __syncthreads();
+  if (ry == 0) {
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+      s0 += red[0][k][cx];
+      s1 += red[1][k][cx];
+    }
+    s_m[0][cx] = s0;
+    s_m[1][cx] = s1;
+    if (live) {
+      if (dgamma) dgamma[c] = (float)s1;
+      if (dbeta) dbeta[c] = (float)s0;
+    }
+  }
+  __syncthreads();
+  if (!live) return;
+  const double m1 = training ? s_m[0][cx] / count : 0.0, m2 = training ? s_m[1][cx] / count : 0.0;
+  const double s = (double)gm * is;
+  for (int m = ry; m < M; m += 32) {
+    double xh;
+    const double gv = masked(m, xh);  // (reads g[m][c] before dx[m][c] is written: in place is fine)
+    Vec<T>::store1(dx + (long)m * lddx + c, (float)(s * (gv - m1 - xh * m2)));
+  }
+}
+
 template <typename TIN>
 __device__ __forceinline__ void bn_bwd_finalize_block(
     const TIN* __restrict__ part, int R, double count, const float* __restrict__ mean,
@@ -861,6 +940,34 @@ extern "C" int seg_bn_bwd_reduce(int dtype, const void* g, long ldg, const void*
     hipLaunchKernelGGL((bn_bwd_reduce_kernel<float>), dim3(gx, grid_y), dim3(EW_THREADS), lds,
                        (hipStream_t)stream, a);
   return check_launch("bn_bwd_reduce");
+}
+
+// The whole BatchNorm backward of a SMALL tensor (M <= 4096 rows) in one launch, float64 inside:
+// dx (may alias g), dgamma, dbeta.  training = 0: evaluation-mode BatchNorm (dx = scale * g').
+extern "C" int seg_bn_bwd_small(int dtype, const void* g, long ldg, const void* x, long ldx,
+                                void* dx, long lddx, long M, int C, int mode, const float* scale,
+                                const float* shift, const float* mean, const float* invstd,
+                                const float* gamma, const float* chan_mul, long rows_per_n,
+                                const void* elem_mul, long ldm, double count, int training,
+                                float* dgamma, float* dbeta, void* stream) {
+  using namespace seg;
+  SEG_REQUIRE(dtype == DT_F32 || dtype == DT_BF16, "bn_bwd_small: bad dtype %d", dtype);
+  SEG_REQUIRE(M >= 1 && M <= 4096 && C >= 1 && count >= 1.0 && mean && invstd && dx,
+              "bn_bwd_small: bad M/C/count or missing statistics");
+  SEG_REQUIRE(((mode & PRO_AFFINE) == 0) || (scale && shift), "bn_bwd_small: affine without scale");
+  const dim3 grid((C + 7) / 8);
+  const int rpn = rows_per_n > 0 ? (int)rows_per_n : 1;
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL((bn_bwd_small_kernel<bf16_t>), grid, dim3(EW_THREADS), 0,
+                       (hipStream_t)stream, (const bf16_t*)g, ldg, (const bf16_t*)x, ldx,
+                       (bf16_t*)dx, lddx, (int)M, C, mode, scale, shift, mean, invstd, gamma,
+                       chan_mul, rpn, (const bf16_t*)elem_mul, ldm, count, training, dgamma, dbeta);
+  else
+    hipLaunchKernelGGL((bn_bwd_small_kernel<float>), grid, dim3(EW_THREADS), 0,
+                       (hipStream_t)stream, (const float*)g, ldg, (const float*)x, ldx, (float*)dx,
+                       lddx, (int)M, C, mode, scale, shift, mean, invstd, gamma, chan_mul, rpn,
+                       (const float*)elem_mul, ldm, count, training, dgamma, dbeta);
+  return check_launch("bn_bwd_small");
 }
 
 extern "C" int seg_bn_bwd_finalize(const double* sums, double count, const double* count_dev,

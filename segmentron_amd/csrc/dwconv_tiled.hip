@@ -39,15 +39,30 @@ struct DwTiledArgs {
   long ldr;            // store (the other gradient of a forked activation) or null
   long ldx, ldy, lddy;
   int N, H, W, C, CV, pro_mode, tiles_h, tiles_w, ntiles;
+  // r05 remainder tiling (forward / fused backward; nb = nc = 0: the classic tiling).  Tiles
+  // [0, ntiles_a) are the 8 x 16 tiles of rows [0, 8 * tiles_h) x columns [0, 16 * tiles_w);
+  // then N * nb bottom-strip tiles (2 x 64, rows from hb0, the full width) and N * nc
+  // right-strip tiles (32 x 4, columns from wc0, rows below hc).  A 65 x 129 map (8*8+1 x
+  // 8*16+1, the Xception middle flow @1025x2049) takes 64 + 3 + 2 tiles per image instead of
+  // 81 of which 17 compute one valid row or column.
+  int ntiles_a, nb, nc, hb0, wc0, hc;
 };
 
-template <int DIL> struct TileGeom {
-  static constexpr int IH = LT_TH + 2 * DIL, IW = LT_TW + 2 * DIL, IWP = IW + 1;
+// A tile is TH x TW output pixels (TH * TW / 4 = 32 strips of four for the 32 pixel threads of
+// a block).  8 x 16 everywhere, except for the REMAINDER tiles of the r05 tiling (see DwRem).
+template <int TH_, int TW_, int DIL_> struct TileGeomS {
+  static_assert(TH_ * TW_ == 128 && TW_ % 4 == 0, "32 pixel threads x 4-pixel strips");
+  static constexpr int TH = TH_, TW = TW_, DIL = DIL_;
+  static constexpr int IH = TH + 2 * DIL, IW = TW + 2 * DIL, IWP = IW + 1;
   static constexpr int NPIX = IH * IW;
   static constexpr int PER = (NPIX * LT_CVB + LT_THREADS - 1) / LT_THREADS;
   static constexpr int TILE_VECS = IH * IWP * LT_CVB;  // 16-byte units
   static constexpr int COLS = 4 + 2 * DIL;             // tile columns one 4-output strip reads
 };
+template <int DIL> using TileGeom = TileGeomS<LT_TH, LT_TW, DIL>;
+// remainder tiles: bottom strip (<= 2 image rows) and right strip (<= 4 image columns)
+template <int DIL> using TileGeomB = TileGeomS<2, 64, DIL>;
+template <int DIL> using TileGeomC = TileGeomS<32, 4, DIL>;
 
 // ---- global -> registers (all loads of the tile issued back to back)
 // The address arithmetic of the six loads used to cost ~150 VALU instructions per tile and
@@ -56,11 +71,26 @@ template <int DIL> struct TileGeom {
 // bandwidth-bound (7.6 M wave-instructions for 12.2 M outputs).  Tiles whose halo lies inside
 // the image (block-uniform test) take the short path: pixel offsets relative to the tile origin
 // are per-thread constants.
+// pixel offsets (r * W + c) of this thread's PER halo-tile positions relative to the tile origin:
+// the same for every interior tile of a launch — computed once per block, not once per tile
+template <int DIL>
+__device__ __forceinline__ void tile_offsets(const DwTiledArgs& a, int (&poff)[TileGeom<DIL>::PER]) {
+  using G = TileGeom<DIL>;
+#pragma unroll
+  for (int u = 0; u < G::PER; ++u) {
+    const int p = (threadIdx.x >> 3) + u * (LT_THREADS / LT_CVB);
+    const int pc = p < G::NPIX ? p : G::NPIX - 1;
+    const int r = pc / G::IW, c = pc - r * G::IW;
+    poff[u] = r * a.W + c;
+  }
+}
+
 template <typename T, typename V, int DIL>
 __device__ __forceinline__ void tile_issue(const DwTiledArgs& a, const T* __restrict__ X, int n,
                                            int h0, int w0, int cv,
                                            typename V::raw_t (&raw)[TileGeom<DIL>::PER],
-                                           unsigned& okmask) {
+                                           unsigned& okmask,
+                                           const int (&poff)[TileGeom<DIL>::PER]) {
   using G = TileGeom<DIL>;
   constexpr int VEC = V::N;
   okmask = 0;
@@ -72,10 +102,8 @@ __device__ __forceinline__ void tile_issue(const DwTiledArgs& a, const T* __rest
 #pragma unroll
     for (int u = 0; u < G::PER; ++u) {
       const int p = (threadIdx.x >> 3) + u * (LT_THREADS / LT_CVB);
-      const int pc = p < G::NPIX ? p : G::NPIX - 1;
-      const int r = pc / G::IW, c = pc - r * G::IW;
       okmask |= (p < G::NPIX && cv < a.CV) ? (1u << u) : 0u;
-      raw[u] = V::load_raw(base + (long)(origin + r * a.W + c) * a.ldx);
+      raw[u] = V::load_raw(base + (long)(origin + poff[u]) * a.ldx);
     }
     return;
   }
@@ -91,15 +119,78 @@ __device__ __forceinline__ void tile_issue(const DwTiledArgs& a, const T* __rest
   }
 }
 
+// Remainder tiles (any shape G, on the image border by construction): global -> registers -> LDS
+// in CHUNKS of three vectors per thread with clamped addressing — a block meets at most a few of
+// them, what matters is that their register footprint stays below the 8 x 16 path's.
+template <typename T, typename V, typename G, int MODE>
+__device__ __forceinline__ void tile_stage_edge(const DwTiledArgs& a, const T* __restrict__ X,
+                                                typename V::raw_t* __restrict__ tile,
+                                                const float4* __restrict__ psm, int n, int h0,
+                                                int w0, int cv) {
+  constexpr int VEC = V::N, WQ = VEC / 4, DIL = G::DIL, CH = 3;
+  const int mode = MODE >= 0 ? MODE : a.pro_mode;
+  const int cx = threadIdx.x & (LT_CVB - 1);
+  const int cvc = min(cv, a.CV - 1);
+  float sc[VEC], sh[VEC];
+  if (mode & PRO_AFFINE) {
+#pragma unroll
+    for (int q = 0; q < WQ; ++q) {
+      const float4 s4 = psm[(9 * LT_CVB + cx) * WQ + q], t4 = psm[(10 * LT_CVB + cx) * WQ + q];
+      sc[q * 4] = s4.x; sc[q * 4 + 1] = s4.y; sc[q * 4 + 2] = s4.z; sc[q * 4 + 3] = s4.w;
+      sh[q * 4] = t4.x; sh[q * 4 + 1] = t4.y; sh[q * 4 + 2] = t4.z; sh[q * 4 + 3] = t4.w;
+    }
+  }
+#pragma unroll 1
+  for (int u0 = 0; u0 < G::PER; u0 += CH) {
+    typename V::raw_t raw[CH];
+    bool ok[CH];
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+      const int p = (threadIdx.x >> 3) + (u0 + k) * (LT_THREADS / LT_CVB);
+      const int r = p / G::IW, c = p - r * G::IW;
+      const int hi = h0 - DIL + r, wi = w0 - DIL + c;
+      ok[k] = p < G::NPIX && cv < a.CV && hi >= 0 && hi < a.H && wi >= 0 && wi < a.W;
+      const int hic = min(max(hi, 0), a.H - 1), wic = min(max(wi, 0), a.W - 1);
+      raw[k] = V::load_raw(X + (((long)n * a.H + hic) * a.W + wic) * a.ldx + cvc * VEC);
+    }
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+      const int p = (threadIdx.x >> 3) + (u0 + k) * (LT_THREADS / LT_CVB);
+      if (p < G::NPIX) {
+        const int r = p / G::IW, c = p - r * G::IW;
+        typename V::raw_t v = raw[k];
+        if (mode != PRO_NONE) {
+          float f[VEC];
+          V::unpack_raw(raw[k], f);
+          if (mode & PRO_AFFINE) {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) f[i] = fmaf(f[i], sc[i], sh[i]);
+          }
+          if (mode & PRO_RELU) {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) f[i] = fmaxf(f[i], 0.f);
+          }
+          if (mode & PRO_CLAMP6) {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) f[i] = fminf(f[i], 6.f);
+          }
+          v = V::pack_raw(f);
+        }
+        if (!ok[k]) v = V::zero_raw();
+        tile[(r * G::IWP + c) * LT_CVB + cx] = v;
+      }
+    }
+  }
+}
+
 // ---- registers -> LDS: activation once per element, zero padding outside the image.
 // MODE >= 0: the prologue mode as a compile-time constant (no per-vector branches; MODE 0 stores
 // the raw vector); MODE < 0: a.pro_mode at run time.
-template <typename T, typename V, int DIL, int MODE = -1>
-__device__ __forceinline__ void tile_commit(const DwTiledArgs& a,
-                                            typename V::raw_t* __restrict__ tile,
-                                            const typename V::raw_t (&raw)[TileGeom<DIL>::PER],
-                                            unsigned okmask, const float4* __restrict__ psm) {
-  using G = TileGeom<DIL>;
+template <typename T, typename V, typename G, int MODE = -1>
+__device__ __forceinline__ void tile_commit_g(const DwTiledArgs& a,
+                                              typename V::raw_t* __restrict__ tile,
+                                              const typename V::raw_t (&raw)[G::PER],
+                                              unsigned okmask, const float4* __restrict__ psm) {
   constexpr int VEC = V::N, WQ = VEC / 4;
   const int mode = MODE >= 0 ? MODE : a.pro_mode;
   const int cx = threadIdx.x & (LT_CVB - 1);
@@ -139,6 +230,14 @@ __device__ __forceinline__ void tile_commit(const DwTiledArgs& a,
       tile[(r * G::IWP + c) * LT_CVB + cx] = v;
     }
   }
+}
+
+template <typename T, typename V, int DIL, int MODE = -1>
+__device__ __forceinline__ void tile_commit(const DwTiledArgs& a,
+                                            typename V::raw_t* __restrict__ tile,
+                                            const typename V::raw_t (&raw)[TileGeom<DIL>::PER],
+                                            unsigned okmask, const float4* __restrict__ psm) {
+  tile_commit_g<T, V, TileGeom<DIL>, MODE>(a, tile, raw, okmask, psm);
 }
 
 // per-block constants -> LDS: rows 0..8 = the nine taps, rows 9/10 = prologue scale / shift
@@ -198,17 +297,111 @@ __device__ __forceinline__ LtBlock lt_block() {
   return b;
 }
 
+// One tile of the forward: halo tile -> registers -> (activation) -> LDS -> taps -> store +
+// statistics.  G: tile shape; POFF: interior 8 x 16 tiles use the per-block pixel offsets.
+template <typename T, typename G, int MODE, bool POFF>
+__device__ __forceinline__ void dw_fwd_tile(const DwTiledArgs& a, const T* __restrict__ X,
+                                            T* __restrict__ Y, uint4* __restrict__ tile,
+                                            const float4* __restrict__ wsm, int n, int h0, int w0,
+                                            int hlim, int cv, const int (&poff)[TileGeom<G::DIL>::PER],
+                                            float (&ssum)[Vec<T>::N], float (&ssq)[Vec<T>::N]) {
+  constexpr int VEC = Vec<T>::N, WQ = VEC / 4, DIL = G::DIL;
+  const int tid = threadIdx.x;
+  const int cx = tid & (LT_CVB - 1), pix = tid >> 3;
+  const int row = pix % G::TH, strip = pix / G::TH;
+  if constexpr (POFF) {
+    uint4 raw[G::PER];
+    unsigned okmask = 0;
+    tile_issue<T, Vec<T>, DIL>(a, X, n, h0, w0, cv, raw, okmask, poff);
+    __syncthreads();  // every thread is done reading the previous tile
+    tile_commit_g<T, Vec<T>, G, MODE>(a, tile, raw, okmask, wsm);
+  } else {
+    __syncthreads();
+    tile_stage_edge<T, Vec<T>, G, MODE>(a, X, tile, wsm, n, h0, w0, cv);
+  }
+  __syncthreads();
+
+  float acc[4][VEC];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) acc[j][i] = 0.f;
+  // kept as a real loop: fully unrolled, the scheduler hoists all 24 LDS reads and spills
+#pragma unroll 1
+  for (int kh = 0; kh < 3; ++kh) {
+    float wv[3][VEC];
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+      for (int q = 0; q < WQ; ++q) {
+        const float4 w4 = wsm[((kh * 3 + kw) * LT_CVB + cx) * WQ + q];
+        wv[kw][q * 4] = w4.x; wv[kw][q * 4 + 1] = w4.y;
+        wv[kw][q * 4 + 2] = w4.z; wv[kw][q * 4 + 3] = w4.w;
+      }
+    const uint4* trow = tile + ((row + kh * DIL) * G::IWP + strip * 4) * LT_CVB + cx;
+#pragma unroll
+    for (int q = 0; q < G::COLS; ++q) {
+      float v[VEC];
+      Vec<T>::unpack(trow[q * LT_CVB], v);
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int j = q - kw * DIL;
+        if (j >= 0 && j < 4) {
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) acc[j][i] = fmaf(v[i], wv[kw][i], acc[j][i]);
+        }
+      }
+    }
+  }
+  const int ho = h0 + row;
+  if (cv < a.CV && ho < hlim) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int wo = w0 + strip * 4 + j;
+      if (wo < a.W) {
+        stg16(Y + (((long)n * a.H + ho) * a.W + wo) * a.ldy + cv * VEC, Vec<T>::pack(acc[j]));
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+          ssum[i] += acc[j][i];
+          ssq[i] = fmaf(acc[j][i], acc[j][i], ssq[i]);
+        }
+      }
+    }
+  }
+}
+
+// remainder tile e (index behind the 8 x 16 tiles) -> image, origin, row limit; true = bottom strip
+__device__ __forceinline__ bool rem_coords(const DwTiledArgs& a, int e, int& n, int& h0, int& w0,
+                                           int& hlim) {
+  if (e < a.N * a.nb) {
+    n = e / a.nb;
+    h0 = a.hb0;
+    w0 = (e - n * a.nb) * 64;
+    hlim = a.H;
+    return true;
+  }
+  e -= a.N * a.nb;
+  n = e / a.nc;
+  h0 = (e - n * a.nc) * 32;
+  w0 = a.wc0;
+  hlim = a.hc;
+  return false;
+}
+
 template <typename T, int DIL, int MODE = -1>
 __global__ __launch_bounds__(LT_THREADS, sizeof(T) == 2 ? 3 : 4) void dwconv_tiled_kernel(const DwTiledArgs a) {
   using G = TileGeom<DIL>;
-  constexpr int VEC = Vec<T>::N, WQ = VEC / 4;
+  constexpr int VEC = Vec<T>::N;
   extern __shared__ uint4 lt_smem[];
   uint4* tile = lt_smem;
-  float4* wsm = reinterpret_cast<float4*>(lt_smem + G::TILE_VECS);
+  // (taps / prologue parameters sit behind the LARGEST tile image this launch can stage)
+  float4* wsm = reinterpret_cast<float4*>(lt_smem + (a.nb ? TileGeomB<DIL>::TILE_VECS
+                                                       : a.nc ? TileGeomC<DIL>::TILE_VECS
+                                                              : G::TILE_VECS));
   const int tid = threadIdx.x;
   const LtBlock lb = lt_block();
   const int cvb0 = lb.x * LT_CVB;
-  const int cx = tid & (LT_CVB - 1), row = (tid >> 3) & (LT_TH - 1), strip = tid >> 6;
+  const int cx = tid & (LT_CVB - 1);
   const int cv = cvb0 + cx;
   const T* __restrict__ X = reinterpret_cast<const T*>(a.x);
   T* __restrict__ Y = reinterpret_cast<T*>(a.y);
@@ -219,80 +412,20 @@ __global__ __launch_bounds__(LT_THREADS, sizeof(T) == 2 ? 3 : 4) void dwconv_til
 #pragma unroll
   for (int i = 0; i < VEC; ++i) ssum[i] = ssq[i] = 0.f;
 
-  // Tile loop with an optional software pipeline (PIPE): the NEXT tile's global loads are issued
-  // right after the current tile has been committed to LDS and stay in flight (across the
-  // barrier) while the current tile is computed.  Measured for THIS kernel (3 blocks/CU already
-  // overlap each other): no gain on the 24 MB tensors, -10 % on the large ones -> off; the fused
-  // backward (2 blocks/CU, long compute phase) gains 35 % from it.
-  constexpr bool PIPE = false;
-  int t = lb.y, nn = 0, nh0 = 0, nw0 = 0;
-  uint4 raw[G::PER];
-  unsigned okmask = 0;
-  if (PIPE && t < a.ntiles) {
-    tile_coords(a, t, nn, nh0, nw0);
-    tile_issue<T, Vec<T>, DIL>(a, X, nn, nh0, nw0, cv, raw, okmask);
-  }
-  while (t < a.ntiles) {
-    if (!PIPE) {
-      tile_coords(a, t, nn, nh0, nw0);
-      tile_issue<T, Vec<T>, DIL>(a, X, nn, nh0, nw0, cv, raw, okmask);
-    }
-    __syncthreads();  // every thread is done reading the previous tile
-    tile_commit<T, Vec<T>, DIL, MODE>(a, tile, raw, okmask, wsm);
-    const int n = nn, h0 = nh0, w0 = nw0;
-    t += gridDim.y;
-    if (PIPE && t < a.ntiles) {
-      tile_coords(a, t, nn, nh0, nw0);
-      tile_issue<T, Vec<T>, DIL>(a, X, nn, nh0, nw0, cv, raw, okmask);
-    }
-    __syncthreads();
-
-    float acc[4][VEC];
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int i = 0; i < VEC; ++i) acc[j][i] = 0.f;
-    // kept as a real loop: fully unrolled, the scheduler hoists all 24 LDS reads and spills
-#pragma unroll 1
-    for (int kh = 0; kh < 3; ++kh) {
-      float wv[3][VEC];
-#pragma unroll
-      for (int kw = 0; kw < 3; ++kw)
-#pragma unroll
-        for (int q = 0; q < WQ; ++q) {
-          const float4 w4 = wsm[((kh * 3 + kw) * LT_CVB + cx) * WQ + q];
-          wv[kw][q * 4] = w4.x; wv[kw][q * 4 + 1] = w4.y;
-          wv[kw][q * 4 + 2] = w4.z; wv[kw][q * 4 + 3] = w4.w;
-        }
-      const uint4* trow = tile + ((row + kh * DIL) * G::IWP + strip * 4) * LT_CVB + cx;
-#pragma unroll
-      for (int q = 0; q < G::COLS; ++q) {
-        float v[VEC];
-        Vec<T>::unpack(trow[q * LT_CVB], v);
-#pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
-          const int j = q - kw * DIL;
-          if (j >= 0 && j < 4) {
-#pragma unroll
-            for (int i = 0; i < VEC; ++i) acc[j][i] = fmaf(v[i], wv[kw][i], acc[j][i]);
-          }
-        }
-      }
-    }
-    const int ho = h0 + row;
-    if (cv < a.CV && ho < a.H) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int wo = w0 + strip * 4 + j;
-        if (wo < a.W) {
-          stg16(Y + (((long)n * a.H + ho) * a.W + wo) * a.ldy + cv * VEC, Vec<T>::pack(acc[j]));
-#pragma unroll
-          for (int i = 0; i < VEC; ++i) {
-            ssum[i] += acc[j][i];
-            ssq[i] = fmaf(acc[j][i], acc[j][i], ssq[i]);
-          }
-        }
-      }
+  // (a software pipeline over the tiles — the next tile's loads in flight during the taps — was
+  // measured for THIS kernel: no gain on the 24 MB tensors, -10 % on the large ones, 3 blocks/CU
+  // already overlap each other; the fused backward, 2 blocks/CU, gains 35 % from it)
+  int poff[G::PER];
+  tile_offsets<DIL>(a, poff);
+  for (int t = lb.y; t < a.ntiles; t += gridDim.y) {
+    int n, h0, w0, hlim = a.H;
+    if (t < a.ntiles_a) {
+      tile_coords(a, t, n, h0, w0);
+      dw_fwd_tile<T, G, MODE, true>(a, X, Y, tile, wsm, n, h0, w0, hlim, cv, poff, ssum, ssq);
+    } else if (rem_coords(a, t - a.ntiles_a, n, h0, w0, hlim)) {
+      dw_fwd_tile<T, TileGeomB<DIL>, MODE, false>(a, X, Y, tile, wsm, n, h0, w0, hlim, cv, poff, ssum, ssq);
+    } else {
+      dw_fwd_tile<T, TileGeomC<DIL>, MODE, false>(a, X, Y, tile, wsm, n, h0, w0, hlim, cv, poff, ssum, ssq);
     }
   }
 
@@ -530,12 +663,14 @@ __global__ __launch_bounds__(LT_THREADS, 2) void dwconv_wgrad_tiled_kernel(const
 #pragma unroll
     for (int i = 0; i < VEC; ++i) acc[k][i] = 0.f;
 
+  int poff[G::PER];
+  tile_offsets<DIL>(a, poff);
   for (int t = lb.y; t < a.ntiles; t += gridDim.y) {
     int n, h0, w0;
     tile_coords(a, t, n, h0, w0);
     uint4 raw[G::PER];
     unsigned okmask;
-    tile_issue<T, Vec<T>, DIL>(a, X, n, h0, w0, cv, raw, okmask);
+    tile_issue<T, Vec<T>, DIL>(a, X, n, h0, w0, cv, raw, okmask, poff);
     // this thread's four dy vectors (zero outside the image / channel range)
     const int ho = h0 + row;
     uint4 graw[4];
@@ -621,6 +756,163 @@ __global__ __launch_bounds__(LT_THREADS, 2) void dwconv_wgrad_tiled_kernel(const
 // RES: the second gradient of a forked activation (an Xception block input feeds the residual
 // sum AND the first separable conv, xception.py:40-42) is added in the store path — the
 // element-wise add autograd would launch for it (2 reads + 1 write of the tensor) is gone.
+// x vectors of one 4-pixel strip (one 64-bit pixel offset per tile and thread, + j * ld: the four
+// vectors used to rebuild ((n*H + h)*W + w)*ld each — with the residual loads and the stores ~150
+// VALU of address arithmetic per tile next to ~250 of tap work; only the last strip of a
+// right-border tile, a wave-uniform case, needs the column clamp)
+template <typename T, typename V>
+__device__ __forceinline__ void dw_bwd_issue_x(const DwTiledArgs& a, const T* __restrict__ X, int n,
+                                               int h0, int w0, int row, int strip, int cv,
+                                               typename V::raw_t (&xr)[4]) {
+  constexpr int VEC = V::N;
+  const int hoc = min(h0 + row, a.H - 1), cvc = min(cv, a.CV - 1);
+  const int wb = w0 + strip * 4;
+  const T* __restrict__ px = X + ((long)(n * a.H + hoc) * a.W + min(wb, a.W - 1)) * a.ldx + cvc * VEC;
+  if (wb + 3 < a.W) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) xr[j] = V::load_raw(px + j * (int)a.ldx);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      xr[j] = V::load_raw(px + (min(wb + j, a.W - 1) - min(wb, a.W - 1)) * (int)a.ldx);
+  }
+}
+
+// The arithmetic of one tile of the fused backward: the dy halo tile is in LDS (tile), this
+// thread's four x vectors in xraw.  G: tile shape (8 x 16, or a remainder shape).
+template <typename T, typename G, bool RES>
+__device__ __forceinline__ void dw_bwd_compute(
+    const DwTiledArgs& a, const typename HVec<T>::raw_t* __restrict__ tile,
+    const float4* __restrict__ psm, T* __restrict__ GO, int n, int h0, int w0, int hlim, int row,
+    int strip, int cx, int cv, const typename HVec<T>::raw_t (&xraw)[4],
+    const float (&sc)[HVec<T>::N], const float (&sh)[HVec<T>::N], float (&accw)[9][HVec<T>::N],
+    float (&s1)[HVec<T>::N], float (&s2)[HVec<T>::N]) {
+  using V = HVec<T>;
+  using raw_t = typename V::raw_t;
+  constexpr int VEC = V::N, WQ = VEC / 4, DIL = G::DIL;
+  const int ho = h0 + row;
+  const bool rok = cv < a.CV && ho < hlim;
+
+  float xa[4][VEC];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    V::unpack_raw(xraw[j], xa[j]);
+    if (a.pro_mode & PRO_AFFINE) {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) xa[j][i] = fmaf(xa[j][i], sc[i], sh[i]);
+    }
+    if (a.pro_mode & PRO_RELU) {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) xa[j][i] = fmaxf(xa[j][i], 0.f);
+    }
+    if (a.pro_mode & PRO_CLAMP6) {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) xa[j][i] = fminf(xa[j][i], 6.f);
+    }
+    const bool ok = rok && (w0 + strip * 4 + j) < a.W;
+    if (!ok) {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) xa[j][i] = 0.f;
+    }
+  }
+  float accg[4][VEC];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) accg[j][i] = 0.f;
+  raw_t rres[4];
+  if (RES) {  // in flight during the tap loop
+    const T* __restrict__ R = reinterpret_cast<const T*>(a.res);
+    const int hoc = min(ho, a.H - 1), cvc = min(cv, a.CV - 1);
+    const int wb = w0 + strip * 4, wbc = min(wb, a.W - 1);
+    const T* __restrict__ pr = R + ((long)(n * a.H + hoc) * a.W + wbc) * a.ldr + cvc * VEC;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      rres[j] = V::load_raw(pr + (min(wb + j, a.W - 1) - wbc) * (int)a.ldr);
+  }
+#pragma unroll
+  for (int kh = 0; kh < 3; ++kh) {
+    float wv[3][VEC];
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+      for (int q = 0; q < WQ; ++q) {
+        const float4 w4 = psm[((kh * 3 + kw) * LT_CVB + cx) * WQ + q];
+        wv[kw][q * 4] = w4.x; wv[kw][q * 4 + 1] = w4.y;
+        wv[kw][q * 4 + 2] = w4.z; wv[kw][q * 4 + 3] = w4.w;
+      }
+    const raw_t* trow = tile + ((row + kh * DIL) * G::IWP + strip * 4) * LT_CVB + cx;
+#pragma unroll
+    for (int q = 0; q < G::COLS; ++q) {
+      float v[VEC];
+      V::unpack_raw(trow[q * LT_CVB], v);
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int j = q - kw * DIL;
+        if (j >= 0 && j < 4) {
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) {
+            accg[j][i] = fmaf(v[i], wv[kw][i], accg[j][i]);
+            accw[kh * 3 + kw][i] = fmaf(v[i], xa[j][i], accw[kh * 3 + kw][i]);
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // mask, store, BatchNorm-backward sums
+  T* __restrict__ pgo = GO + ((long)(n * a.H + min(ho, a.H - 1)) * a.W + (w0 + strip * 4)) * a.ldy + cv * VEC;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int wo = w0 + strip * 4 + j;
+    if (rok && wo < a.W) {
+      float xr[VEC];
+      V::unpack_raw(xraw[j], xr);
+      if (a.pro_mode & PRO_RELU) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+          const bool on = xa[j][i] > 0.f && (!(a.pro_mode & PRO_CLAMP6) || xa[j][i] < 6.f);
+          accg[j][i] = on ? accg[j][i] : 0.f;
+        }
+      }
+      if (RES) {
+        float rr[VEC], o[VEC];
+        V::unpack_raw(rres[j], rr);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) o[i] = accg[j][i] + rr[i];
+        V::store(pgo + j * (int)a.ldy, o);
+      } else {
+        V::store(pgo + j * (int)a.ldy, accg[j]);
+      }
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        s1[i] += accg[j][i];
+        s2[i] = fmaf(accg[j][i], xr[i], s2[i]);
+      }
+    }
+  }
+}
+
+// one REMAINDER tile of the fused backward (no software pipeline: a block meets at most a few)
+template <typename T, typename G, bool RES>
+__device__ __forceinline__ void dw_bwd_edge_tile(
+    const DwTiledArgs& a, const DwTiledArgs& dyargs,
+    typename HVec<T>::raw_t* __restrict__ tile, const float4* __restrict__ psm, int n, int h0,
+    int w0, int hlim, int cx, int cv, const float (&sc)[HVec<T>::N], const float (&sh)[HVec<T>::N],
+    float (&accw)[9][HVec<T>::N], float (&s1)[HVec<T>::N], float (&s2)[HVec<T>::N]) {
+  using V = HVec<T>;
+  using raw_t = typename V::raw_t;
+  const int pix = threadIdx.x >> 3, row = pix % G::TH, strip = pix / G::TH;
+  raw_t xraw[4];
+  dw_bwd_issue_x<T, V>(a, reinterpret_cast<const T*>(a.x), n, h0, w0, row, strip, cv, xraw);
+  __syncthreads();
+  tile_stage_edge<T, V, G, PRO_NONE>(dyargs, reinterpret_cast<const T*>(a.dy), tile, psm, n, h0, w0,
+                                     cv);
+  __syncthreads();
+  dw_bwd_compute<T, G, RES>(a, tile, psm, reinterpret_cast<T*>(a.y), n, h0, w0, hlim, row, strip, cx,
+                            cv, xraw, sc, sh, accw, s1, s2);
+}
+
 template <typename T, int DIL, bool RES = false>
 __global__ __launch_bounds__(LT_THREADS, DW_BWD_OCC) void dwconv_bwd_tiled_kernel(const DwTiledArgs a) {
   // 4 channels per thread in both element types (8-byte bf16 vectors): this kernel carries nine
@@ -631,7 +923,10 @@ __global__ __launch_bounds__(LT_THREADS, DW_BWD_OCC) void dwconv_bwd_tiled_kerne
   constexpr int VEC = V::N, WQ = VEC / 4;
   extern __shared__ uint4 lt_smem[];
   raw_t* tile = reinterpret_cast<raw_t*>(lt_smem);
-  float4* psm = reinterpret_cast<float4*>(lt_smem + G::TILE_VECS);
+  // (parameter rows behind the largest tile image of the launch, tiled_lds)
+  float4* psm = reinterpret_cast<float4*>(lt_smem + (a.nb ? TileGeomB<DIL>::TILE_VECS
+                                                       : a.nc ? TileGeomC<DIL>::TILE_VECS
+                                                              : G::TILE_VECS));
   const int tid = threadIdx.x;
   const LtBlock lb = lt_block();
   const int cvb0 = lb.x * LT_CVB;
@@ -662,32 +957,26 @@ __global__ __launch_bounds__(LT_THREADS, DW_BWD_OCC) void dwconv_bwd_tiled_kerne
 #pragma unroll
   for (int i = 0; i < VEC; ++i) s1[i] = s2[i] = 0.f;
 
-  // software pipeline over the block's tiles (see dwconv_tiled_kernel): the next tile's dy halo
-  // tile and x vectors are in flight while the current tile is computed
-  auto issue_x = [&](int n, int h0, int w0, raw_t (&xr)[4]) {
-    const int hoc = min(h0 + row, a.H - 1), cvc = min(cv, a.CV - 1);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int wo = w0 + strip * 4 + j;
-      xr[j] = V::load_raw(X + (((long)n * a.H + hoc) * a.W + min(wo, a.W - 1)) * a.ldx + cvc * VEC);
-    }
-  };
+  // software pipeline over the block's 8 x 16 tiles (see dwconv_tiled_kernel): the next tile's dy
+  // halo tile and x vectors are in flight while the current tile is computed
   DwTiledArgs dyargs = plain;
   dyargs.ldx = a.lddy;
   constexpr bool PIPE = DIL == 1;  // dilation 2 (wider halo tile) would spill with the prefetch
   int t = lb.y, nn = 0, nh0 = 0, nw0 = 0;
+  int poff[G::PER];
+  tile_offsets<DIL>(a, poff);
   raw_t raw[G::PER], xnext[4];
   unsigned okmask = 0;
-  if (PIPE && t < a.ntiles) {
+  if (PIPE && t < a.ntiles_a) {
     tile_coords(a, t, nn, nh0, nw0);
-    tile_issue<T, V, DIL>(dyargs, DY, nn, nh0, nw0, cv, raw, okmask);
-    issue_x(nn, nh0, nw0, xnext);
+    tile_issue<T, V, DIL>(dyargs, DY, nn, nh0, nw0, cv, raw, okmask, poff);
+    dw_bwd_issue_x<T, V>(a, X, nn, nh0, nw0, row, strip, cv, xnext);
   }
-  while (t < a.ntiles) {
+  while (t < a.ntiles_a) {
     if (!PIPE) {
       tile_coords(a, t, nn, nh0, nw0);
-      tile_issue<T, V, DIL>(dyargs, DY, nn, nh0, nw0, cv, raw, okmask);
-      issue_x(nn, nh0, nw0, xnext);
+      tile_issue<T, V, DIL>(dyargs, DY, nn, nh0, nw0, cv, raw, okmask, poff);
+      dw_bwd_issue_x<T, V>(a, X, nn, nh0, nw0, row, strip, cv, xnext);
     }
     __syncthreads();
     tile_commit<T, V, DIL, PRO_NONE>(plain, tile, raw, okmask, psm);
@@ -696,112 +985,24 @@ __global__ __launch_bounds__(LT_THREADS, DW_BWD_OCC) void dwconv_bwd_tiled_kerne
 #pragma unroll
     for (int j = 0; j < 4; ++j) xraw[j] = xnext[j];
     t += gridDim.y;
-    if (PIPE && t < a.ntiles) {
+    if (PIPE && t < a.ntiles_a) {
       tile_coords(a, t, nn, nh0, nw0);
-      tile_issue<T, V, DIL>(dyargs, DY, nn, nh0, nw0, cv, raw, okmask);
-      issue_x(nn, nh0, nw0, xnext);
+      tile_issue<T, V, DIL>(dyargs, DY, nn, nh0, nw0, cv, raw, okmask, poff);
+      dw_bwd_issue_x<T, V>(a, X, nn, nh0, nw0, row, strip, cv, xnext);
     }
     __syncthreads();
-    const int ho = h0 + row;
-    const bool rok = cv < a.CV && ho < a.H;
-
-    float xa[4][VEC];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      V::unpack_raw(xraw[j], xa[j]);
-      if (a.pro_mode & PRO_AFFINE) {
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) xa[j][i] = fmaf(xa[j][i], sc[i], sh[i]);
-      }
-      if (a.pro_mode & PRO_RELU) {
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) xa[j][i] = fmaxf(xa[j][i], 0.f);
-      }
-      if (a.pro_mode & PRO_CLAMP6) {
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) xa[j][i] = fminf(xa[j][i], 6.f);
-      }
-      const bool ok = rok && (w0 + strip * 4 + j) < a.W;
-      if (!ok) {
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) xa[j][i] = 0.f;
-      }
-    }
-    float accg[4][VEC];
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int i = 0; i < VEC; ++i) accg[j][i] = 0.f;
-    raw_t rres[4];
-    if (RES) {  // in flight during the tap loop
-      const T* __restrict__ R = reinterpret_cast<const T*>(a.res);
-      const int hoc = min(ho, a.H - 1), cvc = min(cv, a.CV - 1);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int wo = min(w0 + strip * 4 + j, a.W - 1);
-        rres[j] = V::load_raw(R + (((long)n * a.H + hoc) * a.W + wo) * a.ldr + cvc * VEC);
-      }
-    }
-#pragma unroll
-    for (int kh = 0; kh < 3; ++kh) {
-      float wv[3][VEC];
-#pragma unroll
-      for (int kw = 0; kw < 3; ++kw)
-#pragma unroll
-        for (int q = 0; q < WQ; ++q) {
-          const float4 w4 = psm[((kh * 3 + kw) * LT_CVB + cx) * WQ + q];
-          wv[kw][q * 4] = w4.x; wv[kw][q * 4 + 1] = w4.y;
-          wv[kw][q * 4 + 2] = w4.z; wv[kw][q * 4 + 3] = w4.w;
-        }
-      const raw_t* trow = tile + ((row + kh * DIL) * G::IWP + strip * 4) * LT_CVB + cx;
-#pragma unroll
-      for (int q = 0; q < G::COLS; ++q) {
-        float v[VEC];
-        V::unpack_raw(trow[q * LT_CVB], v);
-#pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
-          const int j = q - kw * DIL;
-          if (j >= 0 && j < 4) {
-#pragma unroll
-            for (int i = 0; i < VEC; ++i) {
-              accg[j][i] = fmaf(v[i], wv[kw][i], accg[j][i]);
-              accw[kh * 3 + kw][i] = fmaf(v[i], xa[j][i], accw[kh * 3 + kw][i]);
-            }
-          }
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    // mask, store, BatchNorm-backward sums
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int wo = w0 + strip * 4 + j;
-      if (rok && wo < a.W) {
-        float xr[VEC];
-        V::unpack_raw(xraw[j], xr);
-        if (a.pro_mode & PRO_RELU) {
-#pragma unroll
-          for (int i = 0; i < VEC; ++i) {
-            const bool on = xa[j][i] > 0.f && (!(a.pro_mode & PRO_CLAMP6) || xa[j][i] < 6.f);
-            accg[j][i] = on ? accg[j][i] : 0.f;
-          }
-        }
-        if (RES) {
-          float rr[VEC], o[VEC];
-          V::unpack_raw(rres[j], rr);
-#pragma unroll
-          for (int i = 0; i < VEC; ++i) o[i] = accg[j][i] + rr[i];
-          V::store(GO + (((long)n * a.H + ho) * a.W + wo) * a.ldy + cv * VEC, o);
-        } else {
-          V::store(GO + (((long)n * a.H + ho) * a.W + wo) * a.ldy + cv * VEC, accg[j]);
-        }
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) {
-          s1[i] += accg[j][i];
-          s2[i] = fmaf(accg[j][i], xr[i], s2[i]);
-        }
-      }
-    }
+    dw_bwd_compute<T, G, RES>(a, tile, psm, GO, n, h0, w0, a.H, row, strip, cx, cv, xraw, sc, sh,
+                              accw, s1, s2);
+  }
+  // remainder tiles (t continues behind the 8 x 16 tiles with the same stride)
+  for (; t < a.ntiles; t += gridDim.y) {
+    int n, h0, w0, hlim;
+    if (rem_coords(a, t - a.ntiles_a, n, h0, w0, hlim))
+      dw_bwd_edge_tile<T, TileGeomB<DIL>, RES>(a, dyargs, tile, psm, n, h0, w0, hlim, cx, cv,
+                                               sc, sh, accw, s1, s2);
+    else
+      dw_bwd_edge_tile<T, TileGeomC<DIL>, RES>(a, dyargs, tile, psm, n, h0, w0, hlim, cx, cv,
+                                               sc, sh, accw, s1, s2);
   }
 
   // ---- block reductions (rows of a wave by lane exchange, strips through LDS)
@@ -884,12 +1085,23 @@ int launch_dw_wgrad_finalize(const float* partial, int R, int C, float* out, hip
 // ------------------------------------------------------------------ host side
 bool dw_tiled_supported(int stride, int dil) { return stride == 1 && (dil == 1 || dil == 2); }
 
-static void tiled_geom(DwTiledArgs& a, int dtype, int N, int H, int W, int C) {
+// rem: the r05 tiling with remainder tiles (forward / fused backward); the weight-gradient kernel
+// keeps the classic one
+static void tiled_geom(DwTiledArgs& a, int dtype, int N, int H, int W, int C, bool rem = false) {
   const int vec = dtype == DT_BF16 ? 8 : 4;
   a.N = N; a.H = H; a.W = W; a.C = C; a.CV = C / vec;
-  a.tiles_h = (H + LT_TH - 1) / LT_TH;
-  a.tiles_w = (W + LT_TW - 1) / LT_TW;
-  a.ntiles = N * a.tiles_h * a.tiles_w;
+  const int full_h = H / LT_TH, full_w = W / LT_TW, rb = H % LT_TH, rr = W % LT_TW;
+  const bool use_b = rem && rb > 0 && rb <= 2 && full_h > 0;
+  const bool use_c = rem && rr > 0 && rr <= 4 && full_w > 0;
+  a.tiles_h = use_b ? full_h : (H + LT_TH - 1) / LT_TH;
+  a.tiles_w = use_c ? full_w : (W + LT_TW - 1) / LT_TW;
+  a.hb0 = full_h * LT_TH;
+  a.wc0 = full_w * LT_TW;
+  a.hc = use_b ? a.hb0 : H;
+  a.nb = use_b ? (W + 63) / 64 : 0;
+  a.nc = use_c ? (a.hc + 31) / 32 : 0;
+  a.ntiles_a = N * a.tiles_h * a.tiles_w;
+  a.ntiles = a.ntiles_a + N * (a.nb + a.nc);
 }
 
 // Persistent blocks: about one resident set of blocks for the whole launch (3 per CU forward, 2 per
@@ -900,7 +1112,7 @@ int dw_tiled_grid_y(int dtype, int C, int N, int H, int W, int kind) {
   // 1: fused backward (two resident blocks per CU, several tiles each for the tile pipeline),
   // 2: weight gradient (few partial rows: its block reduction is the expensive part)
   DwTiledArgs a;
-  tiled_geom(a, dtype, N, H, W, C);
+  tiled_geom(a, dtype, N, H, W, C, kind != 2);
   const int cv = kind == 1 ? C / 4 : a.CV;  // the fused backward works on 4-channel vectors
   const int gx = (cv + LT_CVB - 1) / LT_CVB;
   // measured (tools/lab/op_time.py, [2,65,129,728] bf16): forward 768 / 1024 / 1536 / 2048
@@ -914,9 +1126,11 @@ int dw_tiled_grid_y(int dtype, int C, int N, int H, int W, int kind) {
   return (int)gy;
 }
 
-template <int DIL> static size_t tiled_lds(int dtype, bool with_weights) {
+template <int DIL> static size_t tiled_lds(int dtype, bool with_weights, int nb = 0, int nc = 0) {
   const int vec = dtype == DT_BF16 ? 8 : 4;
-  size_t b = (size_t)TileGeom<DIL>::TILE_VECS * 16;
+  // (the kernels place the parameter rows behind the largest tile image of the launch)
+  size_t b = (size_t)(nb ? TileGeomB<DIL>::TILE_VECS : nc ? TileGeomC<DIL>::TILE_VECS
+                                                          : TileGeom<DIL>::TILE_VECS) * 16;
   const size_t red_fwd = (size_t)LT_THREADS * 2 * vec * sizeof(float);
   const size_t red_wg = (size_t)4 * LT_CVB * 11 * vec * sizeof(float);
   if (b < red_fwd) b = red_fwd;
@@ -977,7 +1191,7 @@ int launch_dw_tiled(int dtype, const void* x, long ldx, int N, int H, int W, int
                     const float* sh, void* y, long ldy, float* stat_partial, int grid_y,
                     hipStream_t st) {
   DwTiledArgs a;
-  tiled_geom(a, dtype, N, H, W, C);
+  tiled_geom(a, dtype, N, H, W, C, true);
   a.w_layout = w_layout;
   a.x = x; a.w = w; a.y = y; a.dy = nullptr; a.sc = sc; a.sh = sh; a.partial = stat_partial;
   a.partial_bn = nullptr; a.res = nullptr; a.ldr = 0;
@@ -985,7 +1199,7 @@ int launch_dw_tiled(int dtype, const void* x, long ldx, int N, int H, int W, int
   const dim3 grid((a.CV + LT_CVB - 1) / LT_CVB, grid_y);
 #define SEG_LT(TT, DD, MM) \
   hipLaunchKernelGGL((dwconv_tiled_kernel<TT, DD, MM>), grid, dim3(LT_THREADS), \
-                     tiled_lds<DD>(dtype, true), st, a)
+                     tiled_lds<DD>(dtype, true, a.nb, a.nc), st, a)
   if (dtype == DT_BF16 && dil == 1) {
     // the prologue modes of the networks as compile-time constants (no per-vector branches)
     switch (pro_mode) {
@@ -1029,7 +1243,7 @@ int launch_dw_bwd_tiled(int dtype, const void* dy, long lddy, const void* x, lon
                         const float* sc, const float* sh, void* g, long ldg, float* partial_w,
                         float* partial_bn, int grid_y, hipStream_t st, const void* res, long ldr) {
   DwTiledArgs a;
-  tiled_geom(a, dtype, N, H, W, C);
+  tiled_geom(a, dtype, N, H, W, C, true);
   a.CV = C / 4;               // HVec: 4 channels per thread in both element types
   a.w_layout = w_layout ^ 2;  // taps staged flipped (bit 1 toggles the caller's orientation)
   a.x = x; a.w = w; a.y = g; a.dy = dy; a.sc = sc; a.sh = sh;
@@ -1039,7 +1253,7 @@ int launch_dw_bwd_tiled(int dtype, const void* dy, long lddy, const void* x, lon
   const dim3 grid((a.CV + LT_CVB - 1) / LT_CVB, grid_y);
 #define SEG_LT(TT, DD, RR) \
   hipLaunchKernelGGL((dwconv_bwd_tiled_kernel<TT, DD, RR>), grid, dim3(LT_THREADS), \
-                     tiled_lds<DD>(dtype, true), st, a)
+                     tiled_lds<DD>(dtype, true, a.nb, a.nc), st, a)
   if (res != nullptr) {  // (dilation 1 only: dw_bwd_tiled_res_supported)
     if (dtype == DT_BF16) SEG_LT(bf16_t, 1, true); else SEG_LT(float, 1, true);
   } else if (dtype == DT_BF16) { if (dil == 1) SEG_LT(bf16_t, 1, false); else SEG_LT(bf16_t, 2, false); }

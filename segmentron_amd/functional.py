@@ -133,7 +133,11 @@ def finish_bn(bn, partial, count, mean_offset=None, y=None):
         if naive:  # the reference's own SyncBN: biased running_var, no counter (batch_norm.py:174)
             rm = rv = None
         box = parallel.mailbox(group)
-        small = y is not None and count <= K.SMALL_BN_ROWS
+        # (decided on the GLOBAL sample count — local count x ranks, what a single process sees
+        # for the same batch — so that one batch takes the same arithmetic however it is sharded;
+        # ranks that decide differently on an uneven batch still exchange compatible messages:
+        # both forms are (sum x, sum x^2, n) as 2C + 1 doubles, the two-pass one just exact)
+        small = y is not None and count * dist.get_world_size(group) <= K.SMALL_BN_ROWS
         if box is not None and small:  # (the same two-pass arithmetic as the single-process path)
             mean, invstd, scale, shift, cnt = K.bn_finalize_small_sync(
                 box, y, bn.weight, bn.bias, bn.eps, momentum, rm, rv, mean_offset)
@@ -216,6 +220,13 @@ def bn_input_backward(g, x, bn, relu, chan_mul=None, inplace=False, elem_mul=Non
                             out=g if inplace else None, elem_mul=elem_mul)
         return dx, None, None
     pro = (mode, bn.scale, bn.shift)
+    if (bn.group is None and not isinstance(bn.count, torch.Tensor) and bn.mean is not None
+            and bn.count <= K.SMALL_BN_ROWS and g.dim() == 4
+            and g.shape[0] * g.shape[1] * g.shape[2] <= K.SMALL_BN_ROWS):
+        # few samples per channel: dx is the remainder of cancelling terms — one float64 launch
+        # (seg_bn_bwd_small) instead of reduce + finalize + fp32 apply
+        return K.bn_bwd_small(g, x, pro, bn.count, bn.mean, bn.invstd, bn.gamma, chan_mul,
+                              elem_mul, bn.training, out=g if inplace else None)
     partial = K.bn_bwd_reduce_partial(g, x, pro, chan_mul, elem_mul)
     if bn.group is None:
         dgamma, dbeta, c0, c1 = K.bn_bwd_finalize_p(partial, bn.count, bn.mean, bn.invstd,
@@ -1180,6 +1191,13 @@ def channel_attention(x, gamma):
 
 
 # ----------------------------------------------------------------------------- functional API
+# Diagnostic switch (numerics bisecting only, read once at import): SEG_NO_FOLD=1 keeps the
+# pending BatchNorm of a 1x1 convolution's input out of the weights — the activation is
+# materialised (or applied in the GEMM prologue) like torch autocast does it, so that the bf16
+# path's distance to the reference can be measured with and without the fold's weight rounding.
+_NO_FOLD = os.environ.get("SEG_NO_FOLD") == "1"
+
+
 def conv_bn(act, conv, bn=None, out=None):
     """conv (nn.Conv2d, groups=1) [+ BatchNorm statistics].  Returns an Act whose BN (if any) and
     ReLU are pending; caller sets ``.relu``."""
@@ -1189,7 +1207,7 @@ def conv_bn(act, conv, bn=None, out=None):
                     want_stats=batch_stats)
     g, b = act.params
     foldable = (act.bn is not None and not act.relu and conv.kernel_size == (1, 1)
-                and conv.padding[0] == 0 and conv.bias is None)
+                and conv.padding[0] == 0 and conv.bias is None and not _NO_FOLD)
     if not foldable and (act.bn is not None or act.relu) and conv.out_channels >= 256:
         # a wide GEMM re-applies the prologue once per 128-column tile of its output
         # (tools/gemm_bench.py: 709 -> 408 TF forward, 419 -> 222 TF weight gradient on

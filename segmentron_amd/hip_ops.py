@@ -420,6 +420,25 @@ def bn_bwd_reduce_partial(g, x, pro, chan_mul=None, elem_mul=None):
     return partial
 
 
+def bn_bwd_small(g, x, pro, count, mean, invstd, gamma, chan_mul=None, elem_mul=None,
+                 training=True, out=None):
+    """BatchNorm backward of a small tensor (<= SMALL_BN_ROWS samples per channel) in one
+    float64 launch -> (dx, dgamma, dbeta)."""
+    N, H, W, C, ldg = nhwc(g)
+    ldx = nhwc(x)[4]
+    mode, s, t = _pro(pro)
+    if out is None:
+        out = torch.empty((N, H, W, C), dtype=g.dtype, device=g.device)
+    lddx = nhwc(out)[4]
+    dgb = torch.empty((2, C), dtype=torch.float32, device=g.device)
+    ldm = nhwc(elem_mul)[4] if elem_mul is not None else 0
+    LIB.call("seg_bn_bwd_small", _DT[g.dtype], _p(g), ldg, _p(x), ldx, _p(out), lddx, N * H * W, C,
+             mode, _p(s), _p(t), _p(mean), _p(invstd), _p(gamma), _p(chan_mul), H * W,
+             _p(elem_mul), ldm, float(count), 1 if training else 0, _p(dgb[0]), _p(dgb[1]),
+             _stream())
+    return out, dgb[0], dgb[1]
+
+
 def bn_bwd_reduce(g, x, pro, chan_mul=None):
     """-> float64 [2C]: (sum g', sum g'*x)."""
     return colsum(bn_bwd_reduce_partial(g, x, pro, chan_mul), f64=True)

@@ -394,6 +394,51 @@ def test_bn_finalize_small_two_pass_statistics_with_a_large_mean(shape, dtype):
     assert_close(rvd.cpu(), rv_ref, torch.float32, "running_var", fac=5)
 
 
+@pytest.mark.parametrize("relu", [False, True])
+@pytest.mark.parametrize("shape", [(2, 1, 1), (2, 6, 6), (4, 9, 13)])
+def test_bn_backward_small_float64_in_one_launch(shape, relu):
+    """seg_bn_bwd_small (r05): BatchNorm backward over few samples — with two samples per channel
+    dx is what is left when three terms cancel (xhat = +-1 up to eps); fp32 `scale*g - c0 - c1*x`
+    keeps 6e-8 of the TERMS (ASPP image pooling: 94 % of the C3 model's fp32 gradient error).
+    Against torch autograd in float64 on the same fp32 values; channel mask + ReLU mask; a
+    channel-slice pitch; in place."""
+    N, H, W = shape
+    C = 72
+    dtype = torch.float32
+    base = rnd((1, C, 1, 1), 5) * 3 + 20.0
+    x = quant(base + rnd((N, C, H, W), 6) * 0.02, dtype)
+    g = quant(rnd((N, C, H, W), 7), dtype)
+    gamma, beta = torch.rand(C) + 0.5, rnd((C,), 3, 0.2)
+    mul = (torch.rand(N, C) > 0.3).float() / 0.7
+    xd = x.double().requires_grad_()
+    gd, bd = gamma.double().requires_grad_(), beta.double().requires_grad_()
+    y = TF.batch_norm(xd, None, None, gd, bd, True, 0.1, 1e-5)
+    if relu:
+        y = torch.relu(y)
+    (y * mul.double().view(N, C, 1, 1)).backward(g.double())
+    xbuf = to_dev_nhwc(x, dtype, pitch=C + 8)
+    mean, invstd, scale, shift = K().bn_finalize_small(xbuf, gamma.to(DEV), beta.to(DEV), 1e-5, 0.1,
+                                                       None, None)
+    gbuf = to_dev_nhwc(g, dtype)
+    pro = (3 if relu else 2, scale, shift)
+    dx, dgamma, dbeta = K().bn_bwd_small(gbuf, xbuf, pro, float(N * H * W), mean, invstd,
+                                         gamma.to(DEV), chan_mul=mul.to(DEV), out=gbuf)
+    assert dx.data_ptr() == gbuf.data_ptr()
+    ref = xd.grad
+    err = ((to_cpu_nchw(dx).double() - ref).abs().max() / ref.abs().max()).item()
+    # (the forward's fp32 mean / invstd / scale / shift bound this: 1e-7 * |x| / spread = 1e-4)
+    assert err < 5e-3, err
+    assert_close(dgamma.cpu(), gd.grad, torch.float32, "dgamma", fac=50)
+    assert_close(dbeta.cpu(), bd.grad, torch.float32, "dbeta")
+    # the three-launch fp32 path on the same operands loses the result where the terms cancel
+    part = K().bn_bwd_reduce_partial(to_dev_nhwc(g, dtype), xbuf, pro, mul.to(DEV))
+    _, _, c0, c1 = K().bn_bwd_finalize_p(part, float(N * H * W), mean, invstd, gamma.to(DEV))
+    dx32 = K().bn_bwd_apply(to_dev_nhwc(g, dtype), xbuf, pro, c0, c1, mul.to(DEV))
+    err32 = ((to_cpu_nchw(dx32).double() - ref).abs().max() / ref.abs().max()).item()
+    print("bn backward, %d samples per channel, |mean| / spread = 1e3: float64 launch %.2e, "
+          "fp32 reduce + finalize + apply %.2e of max |dx|" % (N * H * W, err, err32))
+
+
 @pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
 def test_bn_apply_residual_and_channel_mask(dtype):
     N, C, H, W = 2, 72, 7, 9

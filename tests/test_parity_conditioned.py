@@ -285,6 +285,13 @@ def test_c3_fp32_and_bf16_train_step_513x1025_fixed_bars():
     st, per = _grad_stats(dict(model.named_parameters()), g64)
     print("PARITY-COND c3 fp32 513x1025: logits max-rel %.2e loss %.6f vs %.6f | gradients vs fp64 "
           "oracle: global rel %.2e cosine %.7f" % (rel, loss.item(), l64, st["global_rel"], st["cos"]))
+    # where the fp32 distance sits (share of the squared global error; the CPU oracle's own fp32
+    # run is 4.1e-4 from float64 at this size — tools/tmp measurement r05)
+    top = sorted(per, key=lambda p: -p[0])[:8]
+    tot = sum(p[0] ** 2 for p in per)
+    print("PARITY-COND c3 fp32 513x1025 error shares: " + "; ".join(
+        "%s %.0f%% (rel %.1e)" % (k, 100 * e * e / tot, e / max(share ** 0.5 * st["norm"], 1e-300))
+        for e, cos, ratio, share, k in top))
     assert rel < 1e-3 and abs(loss.item() - l64) < 1e-3 * l64
     assert st["global_rel"] <= 1e-3
     del model, outs, loss
@@ -302,6 +309,46 @@ def test_c3_fp32_and_bf16_train_step_513x1025_fixed_bars():
     assert abs(loss.item() - l64) <= 1e-2 * l64
     assert st["cos"] >= min(0.99, ac[4]) - 0.03
     assert abs(st["ratio"] - 1.0) <= max(0.10, 1.5 * abs(ac[5] - 1.0))
+
+
+@pytest.mark.gpu
+def test_c3_train_full_size_1025x2049_matches_oracle():
+    """The configuration bench.py is quoted on (BASELINE.json configs[2]: train, batch 2
+    @1025x2049), one step, against the CPU fp32 oracle's step on the same conditioned state —
+    the comparison bench.py emits as `parity` (oracle/parity.py; VERDICT r04 Missing #1;
+    /root/reference/tools/train.py:135-146).  fp32 kernels: north_star's 1e-3 on loss, logits
+    (a [::16, ::16] pixel grid) and the global gradient; bf16: the reference-under-autocast
+    yardstick of the fixture, as in the smaller tests above."""
+    from oracle import parity as OP
+    H, W = 1025, 2049
+    sd = _state("c3")
+    x, y = OP.inputs(2, H, W, seed=0)
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    ref = OP.oracle_step(sd, x, y, torch.float32)
+    _build_hip("c3", torch.float32, True)  # (sets cfg; OP.hip_step builds its own models)
+    f32 = OP.compare(OP.hip_step("fp32", sd, x, y), ref)
+    b16 = OP.compare(OP.hip_step("bf16", sd, x, y), ref)
+    ac = _fixture("c3")["ref_autocast_bf16"]
+    print("PARITY-COND c3 FULL SIZE 1025x2049 B=2 vs CPU fp32 oracle (%.0f s): fp32 loss rel %.2e "
+          "logits max-rel %.2e gradients global rel %.2e cosine %.7f | bf16 loss rel %.2e logits "
+          "L2-rel %.3e argmax %.4f gradients cosine %.5f ratio %.4f (reference autocast @65x129: "
+          "cosine %.5f ratio %.4f)"
+          % (ref["seconds"], f32["loss_rel"], f32["logits_maxrel"], f32["grad_global_rel"],
+             f32["grad_cosine"], b16["loss_rel"], b16["logits_l2rel"], b16["argmax_agree"],
+             b16["grad_cosine"], b16["grad_norm_ratio"], ac[4], ac[5]))
+    assert f32["finite"] and b16["finite"]
+    assert f32["grad_tensors_missing"] == 0 and b16["grad_tensors_missing"] == 0
+    assert f32["loss_rel"] < 1e-3 and f32["logits_maxrel"] < 1e-3
+    assert f32["grad_global_rel"] <= FULL_SIZE_GRAD_BAR_FP32
+    assert b16["loss_rel"] <= 1e-2
+    assert b16["logits_l2rel"] <= max(2e-2, 1.5 * max(ac[0], ac[2])) and b16["argmax_agree"] >= ac[1] - 0.03
+    assert b16["grad_cosine"] >= min(0.99, ac[4]) - 0.03
+    assert abs(b16["grad_norm_ratio"] - 1.0) <= max(0.10, 1.5 * abs(ac[5] - 1.0))
+
+
+# north_star's 1e-3 (against the fp32 CPU oracle, which itself sits FULL_SIZE_ORACLE_FP32_VS_FP64
+# from float64 at this size — measured on the CPU, see DESIGN.md section 4)
+FULL_SIZE_GRAD_BAR_FP32 = 1e-3
 
 
 def _oracle_sgd_steps(sd, x, y, steps, lr, momentum, wd):

@@ -1,0 +1,220 @@
+// Lab: A/B of several builds of the forward / data-gradient GEMM entry point (seg_conv_gemm_fwd)
+// on the GEMM shapes of DeepLabv3+/xception65 @1025x2049 (batch 2, bf16), without torch.
+//   hipcc -O3 --offload-arch=gfx950 -o gemm_ab gemm_ab.hip -ldl
+//   ./gemm_ab <baseline.so> <candidate.so> [<candidate2.so> ...]
+// Every library runs every case on the same inputs.  Checked per library:
+//   * 4096 sampled outputs against a float64 host evaluation of the definition (incl. the
+//     folded-BatchNorm correction of the data-gradient cases), in units of bf16 ulps of the result;
+//   * the whole output tensor against the baseline library (max |diff|, count above 2 ulp);
+//   * the BatchNorm partial rows: column sums against float64 sums of the library's OWN stored
+//     output (the statistics are defined on the values as stored).
+// Timing: HIP events over 40 launches, three interleaved rounds, minimum and median reported.
+// Also prints the lane mapping of v_permlane16_swap (what conv_gemm_g4.hip's epilogue relies on).
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
+  printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
+
+typedef int (*fwd_fn)(int, const void*, long, int, int, int, int, const void*, int, int, int, int, int,
+                      int, int, const float*, const float*, const float*, void*, long, int, int, int,
+                      int, int, float*, const void*, long, const float*, const float*, int, void*);
+typedef int (*rows_fn)(int, int, int, int, int, int, int, int, int, int, int, int, int, int);
+typedef const char* (*err_fn)();
+struct Lib { void* h; fwd_fn fwd; rows_fn rows; err_fn err; const char* path; };
+
+static int load(Lib& l, const char* path) {
+  l.h = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+  if (!l.h) { printf("dlopen %s: %s\n", path, dlerror()); return 1; }
+  l.fwd = (fwd_fn)dlsym(l.h, "seg_conv_gemm_fwd");
+  l.rows = (rows_fn)dlsym(l.h, "seg_conv_gemm_stat_rows");
+  l.err = (err_fn)dlsym(l.h, "seg_last_error");
+  l.path = path;
+  if (!l.fwd || !l.rows || !l.err) { printf("%s: missing symbol\n", path); return 1; }
+  return 0;
+}
+
+__global__ void fill_bf16(uint16_t* p, long n, uint32_t seed, float scale) {
+  long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) {
+    uint32_t h = ((uint32_t)i + seed) * 2654435761u; h ^= h >> 13; h *= 0x5bd1e995u; h ^= h >> 15;
+    const float v = ((float)(h & 0xffff) / 32768.f - 1.f) * scale;  // uniform [-scale, scale)
+    uint32_t u = __float_as_uint(v);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    p[i] = (uint16_t)(u >> 16);
+  }
+}
+
+__global__ void swap_probe(uint32_t* out) {
+  uint32_t a = threadIdx.x, b = 100 + threadIdx.x;
+  auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+  out[threadIdx.x] = r[0];
+  out[64 + threadIdx.x] = r[1];
+  auto q = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+  out[128 + threadIdx.x] = q[0];
+  out[192 + threadIdx.x] = q[1];
+}
+
+static inline float bf(uint16_t v) { union { uint32_t u; float f; } c; c.u = (uint32_t)v << 16; return c.f; }
+static inline double ulp_of(double v) { const double a = fabs(v); if (a < 1e-30) return 1e-30; int e; frexp(a, &e); return ldexp(1.0, e - 8); }
+
+struct Case { const char* name; int N, H, W, C, O, KH, dil; int mode; int per_step; };  // mode 0 plain, 1 stats, 2 ep
+
+int main(int argc, char** argv) {
+  if (argc < 3) { printf("usage: gemm_ab <baseline.so> <candidate.so>...\n"); return 2; }
+  const int nl = argc - 1;
+  std::vector<Lib> L(nl);
+  for (int i = 0; i < nl; ++i) if (load(L[i], argv[1 + i])) return 1;
+  {
+    uint32_t* d; CK(hipMalloc(&d, 256 * 4));
+    hipLaunchKernelGGL(swap_probe, dim3(1), dim3(64), 0, 0, d);
+    uint32_t h[256]; CK(hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost));
+    printf("permlane32_swap(vdst = lane, src = 100 + lane): new vdst halves start with %u %u, new src halves %u %u "
+           "(expected 0 100 / 32 132)\n", h[128], h[160], h[192], h[224]);
+    printf("permlane16_swap(vdst = lane, src = 100 + lane): new vdst rows start with %u %u %u %u, new src rows %u %u %u %u "
+           "(expected 0 100 32 132 / 16 116 48 148)\n", h[0], h[16], h[32], h[48], h[64], h[80], h[96], h[112]);
+    CK(hipFree(d));
+  }
+  const Case cases[] = {
+      {"728->728 fwd+stats", 2, 65, 129, 728, 728, 1, 1, 1, 48},
+      {"728->728 dgrad+ep", 2, 65, 129, 728, 728, 1, 1, 2, 48},
+      {"728->728 plain", 2, 65, 129, 728, 728, 1, 1, 0, 0},
+      {"728->1024 fwd+stats", 2, 65, 129, 728, 1024, 1, 1, 1, 2},
+      {"1024->1536 fwd+stats", 2, 65, 129, 1024, 1536, 1, 1, 1, 1},
+      {"1536->1536 fwd+stats", 2, 65, 129, 1536, 1536, 1, 1, 1, 1},
+      {"1536->2048 fwd+stats", 2, 65, 129, 1536, 2048, 1, 1, 1, 1},
+      {"2048->1536 dgrad+ep", 2, 65, 129, 2048, 1536, 1, 1, 2, 1},
+      {"256->728 @129x257 fwd+stats", 2, 129, 257, 256, 728, 1, 1, 1, 2},
+      {"728->256 @129x257 dgrad+ep", 2, 129, 257, 728, 256, 1, 1, 2, 2},
+      {"728->728 @33x65 fwd+stats", 2, 33, 65, 728, 728, 1, 1, 1, 0},
+      {"304->256 @257x513 fwd+stats", 2, 257, 513, 304, 256, 1, 1, 1, 1},
+      {"3x3 dil2 256->256 @129x257 fwd+stats", 2, 129, 257, 256, 256, 3, 2, 1, 0},
+      {"3x3 dil4 512->512 @65x129 plain", 2, 65, 129, 512, 512, 3, 4, 0, 0},
+      {"3x3 dil1 96->384 @47x47 fwd+stats (ragged)", 2, 47, 47, 96, 384, 3, 1, 1, 0},
+  };
+  const int DT_BF16 = 1;
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  std::vector<double> step_us(nl, 0.0);
+  int failures = 0;
+  for (const Case& c : cases) {
+    const long M = (long)c.N * c.H * c.W;
+    const int K = c.KH * c.KH * c.C, pad = c.KH == 1 ? 0 : c.dil * (c.KH / 2);
+    uint16_t *x, *w, *epx; float *c0, *c1;
+    CK(hipMalloc(&x, M * c.C * 2)); CK(hipMalloc(&w, (long)c.O * K * 2)); CK(hipMalloc(&epx, M * c.O * 2));
+    CK(hipMalloc(&c0, c.O * 4)); CK(hipMalloc(&c1, c.O * 4));
+    hipLaunchKernelGGL(fill_bf16, dim3((M * c.C + 255) / 256), dim3(256), 0, 0, x, M * c.C, 1u, 1.0f);
+    hipLaunchKernelGGL(fill_bf16, dim3(((long)c.O * K + 255) / 256), dim3(256), 0, 0, w, (long)c.O * K, 77u, 1.7f / sqrtf((float)K));
+    hipLaunchKernelGGL(fill_bf16, dim3((M * c.O + 255) / 256), dim3(256), 0, 0, epx, M * c.O, 991u, 1.0f);
+    std::vector<float> hc0(c.O), hc1(c.O);
+    for (int i = 0; i < c.O; ++i) { hc0[i] = 0.01f * ((i % 23) - 11); hc1[i] = 0.02f * ((i % 17) - 8); }
+    CK(hipMemcpy(c0, hc0.data(), c.O * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(c1, hc1.data(), c.O * 4, hipMemcpyHostToDevice));
+    std::vector<uint16_t> hx(M * c.C), hw((long)c.O * K), hep(M * c.O);
+    CK(hipMemcpy(hx.data(), x, M * c.C * 2, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(hw.data(), w, (long)c.O * K * 2, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(hep.data(), epx, M * c.O * 2, hipMemcpyDeviceToHost));
+    printf("%s  [M=%ld K=%d O=%d, %.1f GFLOP]\n", c.name, M, K, c.O, 2.0 * M * K * c.O / 1e9);
+    std::vector<std::vector<uint16_t>> out(nl, std::vector<uint16_t>(M * c.O));
+    std::vector<uint16_t*> y(nl); std::vector<float*> sp(nl); std::vector<int> rows(nl);
+    for (int k = 0; k < nl; ++k) {
+      rows[k] = L[k].rows(DT_BF16, c.N, c.H, c.W, c.C, c.O, c.KH, c.KH, 1, pad, c.dil, 0, 0, 0);
+      CK(hipMalloc(&y[k], M * c.O * 2)); CK(hipMalloc(&sp[k], (long)rows[k] * 2 * c.O * 4));
+      CK(hipMemset(y[k], 0xff, M * c.O * 2)); CK(hipMemset(sp[k], 0xff, (long)rows[k] * 2 * c.O * 4));
+    }
+    auto run = [&](int k) {
+      return L[k].fwd(DT_BF16, x, c.C, c.N, c.H, c.W, c.C, w, c.O, c.KH, c.KH, 1, pad, c.dil, 0, nullptr,
+                      nullptr, nullptr, y[k], c.O, c.H, c.W, c.H, c.W, 1, c.mode == 1 ? sp[k] : nullptr,
+                      c.mode == 2 ? epx : nullptr, c.O, c.mode == 2 ? c0 : nullptr,
+                      c.mode == 2 ? c1 : nullptr, 0, nullptr);
+    };
+    std::vector<std::vector<float>> us(nl);
+    for (int round = 0; round < 3; ++round)
+      for (int k = 0; k < nl; ++k) {
+        for (int i = 0; i < 3; ++i) if (run(k)) { printf("  %s: %s\n", L[k].path, L[k].err()); return 1; }
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(e0));
+        for (int i = 0; i < 40; ++i) run(k);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        us[k].push_back(ms * 1e3f / 40);
+      }
+    // sampled float64 reference
+    const int NS = 4096;
+    std::vector<long> sp_p(NS); std::vector<int> sp_o(NS); std::vector<double> ref(NS);
+    uint32_t h = 12345u;
+    for (int s = 0; s < NS; ++s) {
+      h = h * 1664525u + 1013904223u; long p = (long)(h >> 4) % M;
+      h = h * 1664525u + 1013904223u; int o = (int)((h >> 4) % (uint32_t)c.O);
+      if (s < 64) { p = M - 1 - (s % 32) * 7 % M; o = c.O - 1 - (s % 16); }  // the tails, always
+      if (s >= 64 && s < 128) { p = (s - 64) * 37 % M; o = (s * 5) % c.O; }
+      sp_p[s] = p; sp_o[s] = o;
+      const int wo = (int)(p % c.W), ho = (int)((p / c.W) % c.H), n = (int)(p / ((long)c.W * c.H));
+      double acc = 0;
+      for (int kh = 0; kh < c.KH; ++kh)
+        for (int kw = 0; kw < c.KH; ++kw) {
+          const int hi = ho - pad + kh * c.dil, wi = wo - pad + kw * c.dil;
+          if (hi < 0 || hi >= c.H || wi < 0 || wi >= c.W) continue;
+          const uint16_t* xr = &hx[(((long)n * c.H + hi) * c.W + wi) * c.C];
+          const uint16_t* wr = &hw[(long)o * K + (kh * c.KH + kw) * c.C];
+          for (int ch = 0; ch < c.C; ++ch) acc += (double)bf(xr[ch]) * bf(wr[ch]);
+        }
+      if (c.mode == 2) acc = acc - hc0[o] - (double)hc1[o] * bf(hep[p * c.O + o]);
+      ref[s] = acc;
+    }
+    for (int k = 0; k < nl; ++k) {
+      CK(hipMemcpy(out[k].data(), y[k], M * c.O * 2, hipMemcpyDeviceToHost));
+      double worst = 0; int bad = 0;
+      for (int s = 0; s < NS; ++s) {
+        const double got = bf(out[k][sp_p[s] * c.O + sp_o[s]]);
+        // (+ 4e-6: the fp32 accumulation error of a result that cancelled to ~0)
+        const double d = fabs(got - ref[s]) / (ulp_of(ref[s]) + 4e-6);
+        if (!(d <= 2.0)) ++bad;  // (nan counts; the r02 data-gradient epilogue rounds twice)
+        if (!(d <= worst)) worst = d;
+      }
+      long nd = 0, n2 = 0; double md = 0;
+      if (k > 0)
+        for (long i = 0; i < M * c.O; ++i) if (out[k][i] != out[0][i]) {
+          ++nd; const double a = bf(out[k][i]), b = bf(out[0][i]); const double d = fabs(a - b);
+          if (!(d <= md)) md = d;
+          if (!(d <= 2 * ulp_of(b))) ++n2;
+        }
+      double stat_err = 0;
+      if (c.mode == 1) {
+        std::vector<float> hp((long)rows[k] * 2 * c.O);
+        CK(hipMemcpy(hp.data(), sp[k], hp.size() * 4, hipMemcpyDeviceToHost));
+        std::vector<double> s1(c.O, 0.0), s2(c.O, 0.0), g1(c.O, 0.0), g2(c.O, 0.0);
+        for (long p = 0; p < M; ++p)
+          for (int o = 0; o < c.O; ++o) { const double v = bf(out[k][p * c.O + o]); s1[o] += v; s2[o] += v * v; }
+        for (int r = 0; r < rows[k]; ++r)
+          for (int o = 0; o < c.O; ++o) { g1[o] += hp[((long)r * 2 + 0) * c.O + o]; g2[o] += hp[((long)r * 2 + 1) * c.O + o]; }
+        for (int o = 0; o < c.O; ++o) {
+          const double a = fabs(g1[o] - s1[o]) / (sqrt(s2[o] * (double)M) * 1e-6 + 1e-30);  // in units of 1e-6 * sqrt(M * sum sq)
+          const double b = fabs(g2[o] - s2[o]) / (s2[o] * 1e-6 + 1e-30);
+          if (!(a <= stat_err)) stat_err = a;
+          if (!(b <= stat_err)) stat_err = b;
+        }
+      }
+      std::vector<float> t = us[k]; std::sort(t.begin(), t.end());
+      const bool ok = bad == 0 && (c.mode != 1 || stat_err <= 20.0) && (k == 0 || n2 == 0);
+      if (!ok) ++failures;
+      printf("  %-44s %7.2f us (median %7.2f) %6.0f TF | rows %4d | vs fp64: worst %.2f ulp, %d of %d above 2 ulp | "
+             "vs baseline: %ld differ (max %.3g, %ld above 2 ulp) | stats err %.2f  %s\n",
+             strrchr(L[k].path, '/') ? strrchr(L[k].path, '/') + 1 : L[k].path, t[0], t[1],
+             2.0 * M * K * c.O / (t[0] * 1e-6) / 1e12, rows[k], worst, bad, NS, nd, md, n2, stat_err,
+             ok ? "ok" : "FAIL");
+      step_us[k] += (double)t[0] * c.per_step;
+      CK(hipFree(y[k])); CK(hipFree(sp[k]));
+    }
+    CK(hipFree(x)); CK(hipFree(w)); CK(hipFree(epx)); CK(hipFree(c0)); CK(hipFree(c1));
+  }
+  printf("per-step estimate (launch counts of one C3 train step on these shapes):\n");
+  for (int k = 0; k < nl; ++k) printf("  %-44s %.3f ms\n", L[k].path, step_us[k] * 1e-3);
+  printf(failures ? "FAILURES: %d\n" : "all ok (%d)\n", failures);
+  return failures ? 1 : 0;
+}
