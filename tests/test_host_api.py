@@ -239,7 +239,7 @@ def test_torch_custom_ops_are_registered_with_fake_implementations():
 def _g4_rows(M, O):
     """csrc/conv_gemm_g4.hip g4_rows_per_tile: rounds on 256 CUs x (tile rows + fixed cost)."""
     best = None
-    for bm in (256, 224, 192):
+    for bm in (256, 192):
         tiles = -(-M // bm) * -(-O // 256)
         cost = -(-tiles // 256) * (bm + 96)
         if best is None or cost < best[0]:
@@ -264,11 +264,13 @@ def test_kernel_selection_queries_of_the_c_library():
     assert q("seg_conv_gemm_stat_rows", BF16, 2, 513, 1025, 32, 64, 3, 3, 1, 2, 2, 0, 0, 0) == (M + 255) // 256
     # small map: first-generation 128-pixel tiles; 1x1 with O >= 384: the 256-pixel-tile kernels
     assert q("seg_conv_gemm_stat_rows", BF16, 2, 33, 65, 32, 64, 3, 3, 1, 1, 1, 0, 0, 0) == (2 * 33 * 65 + 127) // 128
-    # ... bf16 without prologue / bias: the r05 kernel picks the tile rows that fill the 256 CUs
-    # (728 -> 728 @ 16770 pixels: 225 tiles of 224 rows instead of 198 of 256; with a bias or in
-    # fp32: the 256-pixel-tile kernel)
-    assert q("seg_conv_gemm_stat_rows", BF16, 2, 65, 129, 728, 728, 1, 1, 1, 0, 1, 0, 0, 0) == (2 * 65 * 129 + 223) // 224
-    assert _g4_rows(2 * 65 * 129, 728) == (2 * 65 * 129 + 223) // 224
+    # ... bf16 without prologue / bias: the r05 kernel picks 256- or 192-row tiles, whichever
+    # fills the 256 CUs in fewer / shorter rounds (728 -> 728 @ 16770 pixels: 198 tiles of 256
+    # rows in one round; 728 -> 1024: 352 tiles of 192 rows instead of 264 of 256, both two
+    # rounds); with a bias or in fp32: the 256-pixel-tile kernel
+    assert q("seg_conv_gemm_stat_rows", BF16, 2, 65, 129, 728, 728, 1, 1, 1, 0, 1, 0, 0, 0) == (2 * 65 * 129 + 255) // 256
+    assert q("seg_conv_gemm_stat_rows", BF16, 2, 65, 129, 728, 1024, 1, 1, 1, 0, 1, 0, 0, 0) == (2 * 65 * 129 + 191) // 192
+    assert _g4_rows(2 * 65 * 129, 728) == 66 and _g4_rows(2 * 65 * 129, 1024) == 88
     assert q("seg_conv_gemm_stat_rows", BF16, 2, 65, 129, 728, 728, 1, 1, 1, 0, 1, 0, 1, 0) == (2 * 65 * 129 + 255) // 256
     assert q("seg_conv_gemm_stat_rows", F32, 2, 65, 129, 728, 728, 1, 1, 1, 0, 1, 0, 0, 0) == (2 * 65 * 129 + 255) // 256
     # ResNet layer3 3x3 (256 -> 256, dilation 2) without a prologue: the direct-to-LDS pipeline
