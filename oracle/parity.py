@@ -89,15 +89,20 @@ def compare(got, ref):
     a, b = got["logits"].double(), ref["logits"].double()
     num = den = dot = na = 0.0
     missing = [k for k in ref["grads"] if k not in got["grads"]]
+    per = []
     for k, t in ref["grads"].items():
         if k not in got["grads"]:
             continue
         g, t = got["grads"][k].double(), t.double()
-        num += float((g - t).norm()) ** 2
-        den += float(t.norm()) ** 2
-        na += float(g.norm()) ** 2
-        dot += float((g * t).sum())
+        e2, n2, m2, d = float((g - t).norm()) ** 2, float(t.norm()) ** 2, float(g.norm()) ** 2, \
+            float((g * t).sum())
+        num, den, na, dot = num + e2, den + n2, na + m2, dot + d
+        per.append((e2, n2, d / max((m2 * n2) ** 0.5, 1e-300), k))
+    per.sort(reverse=True)
+    top = [{"tensor": k, "share_of_sq_error": e2 / max(num, 1e-300),
+            "share_of_sq_norm": n2 / max(den, 1e-300), "cosine": c} for e2, n2, c, k in per[:6]]
     return dict(
+        grad_error_top=top,
         loss_rel=abs(got["loss"] - ref["loss"]) / abs(ref["loss"]),
         logits_maxrel=float((a - b).abs().max() / b.abs().max()),
         logits_l2rel=float((a - b).norm() / b.norm()),

@@ -36,13 +36,10 @@ int launch_conv_gemm_glds(ConvGemmArgs a, hipStream_t stream);
 bool conv_gemm_glds_kxk_usable(int dtype, const ConvGemmArgs& a);
 int launch_conv_gemm_glds_kxk(ConvGemmArgs a, hipStream_t stream);
 
-// fourth generation (conv_gemm_g4.hip, r05): (192 | 224 | 256) x 256 tiles on 16x16x32 MFMAs,
-// register-direct epilogue; a statistics row describes g4_rows_per_tile(M, O) pixels
-bool conv_gemm_g4_usable(int dtype, const ConvGemmArgs& a);
-int g4_rows_per_tile(long M, int O);
-int g4_tiles_m(long M, int O);
-int launch_conv_gemm_g4(ConvGemmArgs a, hipStream_t stream);
-int launch_conv_gemm_g4_kxk(ConvGemmArgs a, hipStream_t stream);
+// r05: 256- or 192-row tiles, whichever fills the 256 CUs in fewer / shorter rounds; a
+// statistics row describes glds_rows_per_tile(M, O) pixels
+int glds_rows_per_tile(long M, int O);
+int glds_tiles_m(long M, int O);
 
 // direct 3x3 stride-1 kernel for few channels at large spatial sizes (conv3x3_direct.hip)
 bool conv3x3_direct_usable(int dtype, const ConvGemmArgs& a);

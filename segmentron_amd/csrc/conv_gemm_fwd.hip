@@ -364,11 +364,11 @@ extern "C" int seg_conv_gemm_stat_rows(int dtype, int N, int Ho, int Wo, int C, 
                                        int has_bias, int pro_mode) {
   const long M = (long)N * Ho * Wo;
   if (seg::g_gemm_px256 && gemm_use_px256(KH, KW, stride, pad, tconv, O, M)) {
-    // the direct-to-LDS kernel (bf16, no prologue / bias: conv_gemm_g4_usable up to the pitch
+    // the direct-to-LDS kernel (bf16, no prologue / bias: conv_gemm_glds_usable up to the pitch
     // checks, which seg_conv_gemm_fwd settles by zero-filling the rows a fallback leaves out)
     if (seg::g_gemm_px256 >= 2 && dtype == seg::DT_BF16 && pro_mode == seg::PRO_NONE &&
         !has_bias && (C % 8) == 0 && (O % 8) == 0)
-      return seg::g4_tiles_m(M, O);
+      return seg::glds_tiles_m(M, O);
     return seg::px256_tiles_m(M);
   }
   {  // KxK on the direct-to-LDS pipeline (the predicate does not look at the input size)
@@ -377,7 +377,7 @@ extern "C" int seg_conv_gemm_stat_rows(int dtype, int N, int Ho, int Wo, int C, 
     probe.tconv = tconv; probe.out_s = 1; probe.C = C; probe.O = O; probe.ldx = 8; probe.ldy = 8;
     probe.N = 1; probe.Hi = 1; probe.Wi = 1; probe.M = (int)M; probe.pro_mode = pro_mode;
     probe.bias = has_bias ? reinterpret_cast<const float*>(&probe) : nullptr;
-    if (gemm_use_glds_kxk(dtype, probe)) return seg::g4_tiles_m(M, O);
+    if (gemm_use_glds_kxk(dtype, probe)) return seg::glds_tiles_m(M, O);
   }
   {  // the direct 3x3 kernel (stride 1, pad 1: the input has the output's size)
     seg::ConvGemmArgs probe = {};
@@ -428,8 +428,8 @@ extern "C" int seg_conv_gemm_fwd(int dtype, const void* x, long ldx, int N, int 
   }
   SEG_REQUIRE(out_s == 1 || stat_partial == nullptr, "conv_gemm_fwd: no statistics with scatter");
   if (g_gemm_px256 && gemm_use_px256(KH, KW, stride, pad, tconv, O, a.M) && out_s == 1) {
-    if (g_gemm_px256 >= 2 && conv_gemm_g4_usable(dtype, a))
-      return launch_conv_gemm_g4(a, (hipStream_t)stream);
+    if (g_gemm_px256 >= 2 && conv_gemm_glds_usable(dtype, a))
+      return launch_conv_gemm_glds(a, (hipStream_t)stream);
     if (stat_partial != nullptr) {
       // the caller sized the statistics rows with seg_conv_gemm_stat_rows, which cannot see the
       // pitches: rows this kernel will not write must read as zero
@@ -444,14 +444,12 @@ extern "C" int seg_conv_gemm_fwd(int dtype, const void* x, long ldx, int N, int 
         return 2;
       }
     }
-    if (g_gemm_px256 >= 2 && conv_gemm_glds_usable(dtype, a))
-      return launch_conv_gemm_glds(a, (hipStream_t)stream);
     return launch_conv_gemm_px256(dtype, a, (hipStream_t)stream);
   }
   if (g_conv3x3_direct && conv3x3_direct_usable(dtype, a))
     return launch_conv3x3_direct(a, (hipStream_t)stream);
   if (out_s == 1 && gemm_use_glds_kxk(dtype, a))
-    return launch_conv_gemm_g4_kxk(a, (hipStream_t)stream);
+    return launch_conv_gemm_glds_kxk(a, (hipStream_t)stream);
   if (dtype == DT_BF16) return launch_conv_gemm_fwd<bf16_t>(a, (hipStream_t)stream);
   return launch_conv_gemm_fwd<float>(a, (hipStream_t)stream);
 }

@@ -2,7 +2,29 @@
 // (gemm_glds.h): bf16, no element-wise prologue on the pixel operand.  Same argument block,
 // epilogue features and BatchNorm-statistics format as conv_gemm_px256.hip (folded-BN
 // backward correction y = acc - c0[o] - c1[o]*x[p][o], channel-slice output, ragged O, per
-// 256-pixel-tile (sum, sum of squares) rows taken from the values as stored).
+// pixel-tile (sum, sum of squares) rows taken from the values as stored).
+//
+// r05: the tile ROWS are chosen per launch — 256 or 192 (IMS = 4 / 3 row blocks per wave) — so
+// that the tiles fill the 256 CUs in fewer or shorter rounds (glds_rows_per_tile); a statistics
+// row then describes 256 OR 192 pixels and seg_conv_gemm_stat_rows tells the caller how many
+// rows there are.  Measured (tools/lab/gemm_ab, profiles/r05_gemm_ab.md): 728 -> 1024 @16770
+// pixels 54.1 -> 47.1 us, 1536 -> 2048 136.6 -> 124.2, dilated 3x3 256 -> 256 @66306 143.5 ->
+// 130.5, 728 -> 728 @4290 22.7 -> 20.1; 728 -> 728 @16770 stays on 256 rows (198 tiles, one
+// round; 192 rows would need two).
+// Tried in r05 and dropped (same file, same harness; numbers in DESIGN.md section 3):
+//  * a register-direct epilogue (v_permlane32_swap + v_permlane16_swap regroup the 32x32
+//    accumulators into 16-byte vectors, 64 contiguous bytes per pixel and store, no LDS patch):
+//    31.0 vs 30.9 us forward, 38.3 vs 33.1 us data gradient on 728 -> 728 — the ~130 lane
+//    exchanges per wave cost what the LDS round trips did; with 32 contiguous bytes per pixel
+//    (one stage) 44.7 us;
+//  * the whole kernel on v_mfma_f32_16x16x32_bf16 (lane-linear fragment reads, 224-row tiles,
+//    one-stage v_permlane16_swap epilogue): 27.0 vs 29.1 us on 728 -> 728 (225 tiles instead of
+//    198, cheaper epilogue) but a 13-17 % slower main loop (74 vs 63 us on 1024 -> 1536, 151 vs
+//    134 us on 1536 -> 2048);
+//  * ping-pong wave groups (waves 4-7 one barrier interval behind waves 0-3; interval X = DMA
+//    issue + all 12 fragment reads, interval Y = the slot's 16 MFMAs): 74.2 vs 68.4 us on
+//    1024 -> 1536 — the load interval is longer than the MFMA interval, and the lockstep ring
+//    already hides its fragment reads under its own MFMAs (~70 % MFMA duty in the loop).
 #include "conv_gemm.h"
 #include "conv_gemm_args.h"
 #include "gemm_glds.h"
@@ -12,7 +34,13 @@ namespace seg {
 // EP: folded-BatchNorm backward correction in the store path; STATS: BatchNorm partial sums
 // KXK: stride-1 KxK convolution as an implicit GEMM (per-lane gather in the DMA source address,
 // gemm_glds.h GlConvA) — ResNet bottleneck / PSP-head 3x3s, C % 32 == 0
-template <bool EP, bool STATS, bool KXK = false>
+#ifdef LAB_TICKET
+__device__ unsigned g_lab_ticket[64];
+__device__ float g_lab_sink[1024];
+#endif
+
+// IMS: 32-pixel blocks per wave (4: 256-row tile, 3: 192-row tile)
+template <bool EP, bool STATS, bool KXK = false, int IMS = 4>
 __global__ __launch_bounds__(GL_THREADS, 2) void conv_gemm_glds_kernel(const ConvGemmArgs a) {
   typedef bf16_t T;
   constexpr int VEC = 8;
@@ -24,7 +52,7 @@ __global__ __launch_bounds__(GL_THREADS, 2) void conv_gemm_glds_kernel(const Con
   const int wm = wave >> 2, wn = wave & 3;
   const int L = xcd_remap(blockIdx.x, a.tiles_m * a.tiles_n);
   const int tile_m = L / a.tiles_n, tile_n = L - tile_m * a.tiles_n;
-  const int m0 = tile_m * GL_BM, n0 = tile_n * GL_BN;
+  const int m0 = tile_m * (64 * IMS), n0 = tile_n * GL_BN;
 
   GemmOperand A, B;
   A.base = reinterpret_cast<const unsigned char*>(a.x);
@@ -34,13 +62,13 @@ __global__ __launch_bounds__(GL_THREADS, 2) void conv_gemm_glds_kernel(const Con
   B.ld_bytes = (long)a.K * 2;
   B.rows = a.O;
 
-  f32x16 acc[2][4];  // (the ring starts from a constant-zero accumulator INPUT)
+  f32x16 acc[2][IMS];  // (the ring starts from a constant-zero accumulator INPUT)
 
   if (KXK) {
     const GlConvA cg = {a.M, a.Hi, a.Wi, a.Ho, a.Wo, a.KW, a.pad, a.dil, a.C / 32};
-    gl_mainloop_ring<true>(A, B, a.K, m0, n0, lds, acc, &cg);
+    gl_mainloop_ring<true, IMS>(A, B, a.K, m0, n0, lds, acc, &cg);
   } else {
-    gl_mainloop_ring<false>(A, B, a.K, m0, n0, lds, acc);
+    gl_mainloop_ring<false, IMS>(A, B, a.K, m0, n0, lds, acc);
   }
 
   // ---- epilogue, per wave and 32-pixel tile: channel groups -> LDS patch [32 px][64 ch] ->
@@ -62,7 +90,7 @@ __global__ __launch_bounds__(GL_THREADS, 2) void conv_gemm_glds_kernel(const Con
     load_params<VEC>(a.ep_c1, o, c1v);
   }
 #pragma unroll
-  for (int im = 0; im < 4; ++im) {
+  for (int im = 0; im < IMS; ++im) {
 #pragma unroll
     for (int jn = 0; jn < 2; ++jn) {
 #pragma unroll
@@ -88,7 +116,7 @@ __global__ __launch_bounds__(GL_THREADS, 2) void conv_gemm_glds_kernel(const Con
       const int r = (q * 64 + lane) / VPR;
       val[q] = *reinterpret_cast<const uint4*>(ep + r * EP_STRIDE + v * 16);
       if (EP) {
-        const int p = m0 + wm * 128 + im * 32 + r;
+        const int p = m0 + wm * 32 * IMS + im * 32 + r;
         const long pc = p < a.M ? p : a.M - 1;
         xr[q] = ldg16(reinterpret_cast<const T*>(a.ep_x) + pc * a.ldep + (epc ? o : 0));
       }
@@ -96,7 +124,7 @@ __global__ __launch_bounds__(GL_THREADS, 2) void conv_gemm_glds_kernel(const Con
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       const int r = (q * 64 + lane) / VPR;
-      const int p = m0 + wm * 128 + im * 32 + r;
+      const int p = m0 + wm * 32 * IMS + im * 32 + r;
       if (STATS) {  // rows beyond M are exact zeros
         float f[VEC];
         Vec<T>::unpack(val[q], f);
@@ -145,10 +173,58 @@ __global__ __launch_bounds__(GL_THREADS, 2) void conv_gemm_glds_kernel(const Con
       const int oc = n0 + tid;
       if (oc < a.O) {
         float* dst = a.stat_partial + (long)tile_m * 2 * a.O;
+#if defined(LAB_TICKET) && LAB_TICKET == 2  // write-through (sc1) rows instead of a release fence
+        __hip_atomic_store(dst + oc, red[0 * 256 + tid] + red[2 * 256 + tid], __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(dst + a.O + oc, red[1 * 256 + tid] + red[3 * 256 + tid],
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
         dst[oc] = red[0 * 256 + tid] + red[2 * 256 + tid];
         dst[a.O + oc] = red[1 * 256 + tid] + red[3 * 256 + tid];
+#endif
       }
     }
+#ifdef LAB_TICKET
+    // LAB ONLY (tools/lab builds, never the product library): the cost of a last-arriver
+    // BatchNorm finalize behind this kernel — one agent-scope release + ticket per block, and in
+    // the last block of a column tile an acquire + the fixed-order re-read of that tile's
+    // statistic rows (profiles/r05_last_arriver.md)
+    {
+      int* s_last = reinterpret_cast<int*>(smem_raw + 8192);  // (inside the idle ring: a second
+      __syncthreads();                                        //  __shared__ object would cost the
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       //  main loop a vmcnt(0) per k-step)
+      __syncthreads();
+      if (tid == 0) {
+#if LAB_TICKET != 2
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        const unsigned t = __hip_atomic_fetch_add(&g_lab_ticket[tile_n & 63], 1u, __ATOMIC_RELAXED,
+                                                  __HIP_MEMORY_SCOPE_AGENT);
+        *s_last = (t % (unsigned)a.tiles_m) == (unsigned)a.tiles_m - 1u;
+#if LAB_TICKET != 2
+        if (*s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
+      }
+      __syncthreads();
+      if (*s_last) {
+        const int cols = min(256, a.O - n0);
+        for (int e = tid; e < cols * 2; e += GL_THREADS) {
+          const int sub = e / cols, c = e - sub * cols;
+          float tot = 0.f;
+          for (int r = 0; r < a.tiles_m; ++r) {
+#if LAB_TICKET == 2
+            tot += __hip_atomic_load(a.stat_partial + ((long)r * 2 + sub) * a.O + n0 + c,
+                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+            tot += a.stat_partial[((long)r * 2 + sub) * a.O + n0 + c];
+#endif
+          }
+          g_lab_sink[e & 1023] = tot;
+        }
+      }
+    }
+#endif
   }
 }
 
@@ -158,11 +234,38 @@ bool conv_gemm_glds_usable(int dtype, const ConvGemmArgs& a) {
          (a.ldy % 8) == 0;
 }
 
-template <bool EP, bool STATS>
+// ---- tile-row choice.  One launch = ceil(tiles / 256) rounds of (fixed cost + rows) on the
+// 256 CUs (one 128 KiB block per CU): the row count with the smallest product wins; on a tie the
+// larger tile (less operand traffic per output).  GLDS_FIXED_ROWS: launch + first DMA round trip
+// + epilogue in units of tile rows; with 96 the rule picks the faster row count on 11 of the 12
+// shapes of tools/lab/gemm_ab (the twelfth, 304 -> 256 @263682 pixels, 5 vs 6 rounds, by 3 %).
+constexpr int GLDS_FIXED_ROWS = 96;
+
+int glds_rows_per_tile(long M, int O) {
+  const long tn = (O + GL_BN - 1) / GL_BN;
+  int best = 256;
+  long best_cost = -1;
+  for (int bm = 256; bm >= 192; bm -= 64) {
+    const long tiles = ((M + bm - 1) / bm) * tn;
+    const long cost = ((tiles + 255) / 256) * (bm + GLDS_FIXED_ROWS);
+    if (best_cost < 0 || cost < best_cost) {
+      best_cost = cost;
+      best = bm;
+    }
+  }
+  return best;
+}
+
+int glds_tiles_m(long M, int O) {
+  const int bm = glds_rows_per_tile(M, O);
+  return (int)((M + bm - 1) / bm);
+}
+
+template <bool EP, bool STATS, bool KXK, int IMS>
 static int launch_glds_inst(const ConvGemmArgs& a, hipStream_t stream) {
   static const int once = [] {
     return (int)hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&conv_gemm_glds_kernel<EP, STATS>),
+        reinterpret_cast<const void*>(&conv_gemm_glds_kernel<EP, STATS, KXK, IMS>),
         hipFuncAttributeMaxDynamicSharedMemorySize, GL_LDS_BYTES);
   }();
   if (once != 0) {
@@ -170,20 +273,27 @@ static int launch_glds_inst(const ConvGemmArgs& a, hipStream_t stream) {
     return 2;
   }
   const dim3 grid(a.tiles_m * a.tiles_n), block(GL_THREADS);
-  hipLaunchKernelGGL((conv_gemm_glds_kernel<EP, STATS>), grid, block, GL_LDS_BYTES,
+  hipLaunchKernelGGL((conv_gemm_glds_kernel<EP, STATS, KXK, IMS>), grid, block, GL_LDS_BYTES,
                      stream, a);
-  return check_launch("conv_gemm_fwd (glds)");
+  return check_launch(KXK ? "conv_gemm_fwd (glds KxK)" : "conv_gemm_fwd (glds)");
+}
+
+template <bool EP, bool STATS, bool KXK>
+static int launch_glds_rows(ConvGemmArgs a, hipStream_t stream) {
+  const int bm = glds_rows_per_tile(a.M, a.O);
+  a.tiles_m = (a.M + bm - 1) / bm;
+  a.tiles_n = (a.O + GL_BN - 1) / GL_BN;
+  if (bm == 256) return launch_glds_inst<EP, STATS, KXK, 4>(a, stream);
+  return launch_glds_inst<EP, STATS, KXK, 3>(a, stream);
 }
 
 int launch_conv_gemm_glds(ConvGemmArgs a, hipStream_t stream) {
-  a.tiles_m = px256_tiles_m(a.M);  // 256-pixel tiles: same statistics rows as the px256 kernel
-  a.tiles_n = (a.O + GL_BN - 1) / GL_BN;
   // (forward convs take statistics, data gradients the folded-BN correction; never both)
   if (a.ep_x != nullptr && a.stat_partial != nullptr)
-    return launch_glds_inst<true, true>(a, stream);
-  if (a.ep_x != nullptr) return launch_glds_inst<true, false>(a, stream);
-  if (a.stat_partial != nullptr) return launch_glds_inst<false, true>(a, stream);
-  return launch_glds_inst<false, false>(a, stream);
+    return launch_glds_rows<true, true, false>(a, stream);
+  if (a.ep_x != nullptr) return launch_glds_rows<true, false, false>(a, stream);
+  if (a.stat_partial != nullptr) return launch_glds_rows<false, true, false>(a, stream);
+  return launch_glds_rows<false, false, false>(a, stream);
 }
 
 // ---- stride-1 KxK on the same pipeline
@@ -194,29 +304,9 @@ bool conv_gemm_glds_kxk_usable(int dtype, const ConvGemmArgs& a) {
          (long)a.N * a.Hi * a.Wi < (1L << 31);
 }
 
-template <bool STATS>
-static int launch_glds_kxk_inst(const ConvGemmArgs& a, hipStream_t stream) {
-  static const int once = [] {
-    return (int)hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&conv_gemm_glds_kernel<false, STATS, true>),
-        hipFuncAttributeMaxDynamicSharedMemorySize, GL_LDS_BYTES);
-  }();
-  if (once != 0) {
-    set_error("conv_gemm_glds (KxK): cannot reserve %d bytes of LDS", GL_LDS_BYTES);
-    return 2;
-  }
-  const dim3 grid(a.tiles_m * a.tiles_n), block(GL_THREADS);
-  hipLaunchKernelGGL((conv_gemm_glds_kernel<false, STATS, true>), grid, block, GL_LDS_BYTES,
-                     stream, a);
-  return check_launch("conv_gemm_fwd (glds KxK)");
-}
-
 int launch_conv_gemm_glds_kxk(ConvGemmArgs a, hipStream_t stream) {
-  a.tiles_m = px256_tiles_m(a.M);
-  a.tiles_n = (a.O + GL_BN - 1) / GL_BN;
-  if (a.stat_partial != nullptr) return launch_glds_kxk_inst<true>(a, stream);
-  return launch_glds_kxk_inst<false>(a, stream);
+  if (a.stat_partial != nullptr) return launch_glds_rows<false, true, true>(a, stream);
+  return launch_glds_rows<false, false, true>(a, stream);
 }
-
 
 }  // namespace seg

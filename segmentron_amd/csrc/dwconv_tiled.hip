@@ -24,6 +24,7 @@ constexpr int LT_TH = 8, LT_TW = 16, LT_CVB = 8, LT_THREADS = 256;
 #ifndef DW_BWD_OCC
 #define DW_BWD_OCC 2
 #endif
+constexpr int DW_BWD_REM_PCT = 6;
 
 struct DwTiledArgs {
   const void* x;       // tensor the taps read (fwd: input, dgrad: dy)
@@ -47,6 +48,46 @@ struct DwTiledArgs {
   // 81 of which 17 compute one valid row or column.
   int ntiles_a, nb, nc, hb0, wc0, hc;
 };
+
+#ifdef LAB_TICKET
+__device__ unsigned g_lab_ticket[64];
+__device__ float g_lab_sink[4096];
+// rows x (nsub sub-rows of `cols` columns at pitch sub_pitch) floats at `base` (row pitch
+// row_pitch): every block arrives; the last one re-reads everything in fixed order
+__device__ __forceinline__ void lab_last_arriver(const float* base, long row_pitch, int rows, int cols,
+                                                 int nsub, long sub_pitch, unsigned* ticket,
+                                                 int expected) {
+  __shared__ int s_last;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#if LAB_TICKET != 2
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = (t % (unsigned)expected) == (unsigned)expected - 1u;
+#if LAB_TICKET != 2
+    if (s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
+  }
+  __syncthreads();
+  if (!s_last) return;
+  for (int e = threadIdx.x; e < cols * nsub; e += blockDim.x) {
+    const int sub = e / cols, c = e - sub * cols;
+    float tot = 0.f;
+    for (int r = 0; r < rows; ++r) {
+#if LAB_TICKET == 2
+      tot += __hip_atomic_load(base + (long)r * row_pitch + sub * sub_pitch + c, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+#else
+      tot += base[(long)r * row_pitch + sub * sub_pitch + c];
+#endif
+    }
+    g_lab_sink[e & 4095] = tot;
+  }
+}
+#endif
 
 // A tile is TH x TW output pixels (TH * TW / 4 = 32 strips of four for the 32 pixel threads of
 // a block).  8 x 16 everywhere, except for the REMAINDER tiles of the r05 tiling (see DwRem).
@@ -446,8 +487,21 @@ __global__ __launch_bounds__(LT_THREADS, sizeof(T) == 2 ? 3 : 4) void dwconv_til
       const int lcx = tid / (2 * VEC), k = tid - lcx * 2 * VEC;
       const int which = k / VEC, ci = k - which * VEC;
       const int c = (cvb0 + lcx) * VEC + ci;
+#if defined(LAB_TICKET) && LAB_TICKET == 2
+      if (c < a.C) __hip_atomic_store(a.partial + ((long)lb.y * 2 + which) * a.C + c, tot,
+                                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
       if (c < a.C) a.partial[((long)lb.y * 2 + which) * a.C + c] = tot;
+#endif
     }
+#ifdef LAB_TICKET
+    // LAB ONLY (tools/lab, never in the product build): what a last-arriver finalize would add to
+    // this kernel — per block one agent-scope release + ticket, and for the last block of a
+    // channel block an acquire + the fixed-order reduction of that block's partial rows
+    // (profiles/r05_last_arriver.md).
+    lab_last_arriver(a.partial + (long)cvb0 * VEC, 2 * a.C, gridDim.y, LT_CVB * VEC, 2, a.C,
+                     &g_lab_ticket[lb.x & 63], (int)gridDim.y);
+#endif
   }
 }
 
@@ -913,7 +967,9 @@ __device__ __forceinline__ void dw_bwd_edge_tile(
                             cv, xraw, sc, sh, accw, s1, s2);
 }
 
-template <typename T, int DIL, bool RES = false>
+// REM: this launch has remainder tiles (a separate instance: with their code compiled in, the
+// 8 x 16 loop of the classic tiling spilled 12 bytes and ran 3-5 % slower on the large maps)
+template <typename T, int DIL, bool RES = false, bool REM = false>
 __global__ __launch_bounds__(LT_THREADS, DW_BWD_OCC) void dwconv_bwd_tiled_kernel(const DwTiledArgs a) {
   // 4 channels per thread in both element types (8-byte bf16 vectors): this kernel carries nine
   // tap accumulators per channel on top of the data-gradient accumulators
@@ -924,9 +980,9 @@ __global__ __launch_bounds__(LT_THREADS, DW_BWD_OCC) void dwconv_bwd_tiled_kerne
   extern __shared__ uint4 lt_smem[];
   raw_t* tile = reinterpret_cast<raw_t*>(lt_smem);
   // (parameter rows behind the largest tile image of the launch, tiled_lds)
-  float4* psm = reinterpret_cast<float4*>(lt_smem + (a.nb ? TileGeomB<DIL>::TILE_VECS
-                                                       : a.nc ? TileGeomC<DIL>::TILE_VECS
-                                                              : G::TILE_VECS));
+  float4* psm = reinterpret_cast<float4*>(
+      lt_smem + (!REM ? G::TILE_VECS : a.nb ? TileGeomB<DIL>::TILE_VECS
+                                            : a.nc ? TileGeomC<DIL>::TILE_VECS : G::TILE_VECS));
   const int tid = threadIdx.x;
   const LtBlock lb = lt_block();
   const int cvb0 = lb.x * LT_CVB;
@@ -995,6 +1051,7 @@ __global__ __launch_bounds__(LT_THREADS, DW_BWD_OCC) void dwconv_bwd_tiled_kerne
                               accw, s1, s2);
   }
   // remainder tiles (t continues behind the 8 x 16 tiles with the same stride)
+  if constexpr (REM)
   for (; t < a.ntiles; t += gridDim.y) {
     int n, h0, w0, hlim;
     if (rem_coords(a, t - a.ntiles_a, n, h0, w0, hlim))
@@ -1087,12 +1144,23 @@ bool dw_tiled_supported(int stride, int dil) { return stride == 1 && (dil == 1 |
 
 // rem: the r05 tiling with remainder tiles (forward / fused backward); the weight-gradient kernel
 // keeps the classic one
-static void tiled_geom(DwTiledArgs& a, int dtype, int N, int H, int W, int C, bool rem = false) {
+// rem_pct: minimum share (percent) of the classic tile count the remainder tiles must save
+// (the fused backward: 6 — below that its pipelined 8 x 16 loop on the classic tiling wins)
+static void tiled_geom(DwTiledArgs& a, int dtype, int N, int H, int W, int C, bool rem = false,
+                       int rem_pct = 0) {
   const int vec = dtype == DT_BF16 ? 8 : 4;
   a.N = N; a.H = H; a.W = W; a.C = C; a.CV = C / vec;
   const int full_h = H / LT_TH, full_w = W / LT_TW, rb = H % LT_TH, rr = W % LT_TW;
-  const bool use_b = rem && rb > 0 && rb <= 2 && full_h > 0;
-  const bool use_c = rem && rr > 0 && rr <= 4 && full_w > 0;
+  bool use_b = rem && rb > 0 && rb <= 2 && full_h > 0;
+  bool use_c = rem && rr > 0 && rr <= 4 && full_w > 0;
+  if (use_b || use_c) {
+    const long classic = (long)((H + LT_TH - 1) / LT_TH) * ((W + LT_TW - 1) / LT_TW);
+    const int hc = use_b ? full_h * LT_TH : H;
+    const long now = (long)(use_b ? full_h : (H + LT_TH - 1) / LT_TH) *
+                         (use_c ? full_w : (W + LT_TW - 1) / LT_TW) +
+                     (use_b ? (W + 63) / 64 : 0) + (use_c ? (hc + 31) / 32 : 0);
+    if ((classic - now) * 100 < (long)rem_pct * classic) use_b = use_c = false;
+  }
   a.tiles_h = use_b ? full_h : (H + LT_TH - 1) / LT_TH;
   a.tiles_w = use_c ? full_w : (W + LT_TW - 1) / LT_TW;
   a.hb0 = full_h * LT_TH;
@@ -1112,7 +1180,7 @@ int dw_tiled_grid_y(int dtype, int C, int N, int H, int W, int kind) {
   // 1: fused backward (two resident blocks per CU, several tiles each for the tile pipeline),
   // 2: weight gradient (few partial rows: its block reduction is the expensive part)
   DwTiledArgs a;
-  tiled_geom(a, dtype, N, H, W, C, kind != 2);
+  tiled_geom(a, dtype, N, H, W, C, kind != 2, kind == 1 ? DW_BWD_REM_PCT : 0);
   const int cv = kind == 1 ? C / 4 : a.CV;  // the fused backward works on 4-channel vectors
   const int gx = (cv + LT_CVB - 1) / LT_CVB;
   // measured (tools/lab/op_time.py, [2,65,129,728] bf16): forward 768 / 1024 / 1536 / 2048
@@ -1243,7 +1311,7 @@ int launch_dw_bwd_tiled(int dtype, const void* dy, long lddy, const void* x, lon
                         const float* sc, const float* sh, void* g, long ldg, float* partial_w,
                         float* partial_bn, int grid_y, hipStream_t st, const void* res, long ldr) {
   DwTiledArgs a;
-  tiled_geom(a, dtype, N, H, W, C, true);
+  tiled_geom(a, dtype, N, H, W, C, true, DW_BWD_REM_PCT);
   a.CV = C / 4;               // HVec: 4 channels per thread in both element types
   a.w_layout = w_layout ^ 2;  // taps staged flipped (bit 1 toggles the caller's orientation)
   a.x = x; a.w = w; a.y = g; a.dy = dy; a.sc = sc; a.sh = sh;
@@ -1251,9 +1319,15 @@ int launch_dw_bwd_tiled(int dtype, const void* dy, long lddy, const void* x, lon
   a.res = res; a.ldr = ldr;
   a.ldx = ldx; a.ldy = ldg; a.lddy = lddy; a.pro_mode = pro_mode;
   const dim3 grid((a.CV + LT_CVB - 1) / LT_CVB, grid_y);
-#define SEG_LT(TT, DD, RR) \
-  hipLaunchKernelGGL((dwconv_bwd_tiled_kernel<TT, DD, RR>), grid, dim3(LT_THREADS), \
-                     tiled_lds<DD>(dtype, true, a.nb, a.nc), st, a)
+#define SEG_LT(TT, DD, RR)                                                                       \
+  do {                                                                                           \
+    if (a.nb || a.nc)                                                                            \
+      hipLaunchKernelGGL((dwconv_bwd_tiled_kernel<TT, DD, RR, true>), grid, dim3(LT_THREADS),    \
+                         tiled_lds<DD>(dtype, true, a.nb, a.nc), st, a);                         \
+    else                                                                                         \
+      hipLaunchKernelGGL((dwconv_bwd_tiled_kernel<TT, DD, RR, false>), grid, dim3(LT_THREADS),   \
+                         tiled_lds<DD>(dtype, true), st, a);                                     \
+  } while (0)
   if (res != nullptr) {  // (dilation 1 only: dw_bwd_tiled_res_supported)
     if (dtype == DT_BF16) SEG_LT(bf16_t, 1, true); else SEG_LT(float, 1, true);
   } else if (dtype == DT_BF16) { if (dil == 1) SEG_LT(bf16_t, 1, false); else SEG_LT(bf16_t, 2, false); }

@@ -908,21 +908,22 @@ class LogitsView:
 
 
 class _GapFn(torch.autograd.Function):
-    """nn.AdaptiveAvgPool2d((1,1)) of a materialised NHWC tensor -> [N,1,1,C]."""
+    """nn.AdaptiveAvgPool2d((1,1)) of a materialised NHWC tensor -> [N,1,1,C] in `out_dtype`
+    (the pooled vector of a bf16 tensor may be kept in float32, see global_avg_pool)."""
 
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, out_dtype):
         N, H, W, C = x.shape
-        ctx.meta = (H, W)
+        ctx.meta = (H, W, x.dtype)
         s = torch.stack([K.bn_bwd_reduce(x[n:n + 1], x[n:n + 1], (PRO_NONE, None, None))[:C]
                          for n in range(N)])
-        return (s / float(H * W)).to(x.dtype).view(N, 1, 1, C)
+        return (s / float(H * W)).to(out_dtype).view(N, 1, 1, C)
 
     @staticmethod
     def backward(ctx, g):
-        H, W = ctx.meta
-        gs = (g.float() / float(H * W)).to(g.dtype).contiguous()
-        return K.bilinear(gs, (H, W), None, None, True)
+        H, W, dt = ctx.meta
+        gs = (g.float() / float(H * W)).to(dt).contiguous()
+        return K.bilinear(gs, (H, W), None, None, True), None
 
 
 class PoolSpec:
@@ -954,16 +955,17 @@ class _AdaptivePoolFn(torch.autograd.Function):
     """nn.AdaptiveAvgPool2d(o) of a materialised tensor -> [N,o,o,C] (module.py:89)."""
 
     @staticmethod
-    def forward(ctx, x, o):
+    def forward(ctx, x, o, out_dtype):
         N, H, W, C = x.shape
         ctx.meta = (H, W)
+        ctx.dt = x.dtype
         sums = K.adaptive_avgpool_sums(x, o)
         areas = K.adaptive_bin_areas(H, W, o, x.device)
-        return (sums / areas.view(1, o, o, 1)).to(x.dtype)  # tiny [N,o,o,C] host-side scale+cast
+        return (sums / areas.view(1, o, o, 1)).to(out_dtype)  # tiny [N,o,o,C] host-side scale+cast
 
     @staticmethod
     def backward(ctx, g):
-        return K.adaptive_avgpool_bwd(g.contiguous(), ctx.meta), None
+        return K.adaptive_avgpool_bwd(g.to(ctx.dt).contiguous(), ctx.meta), None, None
 
 
 class _CatFn(torch.autograd.Function):
@@ -1305,8 +1307,17 @@ def logits_to_nchw(x, out_hw, align_corners=True, lazy=False):
     return _LogitsFn.apply(x, tuple(out_hw), align_corners)
 
 
-def global_avg_pool(x):
-    return _GapFn.apply(x)
+def global_avg_pool(x, keep_fp32=False):
+    """keep_fp32: the pooled [N,1,1,C] vector of a bf16 tensor stays float32 — for the ASPP image
+    pooling branch (module.py:52-64): its BatchNorm sees N samples per channel, and with N = 2
+    the normalised value is the SIGN of the difference of the two pooled features (up to eps), the
+    gradient through it a remainder of cancelling terms.  Rounded to bf16 the two features
+    differ by a few ulps or not at all: measured on the conditioned C3 step (reference under CPU
+    bf16 autocast alike, tests/golden/c3_autocast_sizes.json), the bf16 gradient of this ONE
+    convolution weight has cosine 0.45-0.57 with fp32 and carries a quarter of the whole model's
+    squared gradient error, the exit-flow weights behind it most of the rest.  The branch is two
+    rows of a GEMM: float32 costs nothing."""
+    return _GapFn.apply(x, torch.float32 if keep_fp32 else x.dtype)
 
 
 def max_pool(act, k, stride, pad):
@@ -1314,8 +1325,10 @@ def max_pool(act, k, stride, pad):
     return _MaxPoolFn.apply(act.t, g, b, PoolSpec(act, k, stride, pad))
 
 
-def adaptive_avg_pool(x, o):
-    return _AdaptivePoolFn.apply(x, o)
+def adaptive_avg_pool(x, o, keep_fp32=False):
+    """keep_fp32: as global_avg_pool — PSPNet's pyramid bins (module.py:89-97) feed BatchNorms over
+    N*o*o = 2 .. 72 samples."""
+    return _AdaptivePoolFn.apply(x, o, torch.float32 if keep_fp32 else x.dtype)
 
 
 def dropout_mask(shape, p, dtype, device):

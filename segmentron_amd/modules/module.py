@@ -66,9 +66,12 @@ class PyramidPooling(nn.Module):
         buf = torch.empty((N, H, W, C + oc * len(self.sizes)), dtype=x.dtype, device=x.device)
         parts = [F.materialize(F.Act(x), out=buf[..., :C], force=True)]
         for i, (size, conv) in enumerate(zip(self.sizes, self.convs)):
-            pooled = F.adaptive_avg_pool(x, size)
-            parts.append(F.bilinear(conv(F.Act(pooled)), (H, W),
-                                    out=buf[..., C + i * oc:C + (i + 1) * oc]))
+            # (bins, 1x1 convolution and its few-sample BatchNorm in float32 whatever the compute
+            # dtype, rounded once behind BN + ReLU: functional.global_avg_pool)
+            a = conv(F.Act(F.adaptive_avg_pool(x, size, keep_fp32=True)))
+            if x.dtype != torch.float32:
+                a = F.Act(F.materialize(a).to(x.dtype))
+            parts.append(F.bilinear(a, (H, W), out=buf[..., C + i * oc:C + (i + 1) * oc]))
         return F.Act(F.concat_alias(buf, parts))
 
 
@@ -116,9 +119,13 @@ class _ASPP(nn.Module):
         xs = F.fork(x, 5)
         buf = torch.empty((N, H, W, 5 * oc), dtype=x.dtype, device=x.device)
         # image pooling: gap -> 1x1 -> BN (statistics over the batch) -> ReLU -> broadcast
-        pooled = F.conv_bn(F.Act(F.global_avg_pool(xs[0])), self.image_pooling.conv,
-                           self.image_pooling.bn)
+        # (in float32 whatever the compute dtype — functional.global_avg_pool — and rounded ONCE,
+        # after BatchNorm + ReLU, where nothing cancels any more)
+        pooled = F.conv_bn(F.Act(F.global_avg_pool(xs[0], keep_fp32=True)),
+                           self.image_pooling.conv, self.image_pooling.bn)
         pooled.relu = True
+        if x.dtype != torch.float32:
+            pooled = F.Act(F.materialize(pooled).to(x.dtype))
         parts = [F.bilinear(pooled, (H, W), out=buf[..., 0:oc])]
         b0 = F.conv_bn(F.Act(xs[1]), self.aspp0.conv, self.aspp0.bn)
         b0.relu = True

@@ -237,7 +237,7 @@ def test_torch_custom_ops_are_registered_with_fake_implementations():
 
 
 def _g4_rows(M, O):
-    """csrc/conv_gemm_g4.hip g4_rows_per_tile: rounds on 256 CUs x (tile rows + fixed cost)."""
+    """csrc/conv_gemm_glds.hip glds_rows_per_tile: rounds on 256 CUs x (tile rows + fixed cost)."""
     best = None
     for bm in (256, 192):
         tiles = -(-M // bm) * -(-O // 256)

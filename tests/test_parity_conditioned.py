@@ -88,6 +88,15 @@ def _oracle(tag, sd, x, y=None, dtype=torch.float32, training=True):
     return outs, loss.item(), {k: v.grad for k, v in s.items() if v.grad is not None}, s
 
 
+def _autocast_yardstick(size):
+    """The oracle under torch's CPU bf16 autocast against its fp32 run at a LARGE size
+    (tests/golden/c3_autocast_sizes.json, generated by oracle/gen_autocast_sizes.py): the arg-max
+    agreement / logits distance of two bf16 pipelines on near-tie random-init logits, and the
+    gradient cosine — dominated by the 2-sample BatchNorm of the image pooling branch — do not
+    carry over from the 65x129 fixture."""
+    return json.load(open(os.path.join(GOLDEN, "c3_autocast_sizes.json")))[size]
+
+
 def _l2(a, b):
     return ((a.double() - b.double()).norm() / b.double().norm()).item()
 
@@ -300,15 +309,16 @@ def test_c3_fp32_and_bf16_train_step_513x1025_fixed_bars():
     l2t = _l2(outs[0].detach().float().cpu(), ref)
     agree = (outs[0].detach().cpu().argmax(1) == ref.argmax(1)).float().mean().item()
     st, per = _grad_stats(dict(model.named_parameters()), g64)
-    ac = _fixture("c3")["ref_autocast_bf16"]
+    ac = _autocast_yardstick("513x1025")
     print("PARITY-COND c3 bf16 513x1025 vs fp64 oracle: logits L2-rel %.3e argmax %.4f loss %.5f vs "
-          "%.5f | gradients global rel %.3e cosine %.5f ratio %.4f"
-          % (l2t, agree, loss.item(), l64, st["global_rel"], st["cos"], st["ratio"]))
-    # (yardstick: the larger of the reference-autocast's eval / train distances at 65x129)
-    assert l2t <= max(2e-2, 1.5 * max(ac[0], ac[2])) and agree >= ac[1] - 0.03
+          "%.5f | gradients global rel %.3e cosine %.5f ratio %.4f || the oracle under CPU bf16 "
+          "autocast at this size: logits %.3e argmax %.4f cosine %.5f ratio %.4f"
+          % (l2t, agree, loss.item(), l64, st["global_rel"], st["cos"], st["ratio"],
+             ac["logits_l2rel"], ac["argmax_agree"], ac["grad_cosine"], ac["grad_norm_ratio"]))
+    assert l2t <= max(2e-2, 1.5 * ac["logits_l2rel"]) and agree >= ac["argmax_agree"] - 0.03
     assert abs(loss.item() - l64) <= 1e-2 * l64
-    assert st["cos"] >= min(0.99, ac[4]) - 0.03
-    assert abs(st["ratio"] - 1.0) <= max(0.10, 1.5 * abs(ac[5] - 1.0))
+    assert st["cos"] >= min(0.99, ac["grad_cosine"]) - 0.03
+    assert abs(st["ratio"] - 1.0) <= max(0.10, 1.5 * abs(ac["grad_norm_ratio"] - 1.0))
 
 
 @pytest.mark.gpu
@@ -328,22 +338,28 @@ def test_c3_train_full_size_1025x2049_matches_oracle():
     _build_hip("c3", torch.float32, True)  # (sets cfg; OP.hip_step builds its own models)
     f32 = OP.compare(OP.hip_step("fp32", sd, x, y), ref)
     b16 = OP.compare(OP.hip_step("bf16", sd, x, y), ref)
-    ac = _fixture("c3")["ref_autocast_bf16"]
+    ac = _autocast_yardstick("1025x2049")
     print("PARITY-COND c3 FULL SIZE 1025x2049 B=2 vs CPU fp32 oracle (%.0f s): fp32 loss rel %.2e "
           "logits max-rel %.2e gradients global rel %.2e cosine %.7f | bf16 loss rel %.2e logits "
-          "L2-rel %.3e argmax %.4f gradients cosine %.5f ratio %.4f (reference autocast @65x129: "
-          "cosine %.5f ratio %.4f)"
+          "L2-rel %.3e argmax %.4f gradients cosine %.5f ratio %.4f || the oracle under CPU bf16 "
+          "autocast at this size: logits %.3e argmax %.4f cosine %.5f ratio %.4f"
           % (ref["seconds"], f32["loss_rel"], f32["logits_maxrel"], f32["grad_global_rel"],
              f32["grad_cosine"], b16["loss_rel"], b16["logits_l2rel"], b16["argmax_agree"],
-             b16["grad_cosine"], b16["grad_norm_ratio"], ac[4], ac[5]))
+             b16["grad_cosine"], b16["grad_norm_ratio"], ac["logits_l2rel"], ac["argmax_agree"],
+             ac["grad_cosine"], ac["grad_norm_ratio"]))
+    for tag, c in (("fp32", f32), ("bf16", b16)):
+        print("PARITY-COND c3 FULL SIZE %s gradient error shares: %s" % (tag, "; ".join(
+            "%s %.0f%% (cosine %.3f)" % (t["tensor"], 100 * t["share_of_sq_error"], t["cosine"])
+            for t in c["grad_error_top"][:5])))
     assert f32["finite"] and b16["finite"]
     assert f32["grad_tensors_missing"] == 0 and b16["grad_tensors_missing"] == 0
     assert f32["loss_rel"] < 1e-3 and f32["logits_maxrel"] < 1e-3
     assert f32["grad_global_rel"] <= FULL_SIZE_GRAD_BAR_FP32
     assert b16["loss_rel"] <= 1e-2
-    assert b16["logits_l2rel"] <= max(2e-2, 1.5 * max(ac[0], ac[2])) and b16["argmax_agree"] >= ac[1] - 0.03
-    assert b16["grad_cosine"] >= min(0.99, ac[4]) - 0.03
-    assert abs(b16["grad_norm_ratio"] - 1.0) <= max(0.10, 1.5 * abs(ac[5] - 1.0))
+    assert b16["logits_l2rel"] <= max(2e-2, 1.5 * ac["logits_l2rel"])
+    assert b16["argmax_agree"] >= ac["argmax_agree"] - 0.03
+    assert b16["grad_cosine"] >= min(0.99, ac["grad_cosine"]) - 0.03
+    assert abs(b16["grad_norm_ratio"] - 1.0) <= max(0.10, 1.5 * abs(ac["grad_norm_ratio"] - 1.0))
 
 
 # north_star's 1e-3 (against the fp32 CPU oracle, which itself sits FULL_SIZE_ORACLE_FP32_VS_FP64

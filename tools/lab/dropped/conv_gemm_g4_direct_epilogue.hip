@@ -9,14 +9,14 @@
 //
 // Epilogue.  v_mfma_f32_32x32x16_bf16 with the weights as the row operand leaves lane
 // (px = lane & 31, hh = lane >> 5) with channels 8g + 4hh .. +3 (g = 0..3) of pixel px for every
-// 32-channel block.  For the pair (g = 2t, 2t+1) one v_permlane32_swap per register (upper half
-// of X <-> lower half of Y) gives every lane 8 CONSECUTIVE channels of its pixel, 16t + 8hh .. +7:
-// one 16-byte NHWC store per lane and pair, no LDS patch and no LDS round trip between the
-// accumulators and the stores (r02-r04: 8-byte pieces -> LDS patch -> 16-byte vectors, ~7 us of
-// a 30 us launch; the data-gradient variant also rounded twice there — up to 50 bf16 ulps of
-// error where the correction cancels the accumulator, tools/lab/gemm_ab).  The statistics are
-// lane-local sums over the wave's pixel blocks; the two column blocks of a wave are folded with
-// one v_permlane16_swap per pair of values, the 16 pixel lanes of a row with four DPP adds.
+// 32-channel block.  Two register-exchange stages (v_permlane32_swap, then v_permlane16_swap; one
+// instruction per register, no LDS) regroup a block so that four lanes hold the four consecutive
+// 8-channel vectors of one pixel: 16-byte NHWC stores, 64 contiguous bytes per pixel and
+// instruction, no LDS patch and no LDS round trip between the accumulators and the stores
+// (r02-r04: 8-byte pieces -> LDS patch -> 16-byte vectors, ~7 us of a 30 us launch; the
+// data-gradient variant also rounded twice there — up to 50 bf16 ulps of error where the
+// correction cancels the accumulator, tools/lab/gemm_ab).  The statistics are lane-local sums
+// over the wave's pixel blocks, folded over the 16 pixel lanes of a row with four DPP adds.
 //
 // Tried and dropped in r05 (profiles/r05_gemm_ab.md): the same kernel on v_mfma_f32_16x16x32_bf16
 // with lane-linear fragment reads and 224-row tiles (gemm_g4 16x16 variant) — its epilogue was
@@ -52,19 +52,49 @@ __device__ __forceinline__ void g4_swap32(uint32_t& x, uint32_t& y) {
   y = r[1];
 }
 
-// u, w: the same statistic of column blocks 0 and 1.  Returns, in 16-lane rows of even parity
-// (lanes 0-15, 32-47) u summed over the two rows of its half-wave, in rows of odd parity w — and
-// every lane of a row then gets the row total (quad_perm x2, row_half_mirror, row_mirror).
-__device__ __forceinline__ float g4_fold(float u, float w) {
-  uint32_t a = __float_as_uint(u), b = __float_as_uint(w);
-  const auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
-  float v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-  v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0xB1, 0xF, 0xF, true));
-  v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x4E, 0xF, 0xF, true));
-  v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x141, 0xF, 0xF, true));
-  v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x140, 0xF, 0xF, true));
+__device__ __forceinline__ void g4_swap16(uint32_t& x, uint32_t& y) {
+  const auto r = __builtin_amdgcn_permlane16_swap(x, y, false, false);
+  x = r[0];
+  y = r[1];
+}
+
+// sum over the 16 lanes of a DPP row (every lane of the row ends up with the total)
+__device__ __forceinline__ float g4_row_sum(float v) {
+  v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0xB1, 0xF, 0xF, true));  // quad_perm [1,0,3,2]
+  v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x4E, 0xF, 0xF, true));  // quad_perm [2,3,0,1]
+  v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x141, 0xF, 0xF, true)); // row_half_mirror
+  v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x140, 0xF, 0xF, true)); // row_mirror
   return v;
 }
+
+#ifdef LAB_TICKET
+__device__ unsigned g_lab_g4_ticket[64];
+__device__ float g_lab_g4_sink[1024];
+__device__ __forceinline__ void lab_g4_last_arriver(const float* base, long row_pitch, int rows,
+                                                    int cols, long sub_pitch, unsigned* ticket,
+                                                    int expected) {
+  // (the flag lives in the ring's LDS, free by now: a second __shared__ object would cost the
+  // main loop a vmcnt(0) per k-step — cdna_hip_programming.md)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  int* s_last = reinterpret_cast<int*>(smem_raw + 8192);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *s_last = (t % (unsigned)expected) == (unsigned)expected - 1u;
+    if (*s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+  __syncthreads();
+  if (!*s_last) return;
+  for (int e = threadIdx.x; e < cols * 2; e += blockDim.x) {
+    const int sub = e / cols, c = e - sub * cols;
+    float tot = 0.f;
+    for (int r = 0; r < rows; ++r) tot += base[(long)r * row_pitch + sub * sub_pitch + c];
+    g_lab_g4_sink[e & 1023] = tot;
+  }
+}
+#endif
 
 // IMS: 32-pixel blocks per wave (4: 256-row tile, 3: 192-row tile); EP: folded-BatchNorm backward
 // correction in the store path; STATS: BatchNorm partial sums; KXK: stride-1 KxK convolution as an
@@ -99,96 +129,112 @@ __global__ __launch_bounds__(G4_THREADS, 2) void conv_gemm_g4_kernel(const ConvG
     G4_MAINLOOP(false)(A, B, a.K, m0, n0, lds, acc);
   }
 
-  // ---- epilogue.  Lane (px, hh); vector (jn, t): channels n0 + wn*64 + jn*32 + 16t + 8hh .. +7
+  // ---- epilogue.  Stage 1 (v_permlane32_swap) gives lane (px, hh) the vectors V[t] = channels
+  // 16t + 8hh .. +7 of pixel px; stage 2 (v_permlane16_swap of V[0] with V[1]) regroups them so
+  // that the four lanes {lp, lp+16, lp+32, lp+48} hold the four consecutive vectors of ONE pixel:
+  //   P[0]: pixel lp,      P[1]: pixel 16 + lp      (lp = lane & 15, 16-lane row r = lane >> 4)
+  //   channels jn*32 + 16*(r & 1) + 8*(r >> 1) .. +7
+  // -> a store instruction writes 64 contiguous bytes per pixel.  (Measured r05, gemm_ab: with
+  // stage 1 alone — 32 contiguous bytes per pixel and instruction — the stores and above all the
+  // ep_x loads of the data-gradient variant were slower than the LDS patch they replace: 44.7
+  // vs 31.0 us on 728 -> 728.)
   T* __restrict__ Y = reinterpret_cast<T*>(a.y);
-  const int px = lane & 31, hh = lane >> 5;
-  const int o0 = n0 + wn * 64 + 8 * hh;  // + jn * 32 + t * 16
-  bool ook[2][2];                         // (O % 8 == 0: a vector is inside or outside)
-#pragma unroll
-  for (int jn = 0; jn < 2; ++jn)
-#pragma unroll
-    for (int t = 0; t < 2; ++t) ook[jn][t] = o0 + jn * 32 + t * 16 < a.O;
-  float ssum[2][2][8], ssq[2][2][8];
+  const int lp = lane & 15, r4 = lane >> 4;
+  const int o0 = n0 + wn * 64 + 16 * (r4 & 1) + 8 * (r4 >> 1);  // + jn * 32
+  const bool ook[2] = {o0 < a.O, o0 + 32 < a.O};  // (O % 8 == 0: a vector is inside or outside)
+  float ssum[2][8], ssq[2][8];
   if (STATS) {
 #pragma unroll
     for (int jn = 0; jn < 2; ++jn)
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int k = 0; k < 8; ++k) ssum[jn][t][k] = ssq[jn][t][k] = 0.f;
+      for (int k = 0; k < 8; ++k) ssum[jn][k] = ssq[jn][k] = 0.f;
   }
 #pragma unroll
   for (int jn = 0; jn < 2; ++jn) {
+    const int o = o0 + jn * 32;
+    const int oc = ook[jn] ? o : 0;
+    float c0v[8], c1v[8];
+    uint4 xr[IMS][2];
+    if (EP) {  // this column block's ep_x vectors of all pixel blocks are requested together
+      load_params<8>(a.ep_c0, oc, c0v);
+      load_params<8>(a.ep_c1, oc, c1v);
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const int o = o0 + jn * 32 + t * 16;
-      const int oc = ook[jn][t] ? o : 0;
-      float c0v[8], c1v[8];
-      uint4 xr[IMS];
-      if (EP) {  // this vector column's ep_x loads of all pixel blocks are requested together
-        load_params<8>(a.ep_c0, oc, c0v);
-        load_params<8>(a.ep_c1, oc, c1v);
+      for (int im = 0; im < IMS; ++im)
 #pragma unroll
-        for (int im = 0; im < IMS; ++im) {
-          const int p = m0 + (wm * IMS + im) * 32 + px;
+        for (int u = 0; u < 2; ++u) {
+          const int p = m0 + (wm * IMS + im) * 32 + 16 * u + lp;
           const long pc = p < a.M ? p : a.M - 1;
-          xr[im] = ldg16(reinterpret_cast<const T*>(a.ep_x) + pc * a.ldep + oc);
+          xr[im][u] = ldg16(reinterpret_cast<const T*>(a.ep_x) + pc * a.ldep + oc);
         }
-      }
+    }
 #pragma unroll
-      for (int im = 0; im < IMS; ++im) {
-        const int p = m0 + (wm * IMS + im) * 32 + px;
-        uint4 val;
-        if (EP) {  // swap in fp32, correct, round ONCE
-          float f[8], xv[8];
+    for (int im = 0; im < IMS; ++im) {
+      uint4 val[2];
+      if (EP) {  // both swap stages in fp32, correct, round ONCE
+        uint32_t v[2][8];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
-            uint32_t x = __float_as_uint(acc[jn][im][8 * t + k]);
-            uint32_t y = __float_as_uint(acc[jn][im][8 * t + 4 + k]);
-            g4_swap32(x, y);
-            f[k] = __uint_as_float(x);
-            f[4 + k] = __uint_as_float(y);
+            v[t][k] = __float_as_uint(acc[jn][im][8 * t + k]);
+            v[t][4 + k] = __float_as_uint(acc[jn][im][8 * t + 4 + k]);
+            g4_swap32(v[t][k], v[t][4 + k]);
           }
-          Vec<T>::unpack(xr[im], xv);
 #pragma unroll
-          for (int k = 0; k < 8; ++k) f[k] = f[k] - c0v[k] - c1v[k] * xv[k];
-          val = Vec<T>::pack(f);
-        } else {
-          uint32_t x01 = pack_bf16x2(acc[jn][im][8 * t + 0], acc[jn][im][8 * t + 1]);
-          uint32_t x23 = pack_bf16x2(acc[jn][im][8 * t + 2], acc[jn][im][8 * t + 3]);
-          uint32_t y01 = pack_bf16x2(acc[jn][im][8 * t + 4], acc[jn][im][8 * t + 5]);
-          uint32_t y23 = pack_bf16x2(acc[jn][im][8 * t + 6], acc[jn][im][8 * t + 7]);
-          g4_swap32(x01, y01);
-          g4_swap32(x23, y23);
-          val = make_uint4(x01, x23, y01, y23);
+        for (int k = 0; k < 8; ++k) g4_swap16(v[0][k], v[1][k]);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          float f[8], xv[8];
+          Vec<T>::unpack(xr[im][u], xv);
+#pragma unroll
+          for (int k = 0; k < 8; ++k)
+            f[k] = __uint_as_float(v[u][k]) - c0v[k] - c1v[k] * xv[k];
+          val[u] = Vec<T>::pack(f);
         }
+      } else {
+        uint32_t v[2][4];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          v[t][0] = pack_bf16x2(acc[jn][im][8 * t + 0], acc[jn][im][8 * t + 1]);
+          v[t][1] = pack_bf16x2(acc[jn][im][8 * t + 2], acc[jn][im][8 * t + 3]);
+          v[t][2] = pack_bf16x2(acc[jn][im][8 * t + 4], acc[jn][im][8 * t + 5]);
+          v[t][3] = pack_bf16x2(acc[jn][im][8 * t + 6], acc[jn][im][8 * t + 7]);
+          g4_swap32(v[t][0], v[t][2]);
+          g4_swap32(v[t][1], v[t][3]);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) g4_swap16(v[0][k], v[1][k]);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) val[u] = make_uint4(v[u][0], v[u][1], v[u][2], v[u][3]);
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int p = m0 + (wm * IMS + im) * 32 + 16 * u + lp;
         if (STATS) {  // of the values as stored; rows beyond M are exact zeros
           float f[8];
-          Vec<T>::unpack(val, f);
+          Vec<T>::unpack(val[u], f);
 #pragma unroll
           for (int k = 0; k < 8; ++k) {
-            ssum[jn][t][k] += f[k];
-            ssq[jn][t][k] = fmaf(f[k], f[k], ssq[jn][t][k]);
+            ssum[jn][k] += f[k];
+            ssq[jn][k] = fmaf(f[k], f[k], ssq[jn][k]);
           }
         }
-        if (p < a.M && ook[jn][t]) stg16(Y + (long)p * a.ldy + o, val);
+        if (p < a.M && ook[jn]) stg16(Y + (long)p * a.ldy + o, val[u]);
       }
     }
   }
   if (STATS) {
-    // fold: column blocks jn = 0 / 1 into 16-lane rows of even / odd parity, then the 16 lanes;
-    // the two row halves (wm) through LDS: red[wm][2][256] (the ring is idle: every wave passed
-    // the main loop's closing barrier)
+    // the 16 pixel lanes of a row by four DPP adds per value; the two row halves (wm) through
+    // LDS: red[wm][2][256] (the ring is idle: every wave passed the main loop's closing barrier)
     float* red = reinterpret_cast<float*>(smem_raw);
-    const int jrow = (lane >> 4) & 1;
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int jn = 0; jn < 2; ++jn)
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        const float s = g4_fold(ssum[0][t][k], ssum[1][t][k]);
-        const float q = g4_fold(ssq[0][t][k], ssq[1][t][k]);
-        if ((lane & 15) == 0) {
-          const int cl = wn * 64 + jrow * 32 + t * 16 + 8 * hh + k;
+        const float s = g4_row_sum(ssum[jn][k]);
+        const float q = g4_row_sum(ssq[jn][k]);
+        if (lp == 0) {
+          const int cl = o0 - n0 + jn * 32 + k;
           red[(wm * 2 + 0) * 256 + cl] = s;
           red[(wm * 2 + 1) * 256 + cl] = q;
         }
@@ -202,6 +248,12 @@ __global__ __launch_bounds__(G4_THREADS, 2) void conv_gemm_g4_kernel(const ConvG
         dst[a.O + oc] = red[1 * 256 + tid] + red[3 * 256 + tid];
       }
     }
+#ifdef LAB_TICKET
+    // LAB ONLY: the cost of a last-arriver BatchNorm finalize behind this kernel (one release +
+    // ticket per block; the last block of a column tile re-reads that tile's statistic rows)
+    lab_g4_last_arriver(a.stat_partial + n0, 2 * a.O, a.tiles_m, min(256, a.O - n0), a.O,
+                        &g_lab_g4_ticket[tile_n & 63], a.tiles_m);
+#endif
   }
 }
 

@@ -15,6 +15,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <vector>
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
@@ -133,6 +134,35 @@ int main(int argc, char** argv) {
     }
     (void)hipFree(x); (void)hipFree(dy); (void)hipFree(w); (void)hipFree(sc); (void)hipFree(shf);
     for (int k = 0; k < 2; ++k) { (void)hipFree(y[k]); (void)hipFree(g[k]); }
+  }
+  // optional sweep (argv[3..] = forced partial-row counts): the candidate's forward and fused
+  // backward on [2,65,129,728] with the persistent-block count of the caller's choice
+  if (argc > 3) {
+    const int N = 2, H = 65, W = 129, C = 728; const long elems = (long)N * H * W * C;
+    void *x, *dy, *y, *g; float *w, *sc, *shf, *sp, *pw, *pb;
+    CK(hipMalloc(&x, elems * 2)); CK(hipMalloc(&dy, elems * 2)); CK(hipMalloc(&y, elems * 2)); CK(hipMalloc(&g, elems * 2));
+    CK(hipMalloc(&w, 9 * C * 4)); CK(hipMalloc(&sc, C * 4)); CK(hipMalloc(&shf, C * 4));
+    CK(hipMalloc(&sp, 4096l * 2 * C * 4)); CK(hipMalloc(&pw, 4096l * 9 * C * 4)); CK(hipMalloc(&pb, 4096l * 2 * C * 4));
+    hipLaunchKernelGGL(fill_bf16, dim3((elems / 2 + 255) / 256), dim3(256), 0, 0, (uint32_t*)x, elems / 2, 1u);
+    hipLaunchKernelGGL(fill_bf16, dim3((elems / 2 + 255) / 256), dim3(256), 0, 0, (uint32_t*)dy, elems / 2, 77u);
+    CK(hipMemset(w, 0, 9 * C * 4)); CK(hipMemset(sc, 0, C * 4)); CK(hipMemset(shf, 0, C * 4));
+    printf("grid sweep on [2,65,129,728] (candidate; its own choice: fwd %d, bwd %d rows)\n",
+           L[1].grid(DT_BF16, C, N, H, W, 1, 1, 0), L[1].grid(DT_BF16, C, N, H, W, 1, 1, 1));
+    for (int ai = 3; ai < argc; ++ai) {
+      const int gy = atoi(argv[ai]);
+      if (gy < 1 || gy > 4096) continue;
+      float us2[2];
+      for (int which = 0; which < 2; ++which) {
+        auto run = [&] { return which ? L[1].bwd(DT_BF16, dy, C, x, C, N, H, W, C, w, 0, 1, PRO_AFFINE_RELU, sc, shf, g, C, pw, pb, gy, nullptr)
+                                      : L[1].dw(DT_BF16, 0, x, C, N, H, W, C, w, 0, 1, 1, PRO_AFFINE_RELU, sc, shf, y, C, H, W, sp, gy, nullptr); };
+        for (int i = 0; i < 3; ++i) if (run()) { printf("  %s\n", L[1].err()); return 1; }
+        CK(hipDeviceSynchronize()); CK(hipEventRecord(e0));
+        for (int i = 0; i < 30; ++i) run();
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1)); us2[which] = ms * 1e3f / 30;
+      }
+      printf("  rows %4d: fwd %7.2f us  fused bwd %7.2f us\n", gy, us2[0], us2[1]);
+    }
   }
   printf("per-step estimate (launch counts of C3, 2/3 of the launches with the affine prologue): forward %.2f -> %.2f ms, fused backward %.2f -> %.2f ms\n",
          tot[0][0] / 1e3, tot[1][0] / 1e3, tot[0][1] / 1e3, tot[1][1] / 1e3);

@@ -12,12 +12,20 @@ import os
 import sys
 
 
+def _is_kxk(name):
+    """conv_gemm_glds_kernel<EP, STATS, KXK, IMS>: third template argument"""
+    args = name[name.find("<") + 1:name.rfind(">")].replace(" ", "").split(",")
+    return len(args) >= 3 and args[2] in ("true", "1")
+
+
 def main(path):
     rows = list(csv.DictReader(open(path)))
     steps = sum(int(r["Calls"]) for r in rows if "ce_fwd_kernel" in r["Name"])
     if steps == 0:
         sys.exit("no ce_fwd_kernel launches in %s" % path)
-    glds = [r for r in rows if "conv_gemm_glds_kernel" in r["Name"]]
+    # the direct-to-LDS 1x1 GEMM (its KxK instances excluded: bench.py counts the FLOPs of the
+    # 1x1 launches it times)
+    glds = [r for r in rows if "conv_gemm_glds_kernel" in r["Name"] and not _is_kxk(r["Name"])]
     tot = sum(float(r["TotalDurationNs"]) for r in glds)
     calls = sum(int(r["Calls"]) for r in glds)
     out = {"source": os.path.relpath(path, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))),
