@@ -26,6 +26,9 @@ Rounding points of the HIP bf16 path (segmentron_amd/csrc):
   * BN finalize in fp64 -> fp32 scale/shift;  act(x) = relu(fma(x, scale, shift)) in fp32
   * materialise / residual add / bilinear / global pool: fp32 math, bf16 store
   * logits upsample: bf16 in, fp32 NCHW out
+  * r05: ASPP image pooling / PSP pyramid bins: pooled values, their 1x1 conv and BatchNorm in
+    float32, ONE bf16 rounding behind BN + ReLU (functional.global_avg_pool: with 2 samples per
+    channel the normalised value is the sign of a difference that bf16 storage cannot hold)
   * r04: a BatchNorm over at most 1024 samples (hip_ops.SMALL_BN_ROWS: the ASPP image-pooling
     branch, PSP's pyramid bins, every layer of a tiny test input) takes its statistics two-pass
     from the tensor AS STORED (seg_bn_finalize_small), whatever kernel produced it
@@ -153,6 +156,13 @@ class Bf16EmuNet:
         s, b = self._bn(r16(y) if (fast or kxk or direct or m_ <= SMALL_BN_ROWS) else y, bnp)
         return _A(r16(y), s, b)
 
+    def conv_f32(self, a, p, bnp):
+        """1x1 conv + training/eval BatchNorm of a float32 operand in float32 (no rounding point):
+        the few-row pooled branches since r05."""
+        y = F.conv2d(a.val(), self.sd[p + ".weight"])
+        s, b = self._bn(y, bnp)
+        return _A(y, s, b)
+
     def dw(self, a, p, bnp, stride, dil):
         c = a.t.shape[1]
         v = a.val()
@@ -213,10 +223,12 @@ class Bf16EmuNet:
         """_ASPP on a deferred c4 (segmentron_amd/modules/module.py): c4 is materialised once."""
         xm = _A(r16(c4.val()))
         H, W = xm.t.shape[2:]
-        pooled = _A(r16((xm.t.double().sum((2, 3), keepdim=True) / (H * W)).float()))
-        pa = self.conv(pooled, h + "image_pooling.conv", h + "image_pooling.bn")
+        # r05: the image-pooling branch runs in float32 (pooled vector, 1x1 conv, its N-sample
+        # BatchNorm) and is rounded once behind BN + ReLU (functional.global_avg_pool)
+        pooled = _A((xm.t.double().sum((2, 3), keepdim=True) / (H * W)).float())
+        pa = self.conv_f32(pooled, h + "image_pooling.conv", h + "image_pooling.bn")
         pa.relu = True
-        parts = [r16(pa.val().expand(-1, -1, H, W))]
+        parts = [r16(r16(pa.val()).expand(-1, -1, H, W))]
         b0 = self.conv(xm, h + "aspp0.conv", h + "aspp0.bn")
         b0.relu = True
         parts.append(r16(b0.val()))
@@ -292,10 +304,13 @@ class Bf16EmuNet:
         H, W = x.shape[2:]
         parts = [x]
         for i, o in enumerate((1, 2, 3, 6)):
-            pooled = _A(r16(F.adaptive_avg_pool2d(x.double(), o).float()))
-            a = self.conv(pooled, p + ".psp.convs.%d.conv" % i, p + ".psp.convs.%d.bn" % i)
+            # r05: bins, 1x1 conv and its few-sample BatchNorm in float32, one rounding behind
+            # BN + ReLU, then the bf16 bilinear upsample
+            pooled = _A(F.adaptive_avg_pool2d(x.double(), o).float())
+            a = self.conv_f32(pooled, p + ".psp.convs.%d.conv" % i, p + ".psp.convs.%d.bn" % i)
             a.relu = True
-            parts.append(r16(F.interpolate(a.val(), (H, W), mode="bilinear", align_corners=True)))
+            parts.append(r16(F.interpolate(r16(a.val()), (H, W), mode="bilinear",
+                                           align_corners=True)))
         return self.head_tail(_A(torch.cat(parts, 1)), p + ".block")
 
     def _hr_blocks(self, a, p):

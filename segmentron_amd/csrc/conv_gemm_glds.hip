@@ -73,7 +73,11 @@ __global__ __launch_bounds__(GL_THREADS, 2) void conv_gemm_glds_kernel(const Con
 
   // ---- epilogue, per wave and 32-pixel tile: channel groups -> LDS patch [32 px][64 ch] ->
   // 16-byte NHWC vectors (+ statistics, + folded-BatchNorm correction) -> global
-  constexpr int EP_STRIDE = 64 * (int)sizeof(T) + 16;
+  // (EP: the patch holds the fp32 accumulators — the folded-BatchNorm correction is applied to
+  // them and the result rounded ONCE.  r02-r04 parked bf16 there and rounded twice: up to 50 bf16
+  // ulps of error wherever the correction cancels the accumulator, tools/lab/gemm_ab r05.)
+  typedef typename std::conditional<EP, float, T>::type PT;
+  constexpr int EP_STRIDE = 64 * (int)sizeof(PT) + 16;
   constexpr int VPR = 64 / VEC;  // vectors per patch row
   unsigned char* ep = smem_raw + wave * 32 * EP_STRIDE;
   T* __restrict__ Y = reinterpret_cast<T*>(a.y);
@@ -99,7 +103,7 @@ __global__ __launch_bounds__(GL_THREADS, 2) void conv_gemm_glds_kernel(const Con
         float f[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) f[k] = acc[jn][im][4 * g + k];
-        HVec<T>::store(reinterpret_cast<T*>(ep + r32 * EP_STRIDE) + ch, f);
+        HVec<PT>::store(reinterpret_cast<PT*>(ep + r32 * EP_STRIDE) + ch, f);
       }
     }
     // the patch is private to this wave (in-order LDS): a compiler-level fence is enough
@@ -110,11 +114,16 @@ __global__ __launch_bounds__(GL_THREADS, 2) void conv_gemm_glds_kernel(const Con
     // per iteration, which also waits for the previous iteration's STORE to be acknowledged
     // (16 serialized write round trips per wave: 6 of the 8 us this epilogue used to take)
     constexpr int NQ = (32 * VPR) / 64;
-    uint4 val[NQ], xr[NQ];
+    uint4 val[NQ], xr[NQ], vhi[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       const int r = (q * 64 + lane) / VPR;
-      val[q] = *reinterpret_cast<const uint4*>(ep + r * EP_STRIDE + v * 16);
+      if (EP) {  // 8 fp32 = two 16-byte pieces
+        val[q] = *reinterpret_cast<const uint4*>(ep + r * EP_STRIDE + v * 32);
+        vhi[q] = *reinterpret_cast<const uint4*>(ep + r * EP_STRIDE + v * 32 + 16);
+      } else {
+        val[q] = *reinterpret_cast<const uint4*>(ep + r * EP_STRIDE + v * 16);
+      }
       if (EP) {
         const int p = m0 + wm * 32 * IMS + im * 32 + r;
         const long pc = p < a.M ? p : a.M - 1;
@@ -125,7 +134,18 @@ __global__ __launch_bounds__(GL_THREADS, 2) void conv_gemm_glds_kernel(const Con
     for (int q = 0; q < NQ; ++q) {
       const int r = (q * 64 + lane) / VPR;
       const int p = m0 + wm * 32 * IMS + im * 32 + r;
-      if (STATS) {  // rows beyond M are exact zeros
+      if (EP) {
+        float f[VEC], xv[VEC];
+        Vec<float>::unpack(val[q], f);
+        Vec<float>::unpack(vhi[q], f + 4);
+        Vec<T>::unpack(xr[q], xv);
+        if (epc) {
+#pragma unroll
+          for (int k = 0; k < VEC; ++k) f[k] = f[k] - c0v[k] - c1v[k] * xv[k];
+        }
+        val[q] = Vec<T>::pack(f);
+      }
+      if (STATS) {  // of the values as stored; rows beyond M are exact zeros
         float f[VEC];
         Vec<T>::unpack(val[q], f);
 #pragma unroll
@@ -133,14 +153,6 @@ __global__ __launch_bounds__(GL_THREADS, 2) void conv_gemm_glds_kernel(const Con
           ssum[k] += f[k];
           ssq[k] = fmaf(f[k], f[k], ssq[k]);
         }
-      }
-      if (EP && epc) {
-        float f[VEC], xv[VEC];
-        Vec<T>::unpack(val[q], f);
-        Vec<T>::unpack(xr[q], xv);
-#pragma unroll
-        for (int k = 0; k < VEC; ++k) f[k] = f[k] - c0v[k] - c1v[k] * xv[k];
-        val[q] = Vec<T>::pack(f);
       }
       // (O % 8 == 0 on this kernel — conv_gemm_glds_usable: a vector is inside or outside)
       if (p < a.M && o < a.O) stg16(Y + (long)p * a.ldy + o, val[q]);
@@ -173,7 +185,7 @@ __global__ __launch_bounds__(GL_THREADS, 2) void conv_gemm_glds_kernel(const Con
       const int oc = n0 + tid;
       if (oc < a.O) {
         float* dst = a.stat_partial + (long)tile_m * 2 * a.O;
-#if defined(LAB_TICKET) && LAB_TICKET == 2  // write-through (sc1) rows instead of a release fence
+#if defined(LAB_TICKET) && LAB_TICKET >= 2  // write-through (sc1) rows instead of a release fence
         __hip_atomic_store(dst + oc, red[0 * 256 + tid] + red[2 * 256 + tid], __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(dst + a.O + oc, red[1 * 256 + tid] + red[3 * 256 + tid],
@@ -195,25 +207,37 @@ __global__ __launch_bounds__(GL_THREADS, 2) void conv_gemm_glds_kernel(const Con
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       //  main loop a vmcnt(0) per k-step)
       __syncthreads();
       if (tid == 0) {
-#if LAB_TICKET != 2
+#if LAB_TICKET < 2
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
         const unsigned t = __hip_atomic_fetch_add(&g_lab_ticket[tile_n & 63], 1u, __ATOMIC_RELAXED,
                                                   __HIP_MEMORY_SCOPE_AGENT);
         *s_last = (t % (unsigned)a.tiles_m) == (unsigned)a.tiles_m - 1u;
-#if LAB_TICKET != 2
+#if LAB_TICKET < 2
         if (*s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 #endif
       }
       __syncthreads();
-      if (*s_last) {
+      if (*s_last && LAB_TICKET != 3) {
         const int cols = min(256, a.O - n0);
         for (int e = tid; e < cols * 2; e += GL_THREADS) {
           const int sub = e / cols, c = e - sub * cols;
           float tot = 0.f;
+#if LAB_TICKET == 4  // eight rows in flight per thread
+          for (int r0 = 0; r0 < a.tiles_m; r0 += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+              v[u] = __hip_atomic_load(a.stat_partial + ((long)min(r0 + u, a.tiles_m - 1) * 2 + sub) * a.O + n0 + c,
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) tot += (r0 + u < a.tiles_m) ? v[u] : 0.f;
+          }
+          if (false)
+#endif
           for (int r = 0; r < a.tiles_m; ++r) {
-#if LAB_TICKET == 2
+#if LAB_TICKET >= 2
             tot += __hip_atomic_load(a.stat_partial + ((long)r * 2 + sub) * a.O + n0 + c,
                                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #else

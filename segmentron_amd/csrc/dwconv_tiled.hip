@@ -61,23 +61,35 @@ __device__ __forceinline__ void lab_last_arriver(const float* base, long row_pit
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
-#if LAB_TICKET != 2
+#if LAB_TICKET < 2
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
     const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s_last = (t % (unsigned)expected) == (unsigned)expected - 1u;
-#if LAB_TICKET != 2
+#if LAB_TICKET < 2
     if (s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 #endif
   }
   __syncthreads();
-  if (!s_last) return;
+  if (!s_last || LAB_TICKET == 3) return;
   for (int e = threadIdx.x; e < cols * nsub; e += blockDim.x) {
     const int sub = e / cols, c = e - sub * cols;
     float tot = 0.f;
+#if LAB_TICKET == 4  // eight rows in flight per thread
+    for (int r0 = 0; r0 < rows; r0 += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        v[u] = __hip_atomic_load(base + (long)min(r0 + u, rows - 1) * row_pitch + sub * sub_pitch + c,
+                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) tot += (r0 + u < rows) ? v[u] : 0.f;
+    }
+    if (false)
+#endif
     for (int r = 0; r < rows; ++r) {
-#if LAB_TICKET == 2
+#if LAB_TICKET >= 2
       tot += __hip_atomic_load(base + (long)r * row_pitch + sub * sub_pitch + c, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
 #else
@@ -487,7 +499,7 @@ __global__ __launch_bounds__(LT_THREADS, sizeof(T) == 2 ? 3 : 4) void dwconv_til
       const int lcx = tid / (2 * VEC), k = tid - lcx * 2 * VEC;
       const int which = k / VEC, ci = k - which * VEC;
       const int c = (cvb0 + lcx) * VEC + ci;
-#if defined(LAB_TICKET) && LAB_TICKET == 2
+#if defined(LAB_TICKET) && LAB_TICKET >= 2
       if (c < a.C) __hip_atomic_store(a.partial + ((long)lb.y * 2 + which) * a.C + c, tot,
                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #else

@@ -26,6 +26,18 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+@pytest.fixture(autouse=True)
+def _seed_global_rng(request):
+    """Every test starts from its own fixed state of torch's global generator: a test that draws
+    from it (torch.rand / randn without a generator) no longer depends on which tests ran before
+    it (r05: a near-tie ReLU in test_frozen_batchnorm_* surfaced only after another test had
+    been inserted in front of it)."""
+    import zlib
+    import torch
+    torch.manual_seed(zlib.crc32(request.node.nodeid.encode()) & 0x7FFFFFFF)
+    yield
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN

@@ -408,8 +408,9 @@ def test_bn_backward_small_float64_in_one_launch(shape, relu):
     base = rnd((1, C, 1, 1), 5) * 3 + 20.0
     x = quant(base + rnd((N, C, H, W), 6) * 0.02, dtype)
     g = quant(rnd((N, C, H, W), 7), dtype)
-    gamma, beta = torch.rand(C) + 0.5, rnd((C,), 3, 0.2)
-    mul = (torch.rand(N, C) > 0.3).float() / 0.7
+    gen = torch.Generator().manual_seed(11)
+    gamma, beta = torch.rand(C, generator=gen) + 0.5, rnd((C,), 3, 0.2)
+    mul = (torch.rand(N, C, generator=gen) > 0.3).float() / 0.7
     xd = x.double().requires_grad_()
     gd, bd = gamma.double().requires_grad_(), beta.double().requires_grad_()
     y = TF.batch_norm(xd, None, None, gd, bd, True, 0.1, 1e-5)
@@ -844,16 +845,25 @@ def test_frozen_batchnorm_is_a_constant_affine_in_train_mode(dtype):
     xr = x.double().requires_grad_()
     wr = conv.weight.detach().double().requires_grad_()
     scale = bn.weight.double() * (bn.running_var.double() + bn.eps).rsqrt()
-    ref = torch.relu(TF.conv2d(xr, wr, None, 1, 1) * scale.view(1, -1, 1, 1)
-                     + (bn.bias.double() - bn.running_mean.double() * scale).view(1, -1, 1, 1))
+    z = TF.conv2d(xr, wr, None, 1, 1) * scale.view(1, -1, 1, 1) \
+        + (bn.bias.double() - bn.running_mean.double() * scale).view(1, -1, 1, 1)
+    ref = torch.relu(z)
     g = quant(rnd(tuple(ref.shape), 5), dtype)
-    ref.backward(g.double())
     conv, bn = conv.to(DEV), bn.to(DEV)
     xd = to_dev_nhwc(x, dtype).requires_grad_()
     a = Fm.conv_bn(Fm.Act(xd), conv, bn)
     a.relu = True
     y = Fm.materialize(a)
     assert_close(to_cpu_nchw(y), ref.detach(), dtype, "frozen bn fwd", fac=2)
+    # backward reference with the ReLU decisions of the HIP forward: a pre-activation within
+    # bf16 rounding of zero may land on either side (the conv output is stored in bf16 before the
+    # affine), and ONE flipped unit moves a 3x3 patch of dx by its full weight — this test drew
+    # its BatchNorm parameters from the unseeded global generator until r05 and failed on such a
+    # tie once (7.6e-2) after passing for two rounds
+    mask = (to_cpu_nchw(y) > 0).double()
+    flips = int((mask != (z.detach() > 0).double()).sum())
+    assert flips <= 0.002 * mask.numel(), flips
+    (z * mask).backward(g.double())
     y.backward(to_dev_nhwc(g, dtype))
     assert_close(to_cpu_nchw(xd.grad), xr.grad, dtype, "frozen bn dx", fac=4)
     assert_close(conv.weight.grad.cpu(), wr.grad, dtype, "frozen bn dW", fac=4)
