@@ -309,7 +309,7 @@ int seg_nchw_to_nhwc_pad(int dtype, const float* x, int N, int Cin, int H, int W
  * vector-padded pitch); target: int64 [N, H, W]; loss_out: float32[2] = (mean loss, 1 / number
  * of valid pixels); ws: >= 2 * seg_upsample_ce_blocks(N, H, W) doubles.  Backward: dlo
  * [N, Hi, Wi, lddlo] in `dtype` (channels >= C written as zeros) = grad_out[0] * dLoss/dlo,
- * up-sampling factors up to 4.1.  Deterministic (fixed-order float64 / gather reductions). */
+ * up-sampling factors up to 8.1 (output-stride-4 and -8 heads).  Deterministic (fixed-order float64 / gather reductions). */
 int seg_upsample_ce_blocks(int N, int H, int W);
 int seg_upsample_ce_fwd(int dtype, const void* lo, long ld, int N, int Hi, int Wi, int C,
                         const long* target, int H, int W, long ignore_index, int align_corners,

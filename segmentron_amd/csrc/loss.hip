@@ -315,6 +315,15 @@ template <int NC, int LT, int HT_MAX, int CH> constexpr size_t ce_bwd_lds() {
 constexpr int CE_LT24 = 6, CE_HT24 = 36, CE_CH24 = 12, CE_LT32 = 4, CE_HT32 = 28, CE_CH32 = 10;
 static_assert(ce_bwd_lds<24, CE_LT24, CE_HT24, CE_CH24>() <= 53 * 1024, "LDS budget (3 blocks/CU)");
 static_assert(ce_bwd_lds<32, CE_LT32, CE_HT32, CE_CH32>() <= 53 * 1024, "LDS budget (3 blocks/CU)");
+// r05: up to 8.1x (output-stride-8 heads: PSPNet / DANet / CCNet logits at 129x257 for a 1025x2049
+// image; the PSPNet train step paid 6.5 ms of 72 for materialised logits + torch's log-softmax /
+// NLL kernels): the same kernel on 3 x 3 (2 x 2) low-resolution tiles, (LT + 1.5) * 8.1 + 5 rows
+constexpr int CE8_LT24 = 3, CE8_HT24 = 42, CE8_LT32 = 2, CE8_HT32 = 34;
+static_assert(ce_bwd_lds<24, CE8_LT24, CE8_HT24, CE_CH24>() <= 53 * 1024, "LDS budget (3 blocks/CU)");
+static_assert(ce_bwd_lds<32, CE8_LT32, CE8_HT32, CE_CH32>() <= 53 * 1024, "LDS budget (3 blocks/CU)");
+constexpr float CE_MAX_SCALE = 4.1f, CE8_MAX_SCALE = 8.1f;
+static_assert((CE_LT24 + 1.5f) * CE_MAX_SCALE + 5 <= CE_HT24 + 1 && (CE_LT32 + 1.5f) * CE_MAX_SCALE + 5 <= CE_HT32 + 1, "");
+static_assert((CE8_LT24 + 1.5f) * CE8_MAX_SCALE + 5 <= CE8_HT24 && (CE8_LT32 + 1.5f) * CE8_MAX_SCALE + 5 <= CE8_HT32, "");
 
 template <typename T, int NC, int LT, int HT, int CH>
 static int launch_ce_bwd(int blocks, hipStream_t st, const CeArgs& a, const float* loss_out,
@@ -378,20 +387,27 @@ extern "C" int seg_upsample_ce_bwd(int dtype, const void* lo, long ld, int N, in
   SEG_REQUIRE(C >= 1 && C <= 32 && ld % vec == 0 && lddlo >= C && lddlo <= 32,
               "upsample_ce_bwd: bad C / pitch (1 <= C <= lddlo <= 32)");
   SEG_REQUIRE(H >= Hi && W >= Wi, "upsample_ce_bwd: the fused loss is for UP-sampling heads");
-  // a low-res tile row is touched by at most HT_MAX output rows / columns up to 4.1x
+  // a low-res tile row is touched by at most HT_MAX output rows / columns up to 4.1x (8.1x)
   const float sh = host_scale(Hi, H, align_corners), sw = host_scale(Wi, W, align_corners);
   const float smin = fminf(sh > 0.f ? sh : 1.f, sw > 0.f ? sw : 1.f);
-  SEG_REQUIRE(1.f / smin <= 4.1f,
+  SEG_REQUIRE(1.f / smin <= CE8_MAX_SCALE,
               "upsample_ce_bwd: scale factor %.2f too large for the fused backward", 1.f / smin);
+  const bool wide = 1.f / smin > CE_MAX_SCALE;  // 4.1x .. 8.1x: the small-tile instances
   CeArgs a;
   a.lo = lo; a.target = target; a.ld = ld; a.N = N; a.Hi = Hi; a.Wi = Wi; a.H = H; a.W = W;
   a.C = C; a.ignore = ignore_index; a.align = align_corners; a.sh = sh; a.sw = sw;
   hipStream_t st = (hipStream_t)stream;
   const int nc = C <= 24 ? 24 : 32;
-  const int lt = nc == 24 ? CE_LT24 : CE_LT32;
+  const int lt = wide ? (nc == 24 ? CE8_LT24 : CE8_LT32) : (nc == 24 ? CE_LT24 : CE_LT32);
   const int blocks = N * ((Hi + lt - 1) / lt) * ((Wi + lt - 1) / lt);
   int rc;
-  if (dtype == DT_BF16) {
+  if (wide && dtype == DT_BF16) {
+    rc = nc == 24 ? launch_ce_bwd<bf16_t, 24, CE8_LT24, CE8_HT24, CE_CH24>(blocks, st, a, loss_out, grad_out, dlo, lddlo)
+                  : launch_ce_bwd<bf16_t, 32, CE8_LT32, CE8_HT32, CE_CH32>(blocks, st, a, loss_out, grad_out, dlo, lddlo);
+  } else if (wide) {
+    rc = nc == 24 ? launch_ce_bwd<float, 24, CE8_LT24, CE8_HT24, CE_CH24>(blocks, st, a, loss_out, grad_out, dlo, lddlo)
+                  : launch_ce_bwd<float, 32, CE8_LT32, CE8_HT32, CE_CH32>(blocks, st, a, loss_out, grad_out, dlo, lddlo);
+  } else if (dtype == DT_BF16) {
     rc = nc == 24 ? launch_ce_bwd<bf16_t, 24, CE_LT24, CE_HT24, CE_CH24>(blocks, st, a, loss_out, grad_out, dlo, lddlo)
                   : launch_ce_bwd<bf16_t, 32, CE_LT32, CE_HT32, CE_CH32>(blocks, st, a, loss_out, grad_out, dlo, lddlo);
   } else {

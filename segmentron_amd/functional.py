@@ -881,8 +881,9 @@ class LogitsView:
                 and target.dim() == 3 and tuple(target.shape) == (n,) + self.out_hw
                 and self.align_corners and self.out_hw[0] >= hi and self.out_hw[1] >= wi
                 and hi > 1 and wi > 1
-                # seg_upsample_ce_bwd's own criterion: 1/scale = (H-1)/(Hi-1) <= 4.1
-                and self.out_hw[0] - 1 <= 4.1 * (hi - 1) and self.out_hw[1] - 1 <= 4.1 * (wi - 1))
+                # seg_upsample_ce_bwd's own criterion: 1/scale = (H-1)/(Hi-1) <= 8.1 (r05: the
+                # output-stride-8 heads of PSPNet / DANet / CCNet; 4.1 before)
+                and self.out_hw[0] - 1 <= 8.1 * (hi - 1) and self.out_hw[1] - 1 <= 8.1 * (wi - 1))
 
     @classmethod
     def __torch_function__(cls, func, types, args=(), kwargs=None):
