@@ -175,6 +175,12 @@ int seg_sum_n(int dtype, int n, const void* const* xs, const long* lds, void* y,
 /* eval mode: scale/shift from running statistics. */
 int seg_bn_eval_affine(const float* gamma, const float* beta, const float* rm, const float* rv,
                        float eps, float* scale, float* shift, int C, void* stream);
+/* ... of n BatchNorms at once (host arrays of device pointers; out[j]: 2*C[j] floats = scale row,
+ * shift row; C[j] <= 2048; gamma[j] / beta[j] nullable): one launch per 48 jobs instead of one per
+ * BatchNorm of an evaluation-mode forward. */
+int seg_bn_eval_affine_multi(int n, const float* const* gamma, const float* const* beta,
+                             const float* const* rm, const float* const* rv, const float* eps,
+                             float* const* out, const int* C, void* stream);
 /* Materialise: y = post_relu?( act_x(x) * chan_mul[n][c] + act_r(r) )  (r, chan_mul nullable).
  * Covers BN+ReLU materialisation, the residual adds of xception.py:40,42 / resnet.py:38,78 and
  * nn.Dropout2d (segmentron/modules/module.py:60; chan_mul = mask/(1-p), rows_per_n = H*W) and

@@ -105,6 +105,31 @@ __global__ void bn_eval_affine_kernel(const float* __restrict__ gamma,
   shift_o[c] = b - rm[c] * g * invstd;
 }
 
+// The same for up to 48 BatchNorms in ONE launch (r05): an evaluation-mode forward asked for
+// one 3 us launch per BatchNorm — 52 of the 132 kernels of a DeepLabv3+/MobileNetV2 inference
+// step and 12 % of its 1.39 ms (`profiles/r05_bench_c2.json`).  Block b serves job b / 8,
+// channels (b % 8) * 256 .. (C <= 2048 per job; wider layers go through the single-job entry).
+constexpr int EVAL_MULTI_MAX = 48, EVAL_MULTI_BPJ = 8;
+struct EvalMultiArgs {
+  const float* gamma[EVAL_MULTI_MAX];
+  const float* beta[EVAL_MULTI_MAX];
+  const float* rm[EVAL_MULTI_MAX];
+  const float* rv[EVAL_MULTI_MAX];
+  float* out[EVAL_MULTI_MAX];  // [2][C]: scale row, shift row
+  float eps[EVAL_MULTI_MAX];
+  int C[EVAL_MULTI_MAX];
+};
+__global__ void bn_eval_affine_multi_kernel(const EvalMultiArgs a) {
+  const int j = blockIdx.x / EVAL_MULTI_BPJ;
+  const int c = (blockIdx.x % EVAL_MULTI_BPJ) * 256 + threadIdx.x;
+  const int C = a.C[j];
+  if (c >= C) return;
+  const float g = a.gamma[j] ? a.gamma[j][c] : 1.f, b = a.beta[j] ? a.beta[j][c] : 0.f;
+  const float invstd = 1.0f / sqrtf(a.rv[j][c] + a.eps[j]);
+  a.out[j][c] = g * invstd;
+  a.out[j][C + c] = b - a.rm[j][c] * g * invstd;
+}
+
 // ------------------------------------------------------------------ apply (+ residual)
 struct ApplyArgs {
   const void* x; const void* r; void* y;
@@ -798,6 +823,29 @@ extern "C" int seg_bn_eval_affine(const float* gamma, const float* beta, const f
   hipLaunchKernelGGL(bn_eval_affine_kernel, dim3((C + 255) / 256), dim3(256), 0,
                      (hipStream_t)stream, gamma, beta, rm, rv, eps, scale, shift, C);
   return check_launch("bn_eval_affine");
+}
+
+extern "C" int seg_bn_eval_affine_multi(int n, const float* const* gamma, const float* const* beta,
+                                        const float* const* rm, const float* const* rv,
+                                        const float* eps, float* const* out, const int* C,
+                                        void* stream) {
+  using namespace seg;
+  SEG_REQUIRE(n >= 1, "bn_eval_affine_multi: no jobs");
+  for (int j0 = 0; j0 < n; j0 += EVAL_MULTI_MAX) {
+    EvalMultiArgs a;
+    const int m = n - j0 < EVAL_MULTI_MAX ? n - j0 : EVAL_MULTI_MAX;
+    for (int j = 0; j < m; ++j) {
+      SEG_REQUIRE(C[j0 + j] >= 1 && C[j0 + j] <= 256 * EVAL_MULTI_BPJ && rm[j0 + j] && rv[j0 + j] &&
+                      out[j0 + j],
+                  "bn_eval_affine_multi: job %d: C=%d (1..%d) or a missing operand", j0 + j,
+                  C[j0 + j], 256 * EVAL_MULTI_BPJ);
+      a.gamma[j] = gamma[j0 + j]; a.beta[j] = beta[j0 + j]; a.rm[j] = rm[j0 + j];
+      a.rv[j] = rv[j0 + j]; a.out[j] = out[j0 + j]; a.eps[j] = eps[j0 + j]; a.C[j] = C[j0 + j];
+    }
+    hipLaunchKernelGGL(bn_eval_affine_multi_kernel, dim3(m * EVAL_MULTI_BPJ), dim3(256), 0,
+                       (hipStream_t)stream, a);
+  }
+  return check_launch("bn_eval_affine_multi");
 }
 
 namespace seg {

@@ -105,8 +105,7 @@ def finish_bn(bn, partial, count, mean_offset=None, y=None):
     image-pooling branch and PSP's pyramid bins."""
     use_batch = uses_batch_stats(bn)
     if not use_batch:
-        scale, shift = K.bn_eval_affine(bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                                        bn.eps)
+        scale, shift = eval_affine(bn)
         invstd = mean = None
         if torch.is_grad_enabled():
             mean = bn.running_mean
@@ -121,6 +120,8 @@ def finish_bn(bn, partial, count, mean_offset=None, y=None):
     track = bn.training and getattr(bn, "track_running_stats", False) \
         and bn.running_mean is not None
     rm, rv = (bn.running_mean, bn.running_var) if track else (None, None)
+    if track:
+        note_running_stats_changed()
     if group is None and y is not None and count <= K.SMALL_BN_ROWS:
         mean, invstd, scale, shift = K.bn_finalize_small(y, bn.weight, bn.bias, bn.eps, momentum,
                                                          rm, rv, mean_offset)
@@ -353,6 +354,74 @@ def packed_pointwise(param, transpose, dtype):
     return _WCACHE[key][3]
 
 
+# id(bn) -> weakref(bn): every evaluation-mode BatchNorm whose (scale, shift) was requested so far
+_EVAL_PLAN = {}
+EVAL_AFFINE_MAX_C = 2048  # seg_bn_eval_affine_multi: channels per job
+
+
+# The training-mode finalize kernels update running_mean / running_var through raw pointers:
+# torch's version counters do not see that.  Every training-mode BatchNorm evaluation (and every
+# replay of a captured training forward, graph.py) advances this counter instead, and it is part
+# of the key of the cached evaluation-mode affines.
+_STATS_EPOCH = [0]
+
+
+def note_running_stats_changed():
+    _STATS_EPOCH[0] += 1
+
+
+def _eval_versions(bn):
+    return tuple(-1 if t is None else t._version
+                 for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var)) \
+        + (float(bn.eps), _STATS_EPOCH[0])
+
+
+def eval_affine(bn):
+    """(scale, shift) of an evaluation-mode (or frozen) BatchNorm from its running statistics,
+    cached like the weight packs (`cached_pack`: valid while the four tensors keep their version,
+    eagerly made entries for eager requests, entries made inside a HIP-graph capture for that
+    capture) and computed for ALL planned BatchNorms of the model by one multi-tensor launch at
+    the first miss (hip_ops.bn_eval_affine_multi) — an inference forward used to issue one 3 us
+    launch per BatchNorm (52 of 132 kernels of DeepLabv3+/MobileNetV2).  Under
+    `restrict_pack_plan` only BatchNorms of the capturing model ride along."""
+    key = (id(bn), "eval_affine")
+    scope = _scope()
+
+    def hit(m, k):
+        ent = _WCACHE.get(k)
+        return ent is not None and ent[0] == _eval_versions(m) and ent[2]() is m and ent[4] == scope \
+            and ent[1] == m.running_mean.data_ptr()
+
+    if hit(bn, key):
+        return _WCACHE[key][3]
+    if bn.running_mean.numel() > EVAL_AFFINE_MAX_C:
+        val = K.bn_eval_affine(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
+        _WCACHE[key] = (_eval_versions(bn), bn.running_mean.data_ptr(), weakref.ref(bn), val, scope)
+        return val
+    _EVAL_PLAN[id(bn)] = weakref.ref(bn)
+    todo = []
+    for mid, ref in list(_EVAL_PLAN.items()):
+        m = ref()
+        if m is None or id(m) != mid or m.running_mean is None:
+            del _EVAL_PLAN[mid]
+            continue
+        if m is not bn:
+            if m.running_mean.device != bn.running_mean.device or uses_batch_stats(m):
+                continue
+            if _PLAN_FILTER[0] is not None and (m.weight is None or id(m.weight) not in _PLAN_FILTER[0]):
+                continue
+            if hit(m, (mid, "eval_affine")):
+                continue
+        todo.append(m)
+    outs = K.bn_eval_affine_multi([(m.weight, m.bias, m.running_mean, m.running_var, m.eps)
+                                   for m in todo])
+    for m, val in zip(todo, outs):
+        _WCACHE[(id(m), "eval_affine")] = (_eval_versions(m), m.running_mean.data_ptr(),
+                                           weakref.ref(m), val, scope)
+        _note_miss()
+    return _WCACHE[key][3]
+
+
 def pack_conv_weight(w, cx, dtype):
     """[O, Cw, KH, KW] fp32 -> [O, KH*KW*cx] (`dtype`), input channels zero-padded to cx."""
     O, Cw, KH, KW = w.shape
@@ -471,7 +540,18 @@ class _ConvFn(torch.autograd.Function):
             else:
                 wt = cached_pack(weight, ("dgrad", Op, dt),
                                  lambda: pack_conv_weight_dgrad(weight, Op, dt))
-            if s.stride == 1:
+            res = None
+            if s.fork is not None and s.fork.g is not None:
+                res = s.fork.take()  # the identity path's gradient of a forked block input
+            if s.stride == 1 and res is not None and KH == 1 and KW == 1 and s.bn_in is None \
+                    and not s.relu and Cw % K.vec_of(dt) == 0 and res.dtype == dt:
+                # ... rides in the data-gradient GEMM's store path: the epilogue's
+                # y = acc - c0 - c1 * x with c0 = 0, c1 = -1 (ResNet bottlenecks, resnet.py:52-79:
+                # 33 element-wise adds of 135 MB tensors per PSPNet step, 2.4 of 72 ms)
+                g, _ = K.conv_gemm(dy_full, wt, Cw, 1, 1, 1, 0, 1,
+                                   ep=(res, _const(Cw, x.device, 0.0), _const(Cw, x.device, -1.0)))
+                res = None
+            elif s.stride == 1:
                 g, _ = K.conv_gemm(dy_full, wt, Cw, KH, KW, 1, s.dil * (KH - 1) - s.pad, s.dil)
             elif KH == 1 and KW == 1 and s.pad == 0:
                 g, _ = K.conv_gemm(dy_full, wt, Cw, 1, 1, 1, 0, 1,
@@ -482,17 +562,25 @@ class _ConvFn(torch.autograd.Function):
                 g, _ = K.conv_gemm(dy_full, wt, Cw, KH, KW, s.stride, s.pad, s.dil,
                                    tconv_out_hw=(x.shape[1], x.shape[2]))
             dx, dgamma, dbeta = bn_input_backward(g, x, s.bn_in, s.relu, inplace=True)
+            if res is not None:  # (a path whose kernel cannot add it in its store)
+                dx = dx + res
+        elif s.fork is not None:
+            s.fork.g = None
         return dx, dgamma, dbeta, dW, dbias, None
 
 
 _ONES = {}
 
 
-def _ones(c, device):
-    key = (c, str(device))
+def _const(c, device, value):
+    key = (c, str(device), float(value))
     if key not in _ONES:
-        _ONES[key] = torch.ones(c, dtype=torch.float32, device=device)
+        _ONES[key] = torch.full((c,), float(value), dtype=torch.float32, device=device)
     return _ONES[key]
+
+
+def _ones(c, device):
+    return _const(c, device, 1.0)
 
 
 class _FoldConvFn(torch.autograd.Function):
@@ -1201,9 +1289,10 @@ def channel_attention(x, gamma):
 _NO_FOLD = os.environ.get("SEG_NO_FOLD") == "1"
 
 
-def conv_bn(act, conv, bn=None, out=None):
+def conv_bn(act, conv, bn=None, out=None, fork=None):
     """conv (nn.Conv2d, groups=1) [+ BatchNorm statistics].  Returns an Act whose BN (if any) and
-    ReLU are pending; caller sets ``.relu``."""
+    ReLU are pending; caller sets ``.relu``.  `fork`: see GradFork (the input is a forked plain
+    activation whose other consumer parks its gradient for this conv's data-gradient GEMM)."""
     x = act.t
     batch_stats = bn is not None and uses_batch_stats(bn)
     spec = ConvSpec(act, conv.stride[0], conv.padding[0], conv.dilation[0], out,
@@ -1226,6 +1315,7 @@ def conv_bn(act, conv, bn=None, out=None):
         offset = spec.mean_offset if batch_stats else None
     else:
         spec.drop_bias = batch_stats and conv.bias is not None
+        spec.fork = fork
         y = _ConvFn.apply(x, g, b, conv.weight, conv.bias, spec)
         offset = conv.bias.detach() if spec.drop_bias else None
     if bn is None:

@@ -125,6 +125,7 @@ class GraphedTrainStep:
         if targets is not None:
             self.targets.copy_(targets)
         self.graph.replay()
+        F.note_running_stats_changed()  # (the replayed finalize kernels rewrote running statistics)
         self._replays += 1
         if self._check is not None and self._check_every > 0 \
                 and self._replays % self._check_every == 0:
@@ -148,6 +149,7 @@ class _GraphedSegment(torch.autograd.Function):
     @staticmethod
     def forward(ctx, anchor, seg):
         seg.fwd.replay()
+        F.note_running_stats_changed()  # (functional.eval_affine: cached evaluation-mode affines)
         ctx.seg = seg
         return tuple(t.detach() for t in seg.lo)
 

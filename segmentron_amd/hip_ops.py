@@ -347,6 +347,20 @@ def bn_eval_affine(gamma, beta, rm, rv, eps):
     return out[0], out[1]
 
 
+def bn_eval_affine_multi(jobs):
+    """jobs: [(gamma|None, beta|None, running_mean, running_var, eps)] -> [(scale, shift)] by one
+    launch per 48 BatchNorms."""
+    import ctypes
+    n = len(jobs)
+    outs = [torch.empty((2, j[2].numel()), dtype=torch.float32, device=j[2].device) for j in jobs]
+    vp, fp, ip = ctypes.c_void_p * n, ctypes.c_float * n, ctypes.c_int * n
+    LIB.call("seg_bn_eval_affine_multi", n, vp(*[_p(j[0]) for j in jobs]),
+             vp(*[_p(j[1]) for j in jobs]), vp(*[_p(j[2]) for j in jobs]),
+             vp(*[_p(j[3]) for j in jobs]), fp(*[float(j[4]) for j in jobs]),
+             vp(*[o.data_ptr() for o in outs]), ip(*[j[2].numel() for j in jobs]), _stream())
+    return [(o[0], o[1]) for o in outs]
+
+
 def bn_apply(x, pro_x=None, r=None, pro_r=None, chan_mul=None, post_relu=False, out=None,
              elem_mul=None):
     N, H, W, C, ldx = nhwc(x)

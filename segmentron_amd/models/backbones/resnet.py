@@ -1,5 +1,6 @@
 """ResNet-v1b/c backbones — module tree / state_dict of
 segmentron/models/backbones/resnet.py:9-247, forward on the HIP kernels."""
+import torch
 import torch.nn as nn
 
 from ... import functional as F
@@ -50,7 +51,14 @@ class BottleneckV1b(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        out = F.conv_bn(x, self.conv1, self.bn1)
+        # identity blocks: x feeds conv1 AND the residual sum — the sum's backward parks its
+        # gradient (functional.GradFork), conv1's data-gradient GEMM adds it in its store path
+        # instead of autograd's element-wise add
+        fork = None
+        if self.downsample is None and x.bn is None and not x.relu and torch.is_grad_enabled() \
+                and x.t.requires_grad:
+            fork = F.GradFork()
+        out = F.conv_bn(x, self.conv1, self.bn1, fork=fork)
         out.relu = True
         out = F.conv_bn(out, self.conv2, self.bn2)
         out.relu = True
@@ -58,7 +66,7 @@ class BottleneckV1b(nn.Module):
         identity = x if self.downsample is None else \
             F.conv_bn(x, self.downsample[0], self.downsample[1])
         # bn3(conv3) + identity, then ReLU: one materialising pass (resnet.py:76-79)
-        return F.Act(F.materialize(out, residual=identity, post_relu=True))
+        return F.Act(F.materialize(out, residual=identity, post_relu=True, fork=fork))
 
 
 class ResNetV1(nn.Module):

@@ -440,6 +440,48 @@ def test_bn_backward_small_float64_in_one_launch(shape, relu):
           "fp32 reduce + finalize + apply %.2e of max |dx|" % (N * H * W, err, err32))
 
 
+def test_eval_affine_of_many_batchnorms_in_one_launch_and_cache_invalidation():
+    """functional.eval_affine (r05): the evaluation-mode (scale, shift) of every planned BatchNorm
+    by ONE seg_bn_eval_affine_multi launch, bit-identical to the per-module kernel, cached on the
+    tensors' versions — and dropped when a TRAINING forward rewrites the running statistics through
+    the finalize kernels' raw pointers (which torch's version counters do not see)."""
+    import torch.nn as nn
+    Fm = F()
+    gen = torch.Generator().manual_seed(3)
+    bns = []
+    for C in (24, 728, 2048, 72, 256) * 11:  # 55 modules: two launches of <= 48 jobs
+        bn = nn.BatchNorm2d(C, eps=1e-3).to(DEV).eval()
+        with torch.no_grad():
+            bn.weight.copy_(torch.rand(C, generator=gen) + 0.5)
+            bn.bias.copy_(torch.randn(C, generator=gen) * 0.2)
+            bn.running_mean.copy_(torch.randn(C, generator=gen) * 0.3)
+            bn.running_var.copy_(torch.rand(C, generator=gen) + 0.5)
+        bns.append(bn)
+    Fm.clear_weight_cache()
+    for bn in bns:       # plan them (each request computes what is planned so far)
+        Fm.eval_affine(bn)
+    Fm.clear_weight_cache()
+    misses = Fm._MISSES[0]
+    got = [Fm.eval_affine(bn) for bn in bns]
+    assert Fm._MISSES[0] - misses == len(bns)   # ONE request packed all of them
+    for bn, (sc, sh) in zip(bns, got):
+        es, et = K().bn_eval_affine(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
+        assert torch.equal(sc, es) and torch.equal(sh, et)
+    again = Fm.eval_affine(bns[7])
+    assert again[0].data_ptr() == got[7][0].data_ptr()           # cached
+    # a training-mode BatchNorm evaluation anywhere invalidates the cached affines
+    tbn = nn.BatchNorm2d(72).to(DEV).train()
+    x = to_dev_nhwc(quant(rnd((2, 72, 5, 7), 1), torch.float32), torch.float32)
+    part = K().bn_bwd_reduce_partial(x, x, (0, None, None))  # (sum x, sum x^2) rows
+    Fm.finish_bn(tbn, part.view(part.shape[0], 2, 72), 2 * 5 * 7, y=x)
+    with torch.no_grad():
+        bns[7].running_mean.data.add_(1.0)  # (.data: no version bump, like the kernels' writes)
+    fresh = Fm.eval_affine(bns[7])
+    es, et = K().bn_eval_affine(bns[7].weight, bns[7].bias, bns[7].running_mean,
+                                bns[7].running_var, bns[7].eps)
+    assert torch.equal(fresh[1], et) and not torch.equal(fresh[1], got[7][1])
+
+
 @pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
 def test_bn_apply_residual_and_channel_mask(dtype):
     N, C, H, W = 2, 72, 7, 9
