@@ -1,5 +1,7 @@
 // Direct 3x3 / stride-1 / pad-1 convolution for FEW channels at LARGE spatial sizes (bf16):
-// xception conv2 32->64 and its data gradient 64->32 at 513x1025
+// xception conv2 32->64 and its data gradient 64->32 at 513x1025; r05: HRNet's 16 -> 16 basic
+// blocks of the full-resolution branch (hrnet.py BasicBlock, 12 convolutions per forward at
+// 16 x 256 x 512 pixels: 186-260 us each on the implicit GEMM for 134 MB of traffic)
 // (segmentron/models/backbones/xception.py:66-75; C = O = 64 does not fit the register budget and
 // stays on the implicit GEMM's 256x64 tile), where the implicit GEMM's K slabs are latency-bound: a 128-pixel block re-gathers its operand once per 64-k slab
 // and waits a full memory round trip each time (conv2 forward: 191 us for 215 MB / 39 GFLOP).
@@ -29,6 +31,10 @@ namespace seg {
 constexpr int D3_TH = 8, D3_TW = 32, D3_HH = D3_TH + 2, D3_HW = D3_TW + 2;
 constexpr int D3_THREADS = 256;
 constexpr int D3_MAX_BLOCKS = 512;
+// C = 16: 20 KB of LDS and ~120 VGPRs per block — four blocks per CU hide each other's staging
+#ifndef D3_C16_BLOCKS
+#define D3_C16_BLOCKS 1024
+#endif
 
 typedef __attribute__((address_space(3))) unsigned char d3_lds_t;
 
@@ -64,12 +70,16 @@ __global__ __launch_bounds__(D3_THREADS, 2) void conv3x3_direct_kernel(const Con
   // ---- this wave's weights: [9 taps][KS] fragments of output channel og*32 + r32
   bf16x8 wf[9][G::KS];
   {
-    const T* wrow = W + (long)(og * 32 + r32) * (9 * C) + h * 8;
+    // (O = 16, r05: the upper 16 rows of the only channel group are zero weights)
+    const bool orow = og * 32 + r32 < a.O;
+    const T* wrow = W + (long)(orow ? og * 32 + r32 : 0) * (9 * C) + h * 8;
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
-      for (int ks = 0; ks < G::KS; ++ks)
+      for (int ks = 0; ks < G::KS; ++ks) {
         wf[t][ks] = *reinterpret_cast<const bf16x8*>(wrow + t * C + ks * 16);
+        if (!orow) wf[t][ks] = __builtin_bit_cast(bf16x8, make_uint4(0u, 0u, 0u, 0u));
+      }
   }
   // ---- prologue parameters of this thread's staging vector (its channel slot never changes:
   // 256 % VPP == 0)
@@ -178,7 +188,7 @@ __global__ __launch_bounds__(D3_THREADS, 2) void conv3x3_direct_kernel(const Con
       const int px = (it & 1) * 16 + (lane >> 2), v = lane & 3;
       const int ho = h0 + row0 + pg, wo = w0 + px;
       const uint4 val = *reinterpret_cast<const uint4*>(patch + (pg * 32 + px) * G::OP + v * 16);
-      if (ho < a.Ho && wo < a.Wo) {
+      if (ho < a.Ho && wo < a.Wo && og * 32 + v * 8 < a.O) {
         stg16(Y + (((long)n * a.Ho + ho) * a.Wo + wo) * a.ldy + og * 32 + v * 8, val);
         if (STATS) {
           float f[8];
@@ -222,8 +232,10 @@ __global__ __launch_bounds__(D3_THREADS, 2) void conv3x3_direct_kernel(const Con
         q += red[(w * 2 + 1) * 32 + c];
       }
       float* dst = a.stat_partial + (long)blockIdx.x * 2 * a.O;
-      dst[g * 32 + c] = s;
-      dst[a.O + g * 32 + c] = q;
+      if (g * 32 + c < a.O) {
+        dst[g * 32 + c] = s;
+        dst[a.O + g * 32 + c] = q;
+      }
     }
   }
 }
@@ -232,14 +244,16 @@ __global__ __launch_bounds__(D3_THREADS, 2) void conv3x3_direct_kernel(const Con
 bool conv3x3_direct_usable(int dtype, const ConvGemmArgs& a) {
   return dtype == DT_BF16 && a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && a.dil == 1 &&
          !a.tconv && a.out_s == 1 && a.bias == nullptr && a.ep_x == nullptr &&
-         ((a.C == 32 && (a.O == 32 || a.O == 64)) || (a.C == 64 && a.O == 32)) &&
+         ((a.C == 32 && (a.O == 32 || a.O == 64)) || (a.C == 64 && a.O == 32) ||
+          (a.C == 16 && a.O == 16)) &&
          (a.ldx % 8) == 0 &&
          (a.ldy % 8) == 0 && a.Ho == a.Hi && a.Wo == a.Wi && (long)a.M >= 65536;
 }
 
-int conv3x3_direct_blocks(int N, int H, int W) {
+int conv3x3_direct_blocks(int N, int H, int W, int C) {
   const long nt = (long)N * ((H + D3_TH - 1) / D3_TH) * ((W + D3_TW - 1) / D3_TW);
-  return (int)(nt < D3_MAX_BLOCKS ? nt : D3_MAX_BLOCKS);
+  const int cap = C == 16 ? D3_C16_BLOCKS : D3_MAX_BLOCKS;
+  return (int)(nt < cap ? nt : cap);
 }
 
 template <int C, int NOG>
@@ -247,7 +261,7 @@ static int launch_d3(const ConvGemmArgs& a, hipStream_t stream) {
   using G = D3Geom<C, NOG>;
   const int tiles_h = (a.Hi + D3_TH - 1) / D3_TH, tiles_w = (a.Wi + D3_TW - 1) / D3_TW;
   const int ntiles = a.N * tiles_h * tiles_w;
-  const dim3 grid(conv3x3_direct_blocks(a.N, a.Hi, a.Wi)), block(D3_THREADS);
+  const dim3 grid(conv3x3_direct_blocks(a.N, a.Hi, a.Wi, C)), block(D3_THREADS);
   const bool st = a.stat_partial != nullptr, pro = a.pro_mode != PRO_NONE;
 #define SEG_D3(S, P)                                                                            \
   hipLaunchKernelGGL((conv3x3_direct_kernel<C, NOG, S, P>), grid, block, G::LDS_BYTES, stream, a, \
@@ -261,6 +275,7 @@ static int launch_d3(const ConvGemmArgs& a, hipStream_t stream) {
 }
 
 int launch_conv3x3_direct(const ConvGemmArgs& a, hipStream_t stream) {
+  if (a.C == 16) return launch_d3<16, 1>(a, stream);  // O = 16: half of the channel group
   if (a.C == 32 && a.O == 32) return launch_d3<32, 1>(a, stream);
   if (a.C == 32 && a.O == 64) return launch_d3<32, 2>(a, stream);
   return launch_d3<64, 1>(a, stream);

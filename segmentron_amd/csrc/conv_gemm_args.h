@@ -43,7 +43,7 @@ int glds_tiles_m(long M, int O);
 
 // direct 3x3 stride-1 kernel for few channels at large spatial sizes (conv3x3_direct.hip)
 bool conv3x3_direct_usable(int dtype, const ConvGemmArgs& a);
-int conv3x3_direct_blocks(int N, int H, int W);
+int conv3x3_direct_blocks(int N, int H, int W, int C = 32);
 int launch_conv3x3_direct(const ConvGemmArgs& a, hipStream_t stream);
 
 }  // namespace seg

@@ -386,7 +386,7 @@ extern "C" int seg_conv_gemm_stat_rows(int dtype, int N, int Ho, int Wo, int C, 
     probe.Ho = probe.Hi = Ho; probe.Wo = probe.Wi = Wo; probe.M = (int)M;
     probe.bias = has_bias ? reinterpret_cast<const float*>(&probe) : nullptr;
     if (seg::g_conv3x3_direct && seg::conv3x3_direct_usable(dtype, probe))
-      return seg::conv3x3_direct_blocks(N, Ho, Wo);
+      return seg::conv3x3_direct_blocks(N, Ho, Wo, C);
   }
   if (seg::gemm_use_wide(KH, KW, stride, pad, tconv, O, M)) return (int)((M + 255) / 256);
   return (int)((M + seg::BM - 1) / seg::BM);

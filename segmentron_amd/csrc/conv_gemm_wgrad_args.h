@@ -28,7 +28,7 @@ int launch_conv_wgrad_glds(WgradArgs a, hipStream_t stream);
 // direct halo-tile kernel for 3x3 stride-1 stems with 32 input channels (conv3x3_direct.hip)
 bool conv3x3_wgrad_direct_usable(int dtype, int C, int O, int KH, int KW, int stride, int pad,
                                  int dil, long M, long ldx, long lddy);
-int conv3x3_direct_blocks(int N, int H, int W);
+int conv3x3_direct_blocks(int N, int H, int W, int C = 32);
 int launch_conv3x3_wgrad_direct(const void* x, long ldx, const void* dy, long lddy, int N, int H,
                                 int W, int O, int pro_mode, const float* pro_scale,
                                 const float* pro_shift, float* partial, hipStream_t stream);

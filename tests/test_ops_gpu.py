@@ -66,13 +66,17 @@ CONV_CASES = [
     (1, 130, 127, 64, 32, 3, 1, 1, 1, 0, False, False),
     (1, 261, 259, 8, 32, 3, 2, 1, 1, 0, False, False),
     (1, 129, 131, 16, 24, 3, 1, 2, 2, 2, False, True),
-    # direct halo-tile 3x3 kernel (bf16, stride 1, C/O in {32, 64}, >= 65536 pixels): ragged
+    # direct halo-tile 3x3 kernel (bf16, stride 1, C/O in {16, 32, 64}, >= 65536 pixels): ragged
     # tile rows / columns, BatchNorm+ReLU prologue with zero padding, statistics, two images,
     # channel-slice input and output
     (1, 260, 257, 32, 64, 3, 1, 1, 1, 3, False, False),
     (1, 259, 261, 64, 32, 3, 1, 1, 1, 0, False, False),
     (2, 131, 259, 32, 32, 3, 1, 1, 1, 2, False, True),
     (2, 129, 257, 64, 32, 3, 1, 1, 1, 3, False, False),
+    # ... C = O = 16 (r05: HRNet's full-resolution basic blocks; half of the kernel's 32-channel
+    # group is zero weights): prologue + statistics on ragged tiles, plain on a slice in / out
+    (2, 131, 259, 16, 16, 3, 1, 1, 1, 3, False, False),
+    (1, 259, 261, 16, 16, 3, 1, 1, 1, 0, False, True),
     # stride-1 KxK on the direct-to-LDS pipeline (bf16, no prologue, C % 32 == 0, O >= 256,
     # >= 4096 pixels): ResNet layer3 / layer4 dilated 3x3, ragged O tile + slice in/out, a
     # padding that shrinks the map (the data-gradient geometry of a padded conv)
@@ -111,7 +115,7 @@ def test_conv_gemm_fwd(case, dtype):
         nb = ref - (0 if b is None else b.view(1, -1, 1, 1).double())
         M = N * ref.shape[2] * ref.shape[3]
         direct = k == 3 and stride == 1 and pad == 1 and dil == 1 and M >= 65536 and \
-            (C, O) in ((32, 32), (32, 64), (64, 32))
+            (C, O) in ((32, 32), (32, 64), (64, 32), (16, 16))
         glds_kxk = k > 1 and stride == 1 and C % 32 == 0 and O >= 256 and M >= 4096 \
             and mode == 0 and not bias
         if dtype == torch.bfloat16 and (direct or glds_kxk or (k == 1 and stride == 1 and pad == 0
