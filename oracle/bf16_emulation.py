@@ -152,7 +152,7 @@ class Bf16EmuNet:
         # direct halo-tile 3x3 kernel: statistics of the values AS STORED
         kxk = kh > 1 and stride == 1 and C_ % 32 == 0 and O_ >= 256 and m_ >= 4096 and bias is None
         direct = (kh == 3 and stride == 1 and pad == 1 and dil == 1 and m_ >= 65536
-                  and (C_, O_) in ((32, 32), (32, 64), (64, 32)))
+                  and (C_, O_) in ((32, 32), (32, 64), (64, 32), (16, 16)))
         s, b = self._bn(r16(y) if (fast or kxk or direct or m_ <= SMALL_BN_ROWS) else y, bnp)
         return _A(r16(y), s, b)
 

@@ -312,6 +312,94 @@ __global__ __launch_bounds__(GEMM_THREADS, (DBUF || !FAST) ? 2 : 3) void conv_ge
   }
 }
 
+// ---- a handful of pixels (r05): the ASPP image-pooling conv (2 pixels x 2048 -> 256) and the
+// PSP pyramid bins (2..72 pixels x 2048 -> 512) in float32 — module.py:45-62 / 18-38.  On the
+// 128x128 tile kernel ONE block walks K = 2048 as 64 dependent slabs (156-164 us per call).
+// Here a wave owns 8 pixels x 4 output channels, lanes split K (16 bytes per lane and row), every
+// row is read once per wave straight from L2; butterfly reduction, lane (r, j) stores.  The
+// BatchNorm partial rows: one per 8-pixel chunk (seg_conv_gemm_stat_rows agrees).
+constexpr int SK_ROWS = 8, SK_COLS = 4, SK_MAX_M = 128;
+
+static bool skinny_geometry(int dtype, long M, int C, int KH, int KW, int stride, int pad,
+                            int tconv, int has_bias, int pro_mode) {
+  return dtype == DT_F32 && KH * KW == 1 && stride == 1 && pad == 0 && !tconv && !has_bias &&
+         pro_mode == PRO_NONE && M <= SK_MAX_M && C >= 256 && C % 4 == 0;
+}
+
+__global__ __launch_bounds__(256) void conv_gemm_skinny_kernel(const ConvGemmArgs a, int ogs,
+                                                               int nwaves) {
+  const int lane = threadIdx.x & 63;
+  const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wid >= nwaves) return;
+  const int mc = wid / ogs, og = wid - mc * ogs;
+  const int m0 = mc * SK_ROWS, o0 = og * SK_COLS;
+  const float* __restrict__ X = reinterpret_cast<const float*>(a.x);
+  const float* __restrict__ W = reinterpret_cast<const float*>(a.w);
+  float* __restrict__ Y = reinterpret_cast<float*>(a.y);
+  const float* xr[SK_ROWS];
+  const float* wr[SK_COLS];
+#pragma unroll
+  for (int r = 0; r < SK_ROWS; ++r) xr[r] = X + (long)min(m0 + r, a.M - 1) * a.ldx;
+#pragma unroll
+  for (int j = 0; j < SK_COLS; ++j) wr[j] = W + (long)min(o0 + j, a.O - 1) * a.K;
+  float acc[SK_ROWS][SK_COLS];
+#pragma unroll
+  for (int r = 0; r < SK_ROWS; ++r)
+#pragma unroll
+    for (int j = 0; j < SK_COLS; ++j) acc[r][j] = 0.f;
+  for (int k = lane * 4; k < a.K; k += 256) {
+    float4 wv[SK_COLS], xv[SK_ROWS];
+#pragma unroll
+    for (int j = 0; j < SK_COLS; ++j) wv[j] = *reinterpret_cast<const float4*>(wr[j] + k);
+#pragma unroll
+    for (int r = 0; r < SK_ROWS; ++r) xv[r] = *reinterpret_cast<const float4*>(xr[r] + k);
+#pragma unroll
+    for (int r = 0; r < SK_ROWS; ++r)
+#pragma unroll
+      for (int j = 0; j < SK_COLS; ++j) {
+        acc[r][j] = fmaf(xv[r].x, wv[j].x, acc[r][j]);
+        acc[r][j] = fmaf(xv[r].y, wv[j].y, acc[r][j]);
+        acc[r][j] = fmaf(xv[r].z, wv[j].z, acc[r][j]);
+        acc[r][j] = fmaf(xv[r].w, wv[j].w, acc[r][j]);
+      }
+  }
+  float mine = 0.f;
+#pragma unroll
+  for (int r = 0; r < SK_ROWS; ++r)
+#pragma unroll
+    for (int j = 0; j < SK_COLS; ++j) {
+      acc[r][j] = wave_sum(acc[r][j]);  // (xor butterfly: every lane ends with the same sum)
+      if (lane == r * SK_COLS + j) mine = acc[r][j];
+    }
+  if (lane < SK_ROWS * SK_COLS) {
+    const int r = lane / SK_COLS, j = lane - r * SK_COLS;
+    if (m0 + r < a.M && o0 + j < a.O) Y[(long)(m0 + r) * a.ldy + o0 + j] = mine;
+  }
+  if (a.stat_partial != nullptr && lane < SK_COLS && o0 + lane < a.O) {
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int r = 0; r < SK_ROWS; ++r) {
+      float v = 0.f;
+#pragma unroll
+      for (int j = 0; j < SK_COLS; ++j) v = lane == j ? acc[r][j] : v;
+      if (m0 + r < a.M) {
+        s1 += v;
+        s2 = fmaf(v, v, s2);
+      }
+    }
+    a.stat_partial[((long)mc * 2 + 0) * a.O + o0 + lane] = s1;
+    a.stat_partial[((long)mc * 2 + 1) * a.O + o0 + lane] = s2;
+  }
+}
+
+static int launch_conv_gemm_skinny(const ConvGemmArgs& a, hipStream_t stream) {
+  const int ogs = (a.O + SK_COLS - 1) / SK_COLS, mcs = (a.M + SK_ROWS - 1) / SK_ROWS;
+  const int nwaves = ogs * mcs;
+  hipLaunchKernelGGL(conv_gemm_skinny_kernel, dim3((nwaves + 3) / 4), dim3(256), 0, stream, a, ogs,
+                     nwaves);
+  return check_launch("conv_gemm_fwd (skinny)");
+}
+
 // 1x1 stride-1 convs: 0 = first-generation 128x128 kernel, 1 = 256x128 kernel
 // (conv_gemm_px256.hip), 2 = direct-to-LDS 256x256 kernel where it applies (conv_gemm_glds.hip:
 // bf16, no prologue), 256x128 otherwise
@@ -363,6 +451,8 @@ extern "C" int seg_conv_gemm_stat_rows(int dtype, int N, int Ho, int Wo, int C, 
                                        int KW, int stride, int pad, int dil, int tconv,
                                        int has_bias, int pro_mode) {
   const long M = (long)N * Ho * Wo;
+  if (seg::skinny_geometry(dtype, M, C, KH, KW, stride, pad, tconv, has_bias, pro_mode))
+    return (int)((M + seg::SK_ROWS - 1) / seg::SK_ROWS);
   if (seg::g_gemm_px256 && gemm_use_px256(KH, KW, stride, pad, tconv, O, M)) {
     // the direct-to-LDS kernel (bf16, no prologue / bias: conv_gemm_glds_usable up to the pitch
     // checks, which seg_conv_gemm_fwd settles by zero-filling the rows a fallback leaves out)
@@ -427,6 +517,19 @@ extern "C" int seg_conv_gemm_fwd(int dtype, const void* x, long ldx, int N, int 
     a.tiles_n = (O + 63) / 64;
   }
   SEG_REQUIRE(out_s == 1 || stat_partial == nullptr, "conv_gemm_fwd: no statistics with scatter");
+  if (out_s == 1 && skinny_geometry(dtype, a.M, C, KH, KW, stride, pad, tconv, bias != nullptr,
+                                    pro_mode)) {
+    if (ep_x == nullptr) return launch_conv_gemm_skinny(a, (hipStream_t)stream);
+    // (a correction epilogue on a handful of pixels: the tile kernel below writes ONE statistics
+    // row where seg_conv_gemm_stat_rows promised one per 8 pixels — the others read as zero)
+    const int promised = (a.M + SK_ROWS - 1) / SK_ROWS;
+    if (stat_partial != nullptr && promised > 1 &&
+        hipMemsetAsync(stat_partial + 2L * O, 0, (size_t)(promised - 1) * 2 * O * sizeof(float),
+                       (hipStream_t)stream) != hipSuccess) {
+      set_error("conv_gemm_fwd: cannot clear the unused statistics rows");
+      return 2;
+    }
+  }
   if (g_gemm_px256 && gemm_use_px256(KH, KW, stride, pad, tconv, O, a.M) && out_s == 1) {
     if (g_gemm_px256 >= 2 && conv_gemm_glds_usable(dtype, a))
       return launch_conv_gemm_glds(a, (hipStream_t)stream);

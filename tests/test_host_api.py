@@ -273,6 +273,11 @@ def test_kernel_selection_queries_of_the_c_library():
     assert _g4_rows(2 * 65 * 129, 728) == 66 and _g4_rows(2 * 65 * 129, 1024) == 88
     assert q("seg_conv_gemm_stat_rows", BF16, 2, 65, 129, 728, 728, 1, 1, 1, 0, 1, 0, 1, 0) == (2 * 65 * 129 + 255) // 256
     assert q("seg_conv_gemm_stat_rows", F32, 2, 65, 129, 728, 728, 1, 1, 1, 0, 1, 0, 0, 0) == (2 * 65 * 129 + 255) // 256
+    # a handful of pixels in float32 (ASPP image pooling, PSP bins): one row per 8-pixel chunk
+    assert q("seg_conv_gemm_stat_rows", F32, 2, 1, 1, 2048, 256, 1, 1, 1, 0, 1, 0, 0, 0) == 1
+    assert q("seg_conv_gemm_stat_rows", F32, 2, 6, 6, 2048, 512, 1, 1, 1, 0, 1, 0, 0, 0) == 9
+    assert q("seg_conv_gemm_stat_rows", BF16, 2, 6, 6, 2048, 512, 1, 1, 1, 0, 1, 0, 0, 0) == 1
+    assert q("seg_conv_gemm_stat_rows", F32, 2, 6, 6, 2048, 512, 1, 1, 1, 0, 1, 0, 0, 3) == 1
     # ResNet layer3 3x3 (256 -> 256, dilation 2) without a prologue: the direct-to-LDS pipeline
     # as an implicit GEMM (256-pixel tiles); with a pending BatchNorm/ReLU: first generation
     Mr = 2 * 129 * 257

@@ -53,6 +53,11 @@ CONV_CASES = [
     (2, 13, 11, 8, 32, 3, 2, 1, 1, 0, False, False),      # stem on channel-padded input
     (1, 10, 14, 16, 24, 3, 1, 2, 2, 2, False, True),      # dilated dense
     (2, 1, 1, 2048, 256, 1, 1, 0, 1, 0, False, False),    # ASPP image-pooling (M = batch)
+    # ... a handful of pixels in float32 on the lanes-split-K kernel (r05): PSP pyramid bins
+    # (ragged pixel chunk, ragged channel group + slice output), K not a multiple of 256
+    (2, 6, 6, 2048, 512, 1, 1, 0, 1, 0, False, False),
+    (2, 3, 3, 512, 2047, 1, 1, 0, 1, 0, False, True),
+    (1, 1, 3, 264, 6, 1, 1, 0, 1, 0, False, False),
     (2, 7, 9, 4096, 512, 3, 1, 1, 1, 0, False, False),    # PSP head: K = 36864
     (2, 37, 45, 8, 64, 7, 2, 3, 1, 0, False, False),      # ResNet stem 7x7 s2 p3 (resnet.py:116)
     (1, 29, 31, 8, 64, 7, 2, 3, 1, 2, False, True),       # the same on bf16 padding, prologue
