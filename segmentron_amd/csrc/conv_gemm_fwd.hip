@@ -435,6 +435,8 @@ static int launch_conv_gemm_fwd(const ConvGemmArgs& a, hipStream_t stream) {
 // 419 -> 487, 1536->2048 675 -> 675, 304->256 @257x513 434 -> 430, 128->128 @513x1025 326 -> 315)
 // (r02: also O >= 256 when there are >= 256 pixel tiles — the decoder's 304->256 / 256->256
 // convs at 257x513: one 256-wide column tile per 256-pixel tile still fills the chip four times)
+// (r05: O >= 224 there was tried for HRNet's biased 240 -> 240 last layer at 16 x 256 x 512
+// pixels: 866 us on this kernel against 592 on the 128x128 one)
 static bool gemm_use_px256(int KH, int KW, int stride, int pad, int tconv, int O, long M) {
   return KH * KW == 1 && stride == 1 && pad == 0 && !tconv &&
          ((O >= 384 && M >= 4096) || (O >= 256 && M >= 65536));

@@ -195,6 +195,59 @@ __global__ __launch_bounds__(RS_THREADS) void upsample_to_nchw_kernel(const Resi
   }
 }
 
+// ... four consecutive output columns per thread -> 16-byte plane stores (r05: the inference
+// configs write 0.15 - 2.5 GB of float32 logits through this kernel; dword stores reached
+// 3.2 TB/s).  Same per-output arithmetic as above, bit for bit.  Wo % 4 == 0, out 16-byte aligned.
+template <typename T>
+__global__ __launch_bounds__(RS_THREADS) void upsample_to_nchw_v4_kernel(const ResizeArgs a,
+                                                                         float* __restrict__ out) {
+  constexpr int VEC = Vec<T>::N;
+  const T* __restrict__ X = reinterpret_cast<const T*>(a.x);
+  const int wq = a.Wo >> 2;
+  const long total = (long)a.N * a.Ho * wq;
+  const long plane = (long)a.Ho * a.Wo;
+  for (long i = (long)blockIdx.x * RS_THREADS + threadIdx.x; i < total;
+       i += (long)gridDim.x * RS_THREADS) {
+    long p = i;
+    const int wo0 = (int)(p % wq) * 4; p /= wq;
+    const int ho = (int)(p % a.Ho);
+    const int n = (int)(p / a.Ho);
+    int h0, h1; float lh;
+    taps(a.sh, ho, a.Hi, a.align, h0, h1, lh);
+    int w0[4], w1[4]; float lw[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) taps(a.sw, wo0 + j, a.Wi, a.align, w0[j], w1[j], lw[j]);
+    const long base = (long)n * a.Hi * a.Wi;
+    const T* r0 = X + (base + (long)h0 * a.Wi) * a.ldx;
+    const T* r1 = X + (base + (long)h1 * a.Wi) * a.ldx;
+    float* o = out + (long)n * a.C * plane + (long)ho * a.Wo + wo0;
+    for (int cv = 0; cv < a.CV; ++cv) {
+      const int c0 = cv * VEC;
+      float res[4][VEC];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float f00[VEC], f01[VEC], f10[VEC], f11[VEC];
+        Vec<T>::unpack(ldg16(r0 + (long)w0[j] * a.ldx + c0), f00);
+        Vec<T>::unpack(ldg16(r0 + (long)w1[j] * a.ldx + c0), f01);
+        Vec<T>::unpack(ldg16(r1 + (long)w0[j] * a.ldx + c0), f10);
+        Vec<T>::unpack(ldg16(r1 + (long)w1[j] * a.ldx + c0), f11);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+          const float top = (1.f - lw[j]) * f00[k] + lw[j] * f01[k];
+          const float bot = (1.f - lw[j]) * f10[k] + lw[j] * f11[k];
+          res[j][k] = (1.f - lh) * top + lh * bot;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) {
+        if (c0 + k < a.C)
+          *reinterpret_cast<float4*>(o + (long)(c0 + k) * plane) =
+              make_float4(res[0][k], res[1][k], res[2][k], res[3][k]);
+      }
+    }
+  }
+}
+
 // gx NHWC (T, padded channels written as 0) <- gy NCHW fp32
 template <typename T>
 __global__ __launch_bounds__(RS_THREADS) void upsample_to_nchw_bwd_kernel(
@@ -413,6 +466,16 @@ extern "C" int seg_upsample_to_nchw(int dtype, const void* x, long ldx, int N, i
   ResizeArgs a;
   if (fill_args(a, dtype, x, ldx, N, Hi, Wi, C, nullptr, 0, Ho, Wo, align_corners, false)) return 1;
   SEG_REQUIRE(ldx >= (long)a.CV * (dtype == DT_BF16 ? 8 : 4), "upsample_to_nchw: ldx too small");
+  if (Wo % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
+    const int grid4 = rs_grid((long)N * Ho * (Wo / 4));
+    if (dtype == DT_BF16)
+      hipLaunchKernelGGL((upsample_to_nchw_v4_kernel<bf16_t>), dim3(grid4), dim3(RS_THREADS), 0,
+                         (hipStream_t)stream, a, out);
+    else
+      hipLaunchKernelGGL((upsample_to_nchw_v4_kernel<float>), dim3(grid4), dim3(RS_THREADS), 0,
+                         (hipStream_t)stream, a, out);
+    return check_launch("upsample_to_nchw");
+  }
   const int grid = rs_grid((long)N * Ho * Wo);
   if (dtype == DT_BF16)
     hipLaunchKernelGGL((upsample_to_nchw_kernel<bf16_t>), dim3(grid), dim3(RS_THREADS), 0,

@@ -65,6 +65,8 @@ CONV_CASES = [
     (2, 45, 47, 728, 728, 1, 1, 0, 1, 0, False, False),
     (1, 65, 67, 200, 392, 1, 1, 0, 1, 3, False, True),
     (2, 33, 63, 264, 1000, 1, 1, 0, 1, 2, True, False),
+    # HRNet's 240 -> 240 last layer geometry (>= 65536 pixels, O just below the wide kernels)
+    (1, 257, 259, 64, 240, 1, 1, 0, 1, 0, False, False),
     # 256x64-tile general path (KxK, O <= 64, M >= 16384): ragged M, prologue + statistics,
     # the conv2 data-gradient shape (64 -> 32), a strided stem, a slice output with ragged O
     (1, 131, 129, 32, 64, 3, 1, 1, 1, 3, False, False),
@@ -123,8 +125,9 @@ def test_conv_gemm_fwd(case, dtype):
             (C, O) in ((32, 32), (32, 64), (64, 32), (16, 16))
         glds_kxk = k > 1 and stride == 1 and C % 32 == 0 and O >= 256 and M >= 4096 \
             and mode == 0 and not bias
-        if dtype == torch.bfloat16 and (direct or glds_kxk or (k == 1 and stride == 1 and pad == 0
-                                                               and O >= 384 and M >= 4096)):
+        wide = k == 1 and stride == 1 and pad == 0 and ((O >= 384 and M >= 4096)
+                                                        or (O >= 256 and M >= 65536))
+        if dtype == torch.bfloat16 and (direct or glds_kxk or wide):
             # the 256x128, direct-to-LDS and direct-3x3 kernels take the statistics of the values AS STORED
             # (bf16-rounded):
             # that is the tensor the consumer's normalisation is applied to
@@ -584,7 +587,8 @@ def test_bilinear_fwd_bwd(case, dtype):
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
 @pytest.mark.parametrize("geom", [(9, 17, 33, 65, True), (16, 32, 64, 128, False),
-                                  (5, 7, 61, 83, False)])
+                                  (5, 7, 61, 83, False),
+                                  (9, 17, 35, 68, True)])  # Wo % 4 == 0: 16-byte plane stores
 def test_logits_upsample_to_nchw_fwd_bwd(geom, dtype):
     Hi, Wi, Ho, Wo, ac = geom
     N, C = 2, 19
