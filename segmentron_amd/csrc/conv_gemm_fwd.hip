@@ -318,10 +318,7 @@ __global__ __launch_bounds__(GEMM_THREADS, (DBUF || !FAST) ? 2 : 3) void conv_ge
 // Here a wave owns 8 pixels x 4 output channels, lanes split K (16 bytes per lane and row), every
 // row is read once per wave straight from L2; butterfly reduction, lane (r, j) stores.  The
 // BatchNorm partial rows: one per 8-pixel chunk (seg_conv_gemm_stat_rows agrees).
-#ifndef SK_MAX_M_V
-#define SK_MAX_M_V 128
-#endif
-constexpr int SK_ROWS = 8, SK_COLS = 4, SK_MAX_M = SK_MAX_M_V;
+constexpr int SK_ROWS = 8, SK_COLS = 4, SK_MAX_M = 128;
 
 static bool skinny_geometry(int dtype, long M, int C, int KH, int KW, int stride, int pad,
                             int tconv, int has_bias, int pro_mode) {

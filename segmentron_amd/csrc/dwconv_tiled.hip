@@ -24,10 +24,7 @@ constexpr int LT_TH = 8, LT_TW = 16, LT_CVB = 8, LT_THREADS = 256;
 #ifndef DW_BWD_OCC
 #define DW_BWD_OCC 2
 #endif
-#ifndef DW_BWD_REM_PCT_V
-#define DW_BWD_REM_PCT_V 6
-#endif
-constexpr int DW_BWD_REM_PCT = DW_BWD_REM_PCT_V;
+constexpr int DW_BWD_REM_PCT = 6;
 
 struct DwTiledArgs {
   const void* x;       // tensor the taps read (fwd: input, dgrad: dy)
