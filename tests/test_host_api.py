@@ -259,6 +259,9 @@ def test_kernel_selection_queries_of_the_c_library():
     M = 2 * 513 * 1025
     assert q("seg_conv_gemm_stat_rows", BF16, 2, 513, 1025, 32, 64, 3, 3, 1, 1, 1, 0, 0, 3) == 512
     assert q("seg_conv_gemm_stat_rows", F32, 2, 513, 1025, 32, 64, 3, 3, 1, 1, 1, 0, 0, 3) == (M + 255) // 256
+    # HRNet's 16 -> 16 basic blocks (r05): the same kernel with four persistent blocks per CU
+    assert q("seg_conv_gemm_stat_rows", BF16, 16, 256, 512, 16, 16, 3, 3, 1, 1, 1, 0, 0, 3) == 1024
+    assert q("seg_conv_gemm_stat_rows", BF16, 1, 64, 128, 16, 16, 3, 3, 1, 1, 1, 0, 0, 0) == (64 * 128 + 127) // 128  # < 65536 pixels
     # a bias keeps the conv on the implicit GEMM; dilation 2 likewise
     assert q("seg_conv_gemm_stat_rows", BF16, 2, 513, 1025, 32, 64, 3, 3, 1, 1, 1, 0, 1, 0) == (M + 255) // 256
     assert q("seg_conv_gemm_stat_rows", BF16, 2, 513, 1025, 32, 64, 3, 3, 1, 2, 2, 0, 0, 0) == (M + 255) // 256
