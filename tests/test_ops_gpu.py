@@ -474,8 +474,12 @@ def test_eval_affine_of_many_batchnorms_in_one_launch_and_cache_invalidation():
         Fm.eval_affine(bn)
     Fm.clear_weight_cache()
     misses = Fm._MISSES[0]
+    Fm.eval_affine(bns[0])
+    after_first = Fm._MISSES[0]
     got = [Fm.eval_affine(bn) for bn in bns]
-    assert Fm._MISSES[0] - misses == len(bns)   # ONE request packed all of them
+    # ONE request packed all of them (>=: evaluation-mode BatchNorms of earlier tests that are
+    # still alive in this process are planned too and ride along)
+    assert Fm._MISSES[0] == after_first and after_first - misses >= len(bns)
     for bn, (sc, sh) in zip(bns, got):
         es, et = K().bn_eval_affine(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
         assert torch.equal(sc, es) and torch.equal(sh, et)
