@@ -17,6 +17,7 @@
 // blockIdx.y (deterministic: LDS tree over the strips of a block, fp64 finish in bn_finalize).
 #include "common.h"
 #include "dwconv_tiled.h"
+#include "dwconv_slide.h"
 #include <cstdlib>
 #include <type_traits>
 
@@ -467,6 +468,9 @@ extern "C" int seg_dwconv_grid_y(int dtype, int C, int N, int Ho, int Wo, int st
                                  int kind) {
   using namespace seg;
   const int tiled_stride = kind == 0 ? stride : 1;  // kinds 1/2 describe a stride-1 layer's backward
+  // r06: stride 1 / dilation 1 forward and fused backward on the register-sliding kernels
+  if ((kind == 0 || kind == 1) && dw_slide_supported(stride, dil, C))
+    return dw_slide_rows(C, N, Ho, Wo);
   if ((kind == 0 || stride == 1) && dw_tiled_supported(tiled_stride, dil))
     return dw_tiled_grid_y(dtype, C, N, Ho, Wo, kind);
   if (kind == 0 && stride == 2 && dil == 1)  // LDS-tiled stride-2 forward
@@ -498,6 +502,11 @@ extern "C" int seg_dwconv3x3(int dtype, int mode, const void* x, long ldx, int N
               "dwconv3x3: affine prologue without scale/shift");
   SEG_REQUIRE(mode == MODE_FWD || stat_partial == nullptr, "dwconv3x3: stats only in forward");
   SEG_REQUIRE(grid_y >= 1, "dwconv3x3: grid_y must be >= 1");
+  if (mode == MODE_FWD && dw_slide_supported(stride, dil, C)) {
+    SEG_REQUIRE(Ho == Hi && Wo == Wi, "dwconv3x3: stride 1 keeps the size");
+    return launch_dw_slide_fwd(dtype, x, ldx, N, Hi, Wi, C, w9c, w_layout, pro_mode, pro_scale,
+                               pro_shift, y, ldy, stat_partial, grid_y, (hipStream_t)stream);
+  }
   if (mode == MODE_FWD && dw_tiled_supported(stride, dil)) {  // incl. stride-1 dgrad (flipped taps)
     SEG_REQUIRE(Ho == Hi && Wo == Wi, "dwconv3x3: stride 1 keeps the size");
     return launch_dw_tiled(dtype, x, ldx, N, Hi, Wi, C, w9c, w_layout, dil, pro_mode, pro_scale,
@@ -599,6 +608,10 @@ extern "C" int seg_dwconv3x3_bwd_fused_add(int dtype, const void* dy, long lddy,
   SEG_REQUIRE(((pro_mode & PRO_AFFINE) == 0) || (pro_scale && pro_shift),
               "dwconv3x3_bwd_fused_add: affine prologue without scale/shift");
   SEG_REQUIRE(grid_y >= 1 && partial_w != nullptr, "dwconv3x3_bwd_fused_add: bad grid/partials");
+  if (dw_slide_supported(1, 1, C))
+    return launch_dw_slide_bwd(dtype, dy, lddy, x, ldx, N, H, W, C, w9c, w_layout, pro_mode,
+                               pro_scale, pro_shift, g, ldg, partial_w, partial_bn, grid_y,
+                               (hipStream_t)stream, res, ldr);
   return launch_dw_bwd_tiled(dtype, dy, lddy, x, ldx, N, H, W, C, w9c, w_layout, 1, pro_mode,
                              pro_scale, pro_shift, g, ldg, partial_w, partial_bn, grid_y,
                              (hipStream_t)stream, res, ldr);
@@ -618,6 +631,10 @@ extern "C" int seg_dwconv3x3_bwd_fused(int dtype, const void* dy, long lddy, con
   SEG_REQUIRE(((pro_mode & PRO_AFFINE) == 0) || (pro_scale && pro_shift),
               "dwconv3x3_bwd_fused: affine prologue without scale/shift");
   SEG_REQUIRE(grid_y >= 1 && partial_w != nullptr, "dwconv3x3_bwd_fused: bad grid/partials");
+  if (dw_slide_supported(1, dil, C))
+    return launch_dw_slide_bwd(dtype, dy, lddy, x, ldx, N, H, W, C, w9c, w_layout, pro_mode,
+                               pro_scale, pro_shift, g, ldg, partial_w, partial_bn, grid_y,
+                               (hipStream_t)stream);
   if (dw_tiled_supported(1, dil)) {
     const int tvec = dtype == DT_BF16 ? 8 : 4;
     SEG_REQUIRE(C % tvec == 0 && ldx % tvec == 0 && lddy % tvec == 0 && ldg % tvec == 0,

@@ -77,7 +77,16 @@ int main(int argc, char** argv) {
   const int PRO_RELU = 1, PRO_AFFINE_RELU = 3, DT_BF16 = 1;
   double tot[2][2] = {{0, 0}, {0, 0}};
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  const char* only = getenv("DW_AB_SHAPES");  // e.g. "6" or "1,6": indices into shapes[]
+  int shape_idx = -1;
   for (auto& sh : shapes) {
+    ++shape_idx;
+    if (only) {
+      bool hit = false;
+      for (const char* q = only; *q; ++q)
+        if (*q >= '0' && *q <= '9' && (*q - '0') == shape_idx && (q == only || q[-1] == ',') && (q[1] == 0 || q[1] == ',')) hit = true;
+      if (!hit) continue;
+    }
     const int N = sh[0], H = sh[1], W = sh[2], C = sh[3], per_step = sh[4];
     const long elems = (long)N * H * W * C;
     void *x, *dy, *y[2], *g[2]; float *w, *sc, *shf;
