@@ -19,7 +19,14 @@
 namespace seg {
 
 constexpr int EW_THREADS = 256;
-constexpr int EW_UN = 4;  // rows per thread per iteration in the row-tile kernels
+constexpr int EW_MAX_THREADS = 512;  // the row-tile kernels: rows x channel vectors of a block (ew_geom)
+#ifndef EW_UN_V
+#define EW_UN_V 4
+#endif
+#ifndef EW_CAP
+#define EW_CAP 512
+#endif
+constexpr int EW_UN = EW_UN_V;  // rows per thread per iteration in the row-tile kernels
 
 // ------------------------------------------------------------------ column sums of partials
 // in [R][L] fp32 -> out[gridDim.y][L] (fp64 or fp32)
@@ -155,7 +162,7 @@ struct ApplyArgs {
   long M; int C, CV;
   int mode_x, mode_r, post_relu;
   long rows_per_n;
-  int cvb_log2;
+  int lpr, rpb;  // lanes (channel vectors) per row of a block, rows per block (ew_geom)
 };
 
 // Row-tile mapping shared by the element-wise kernels: a thread owns ONE 16-byte channel vector
@@ -190,13 +197,12 @@ __device__ __forceinline__ void act_regs(float* f, int mode, const float* sc, co
 }
 
 template <typename T>
-__global__ __launch_bounds__(EW_THREADS) void bn_apply_kernel(const ApplyArgs a) {
+__global__ __launch_bounds__(EW_MAX_THREADS) void bn_apply_kernel(const ApplyArgs a) {
   constexpr int VEC = Vec<T>::N;
-  const int cvb = 1 << a.cvb_log2;
-  const int cx = threadIdx.x & (cvb - 1), sy = threadIdx.x >> a.cvb_log2;
-  const int rpb = EW_THREADS >> a.cvb_log2;
+  const int cvb = a.lpr, rpb = a.rpb;
+  const int sy = threadIdx.x / cvb, cx = threadIdx.x - sy * cvb;
   const int cv = blockIdx.x * cvb + cx;
-  if (cv >= a.CV) return;
+  if (cv >= a.CV || sy >= rpb) return;
   const int c0 = cv * VEC;
   const T* __restrict__ X = reinterpret_cast<const T*>(a.x);
   const T* __restrict__ R = reinterpret_cast<const T*>(a.r);
@@ -263,7 +269,7 @@ struct BwdArgs {
   long ldg, ldx, lddx;
   long M; int C, CV;
   int mode;  // PRO_* of the forward prologue this is the backward of
-  int cvb_log2;
+  int lpr, rpb;  // lanes (channel vectors) per row of a block, rows per block (ew_geom)
 };
 
 template <typename T>
@@ -306,13 +312,12 @@ __device__ __forceinline__ void masked_grad(const BwdArgs& a, const BwdRaw<T>& r
 }
 
 template <typename T>
-__global__ __launch_bounds__(EW_THREADS) void bn_bwd_reduce_kernel(const BwdArgs a) {
+__global__ __launch_bounds__(EW_MAX_THREADS) void bn_bwd_reduce_kernel(const BwdArgs a) {
   constexpr int VEC = Vec<T>::N;
   extern __shared__ __attribute__((aligned(16))) float bn_smem[];
   const int tid = threadIdx.x;
-  const int cvb = 1 << a.cvb_log2;
-  const int cx = tid & (cvb - 1), sy = tid >> a.cvb_log2;
-  const int spb = EW_THREADS >> a.cvb_log2;
+  const int cvb = a.lpr, spb = a.rpb;
+  const int sy = tid / cvb, cx = tid - sy * cvb;
   const int cv = blockIdx.x * cvb + cx;
   const int c0 = cv * VEC;
   const T* __restrict__ G = reinterpret_cast<const T*>(a.g);
@@ -320,7 +325,7 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_reduce_kernel(const BwdArgs
   float s1[VEC], s2[VEC];
 #pragma unroll
   for (int k = 0; k < VEC; ++k) s1[k] = s2[k] = 0.f;
-  if (cv < a.CV) {
+  if (cv < a.CV && sy < spb) {
     float sc[VEC], sh[VEC];
     load_affine<VEC>(a.mode, a.scale, a.shift, c0, sc, sh);
     const int M = (int)a.M, tile = spb * EW_UN, step = gridDim.y * tile;
@@ -350,7 +355,7 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_reduce_kernel(const BwdArgs
     mine[VEC + k] = s2[k];
   }
   __syncthreads();
-  for (int e = tid; e < cvb * 2 * VEC; e += EW_THREADS) {
+  for (int e = tid; e < cvb * 2 * VEC; e += (int)blockDim.x) {
     float tot = 0.f;
     for (int r = 0; r < spb; ++r) tot += bn_smem[(long)r * cvb * 2 * VEC + e];
     const int lcx = e / (2 * VEC), k = e % (2 * VEC);
@@ -387,13 +392,12 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ sums, double c
 }
 
 template <typename T>
-__global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_kernel(const BwdArgs a) {
+__global__ __launch_bounds__(EW_MAX_THREADS) void bn_bwd_apply_kernel(const BwdArgs a) {
   constexpr int VEC = Vec<T>::N;
-  const int cvb = 1 << a.cvb_log2;
-  const int cx = threadIdx.x & (cvb - 1), sy = threadIdx.x >> a.cvb_log2;
-  const int rpb = EW_THREADS >> a.cvb_log2;
+  const int cvb = a.lpr, rpb = a.rpb;
+  const int sy = threadIdx.x / cvb, cx = threadIdx.x - sy * cvb;
   const int cv = blockIdx.x * cvb + cx;
-  if (cv >= a.CV) return;
+  if (cv >= a.CV || sy >= rpb) return;
   const int c0 = cv * VEC;
   const T* __restrict__ G = reinterpret_cast<const T*>(a.g);
   const T* __restrict__ X = reinterpret_cast<const T*>(a.x);
@@ -779,17 +783,39 @@ static int pick_cvb_log2_ew(int CV) {
   return best;
 }
 
-// 2-D launch geometry of the row-tile kernels: x over channel-vector blocks, y over row groups
-static dim3 ew_grid2(int CV, long M, int& cvb_log2) {
-  cvb_log2 = pick_cvb_log2_ew(CV);
-  const int gx = (CV + (1 << cvb_log2) - 1) >> cvb_log2;
-  const int rpb = EW_THREADS >> cvb_log2;
-  long gy = (M + (long)rpb * EW_UN - 1) / ((long)rpb * EW_UN);  // one batch of EW_UN rows per thread
-  long cap = 8192 / gx;
+// Launch geometry of the row-tile kernels.  r06: a block covers WHOLE rows whenever a row has more
+// than 32 channel vectors (C > 256 in bf16).  With power-of-two column blocks the 91 vectors of a
+// 728-channel row were split over three blocks (512 + 512 + 432 bytes of every 1456-byte pixel,
+// one block each): bn_bwd_apply moved its 73 MB at 4.6 TB/s where a flat 2-read-1-write stream
+// of the same bytes runs at 6.9 TB/s (tools/lab/wb_lab).  Now lanes = the row's vectors, rows per
+// block chosen so that rows x vectors fills a multiple of 64 threads (<= 512) best: a block
+// iteration reads EW_UN x rows x C contiguous elements.
+struct EwGeom { int lpr, rpb, threads, gx; };
+static EwGeom ew_geom(int CV) {
+  EwGeom g;
+  if (CV <= 32 || CV > EW_MAX_THREADS) {
+    const int l = pick_cvb_log2_ew(CV);
+    g.lpr = 1 << l; g.rpb = EW_THREADS >> l; g.threads = EW_THREADS;
+    g.gx = (CV + g.lpr - 1) >> l;
+    return g;
+  }
+  g.lpr = CV; g.gx = 1; g.rpb = 1; g.threads = ((CV + 63) / 64) * 64;
+  double best = -1.0;
+  for (int r = 1; r * CV <= EW_MAX_THREADS; ++r) {
+    const int t = ((r * CV + 63) / 64) * 64;
+    // lane utilisation first, then a block near 256-384 threads
+    const double score = (double)(r * CV) / t - 0.02 * (t < 256 ? (256 - t) / 256.0 : t > 384 ? (t - 384) / 384.0 : 0.0);
+    if (score > best + 1e-9) { best = score; g.rpb = r; g.threads = t; }
+  }
+  return g;
+}
+static dim3 ew_grid2(const EwGeom& g, long M) {
+  long gy = (M + (long)g.rpb * EW_UN - 1) / ((long)g.rpb * EW_UN);  // one batch of EW_UN rows per thread
+  long cap = EW_CAP / g.gx;
   if (cap < 1) cap = 1;
   if (gy > cap) gy = cap;
   if (gy < 1) gy = 1;
-  return dim3(gx, (unsigned)gy);
+  return dim3(g.gx, (unsigned)gy);
 }
 
 }  // namespace seg
@@ -896,17 +922,16 @@ struct SumNArgs {
   long ld[SUMN_MAX];
   void* y;
   long ldy, M;
-  int n, CV, cvb_log2;
+  int n, CV, lpr, rpb;
 };
 
 template <typename T>
-__global__ __launch_bounds__(EW_THREADS) void sum_n_kernel(const SumNArgs a) {
+__global__ __launch_bounds__(EW_MAX_THREADS) void sum_n_kernel(const SumNArgs a) {
   constexpr int VEC = Vec<T>::N;
-  const int cvb = 1 << a.cvb_log2;
-  const int cx = threadIdx.x & (cvb - 1), sy = threadIdx.x >> a.cvb_log2;
-  const int rpb = EW_THREADS >> a.cvb_log2;
+  const int cvb = a.lpr, rpb = a.rpb;
+  const int sy = threadIdx.x / cvb, cx = threadIdx.x - sy * cvb;
   const int cv = blockIdx.x * cvb + cx;
-  if (cv >= a.CV) return;
+  if (cv >= a.CV || sy >= rpb) return;
   const int c0 = cv * VEC;
   T* __restrict__ Y = reinterpret_cast<T*>(a.y);
   const int M = (int)a.M, step = gridDim.y * rpb;
@@ -951,12 +976,14 @@ extern "C" int seg_bn_apply(int dtype, const void* x, long ldx, int mode_x, cons
   a.mode_x = mode_x; a.mode_r = mode_r; a.post_relu = post_relu;
   a.rows_per_n = rows_per_n > 0 ? rows_per_n : 1;
   SEG_REQUIRE(M < (1L << 31), "bn_apply: M overflows int");
-  const dim3 grid = ew_grid2(a.CV, M, a.cvb_log2);
+  const EwGeom geo = ew_geom(a.CV);
+  a.lpr = geo.lpr; a.rpb = geo.rpb;
+  const dim3 grid = ew_grid2(geo, M);
   if (dtype == DT_BF16)
-    hipLaunchKernelGGL((bn_apply_kernel<bf16_t>), grid, dim3(EW_THREADS), 0,
+    hipLaunchKernelGGL((bn_apply_kernel<bf16_t>), grid, dim3(geo.threads), 0,
                        (hipStream_t)stream, a);
   else
-    hipLaunchKernelGGL((bn_apply_kernel<float>), grid, dim3(EW_THREADS), 0,
+    hipLaunchKernelGGL((bn_apply_kernel<float>), grid, dim3(geo.threads), 0,
                        (hipStream_t)stream, a);
   return check_launch("bn_apply");
 }
@@ -975,11 +1002,13 @@ extern "C" int seg_sum_n(int dtype, int n, const void* const* xs, const long* ld
     SEG_REQUIRE(k >= n || (xs[k] != nullptr && lds[k] % vec == 0 && lds[k] >= C), "sum_n: operand %d", k);
   }
   a.y = y; a.ldy = ldy; a.M = M; a.n = n; a.CV = C / vec;
-  const dim3 grid = ew_grid2(a.CV, M, a.cvb_log2);
+  const EwGeom geo = ew_geom(a.CV);
+  a.lpr = geo.lpr; a.rpb = geo.rpb;
+  const dim3 grid = ew_grid2(geo, M);
   if (dtype == DT_BF16)
-    hipLaunchKernelGGL((sum_n_kernel<bf16_t>), grid, dim3(EW_THREADS), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL((sum_n_kernel<bf16_t>), grid, dim3(geo.threads), 0, (hipStream_t)stream, a);
   else
-    hipLaunchKernelGGL((sum_n_kernel<float>), grid, dim3(EW_THREADS), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL((sum_n_kernel<float>), grid, dim3(geo.threads), 0, (hipStream_t)stream, a);
   return check_launch("sum_n");
 }
 
@@ -987,11 +1016,11 @@ extern "C" int seg_bn_bwd_grid_y(int dtype, int C, long M) {
   using namespace seg;
   const int vec = dtype == DT_BF16 ? 8 : 4;
   const int CV = C / vec;
-  const int l = pick_cvb_log2_ew(CV);
-  const int spb = EW_THREADS >> l;
-  const int gx = (CV + (1 << l) - 1) >> l;
+  const EwGeom geo = ew_geom(CV);
+  const int spb = geo.rpb, gx = geo.gx;
   long gy = (M + (long)spb * 8 - 1) / ((long)spb * 8);  // >= 8 rows per thread
   long cap = 2048 / gx;
+  if (cap > 1024) cap = 1024;  // (more rows than the one-launch finalize kernels take)
   if (cap < 1) cap = 1;
   if (gy > cap) gy = cap;
   if (gy < 1) gy = 1;
@@ -1015,14 +1044,16 @@ extern "C" int seg_bn_bwd_reduce(int dtype, const void* g, long ldg, const void*
   a.chan_mul = chan_mul; a.rows_per_n = rows_per_n > 0 ? rows_per_n : 1;
   a.elem_mul = elem_mul; a.ldm = ldm;
   a.partial = partial; a.ldg = ldg; a.ldx = ldx; a.lddx = 0; a.M = M; a.C = C; a.CV = C / vec;
-  a.mode = mode; a.cvb_log2 = pick_cvb_log2_ew(a.CV);
-  const int gx = (a.CV + (1 << a.cvb_log2) - 1) >> a.cvb_log2;
-  const size_t lds = (size_t)EW_THREADS * 2 * vec * sizeof(float);
+  a.mode = mode;
+  const EwGeom geo = ew_geom(a.CV);
+  a.lpr = geo.lpr; a.rpb = geo.rpb;
+  const int gx = geo.gx;
+  const size_t lds = (size_t)geo.threads * 2 * vec * sizeof(float);
   if (dtype == DT_BF16)
-    hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16_t>), dim3(gx, grid_y), dim3(EW_THREADS), lds,
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16_t>), dim3(gx, grid_y), dim3(geo.threads), lds,
                        (hipStream_t)stream, a);
   else
-    hipLaunchKernelGGL((bn_bwd_reduce_kernel<float>), dim3(gx, grid_y), dim3(EW_THREADS), lds,
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<float>), dim3(gx, grid_y), dim3(geo.threads), lds,
                        (hipStream_t)stream, a);
   return check_launch("bn_bwd_reduce");
 }
@@ -1098,12 +1129,14 @@ extern "C" int seg_bn_bwd_apply(int dtype, const void* g, long ldg, const void* 
   a.partial = nullptr; a.ldg = ldg; a.ldx = ldx; a.lddx = lddx; a.M = M; a.C = C; a.CV = C / vec;
   a.mode = mode;
   SEG_REQUIRE(M < (1L << 31), "bn_bwd_apply: M overflows int");
-  const dim3 grid = ew_grid2(a.CV, M, a.cvb_log2);
+  const EwGeom geo = ew_geom(a.CV);
+  a.lpr = geo.lpr; a.rpb = geo.rpb;
+  const dim3 grid = ew_grid2(geo, M);
   if (dtype == DT_BF16)
-    hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t>), grid, dim3(EW_THREADS), 0,
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t>), grid, dim3(geo.threads), 0,
                        (hipStream_t)stream, a);
   else
-    hipLaunchKernelGGL((bn_bwd_apply_kernel<float>), grid, dim3(EW_THREADS), 0,
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<float>), grid, dim3(geo.threads), 0,
                        (hipStream_t)stream, a);
   return check_launch("bn_bwd_apply");
 }

@@ -37,6 +37,24 @@ __global__ __launch_bounds__(256) void k_stream(const u32x4* __restrict__ in, u3
   }
 }
 
+// bn_bwd_apply-like: two reads + one write (73 MB on the 24.4 MB tensors), flat mapping
+__global__ __launch_bounds__(256) void k_stream2(const u32x4* __restrict__ g, const u32x4* __restrict__ x,
+                                                 u32x4* __restrict__ out, long n) {
+  const long i0 = (long)blockIdx.x * 1024 + threadIdx.x;
+  u32x4 a[4], b[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const long i = i0 + u * 256;
+    a[u] = i < n ? g[i] : u32x4{0, 0, 0, 0};
+    b[u] = i < n ? x[i] : u32x4{0, 0, 0, 0};
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const long i = i0 + u * 256;
+    if (i < n) { a[u].x += b[u].y; a[u].z ^= b[u].w; out[i] = a[u]; }
+  }
+}
+
 template <int MODE>
 __global__ __launch_bounds__(512) void k_gemmlike(const float* __restrict__ dep, u32x4* __restrict__ out,
                                                   long cycles) {
@@ -147,6 +165,16 @@ int main(int argc, char** argv) {
   CK(hipFuncSetAttribute((const void*)k_gemmlike<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
   CK(hipFuncSetAttribute((const void*)k_gemmlike<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
   printf("us per node-group, N = %d per graph, 24.4 MB tensors\n", N);
+  {
+    u32x4* c; CK(hipMalloc(&c, bytes)); CK(hipMemset(c, 0, bytes));
+    const int nb = (int)((n + 1023) / 1024);
+    hipGraphExec_t g2 = capture(s, [&] {
+      for (int i = 0; i < N; ++i)
+        hipLaunchKernelGGL(k_stream2, dim3(nb), dim3(256), 0, s, (i & 1) ? b : a, c, (i & 1) ? a : b, n);
+    });
+    const float t = replay_us(g2, s, 10, N);
+    printf("stream2 (2 reads + 1 write, 73.2 MB): %.2f us = %.2f TB/s\n", t, 3 * n * 16 / t * 1e-6);
+  }
   for (int rep = 0; rep < 2; ++rep) {
     run<0>(s, a, b, outv, n, cyc, N);
     run<1>(s, a, b, outv, n, cyc, N);

@@ -15,8 +15,8 @@ CLASSES = [
     ("forward / data-gradient convolutions, other (first-generation GEMM, px256, direct 3x3)",
      r"conv_gemm_fwd_kernel|conv_gemm_px256_kernel|conv3x3_direct_kernel"),
     ("weight-gradient GEMM", r"conv_wgrad_glds_kernel|conv_gemm_wgrad_kernel|conv3x3_wgrad_direct"),
-    ("depthwise forward", r"dwconv_tiled_kernel|dwconv_tiled_s2_kernel|dwconv_row_kernel<[^>]*false>|dwconv_kernel"),
-    ("depthwise fused backward", r"dwconv_bwd|dwconv_row_kernel<[^>]*true>|dwconv_wgrad|dwconv_dgrad"),
+    ("depthwise forward", r"dwconv_slide_fwd|dwconv_tiled_kernel|dwconv_tiled_s2_kernel|dwconv_row_kernel<[^>]*false>|dwconv_kernel"),
+    ("depthwise fused backward", r"dwconv_slide_bwd|dwconv_bwd|dwconv_row_kernel<[^>]*true>|dwconv_wgrad|dwconv_dgrad"),
     ("BatchNorm element-wise passes (apply, backward apply / reduce, n-ary gradient sum)",
      r"bn_apply_kernel|bn_bwd_apply_kernel|bn_bwd_reduce_kernel|sum_n_kernel"),
     ("finalize / fold / column-sum micro-kernels",
