@@ -32,9 +32,13 @@ def inputs(batch, h, w, seed=0):
     return synth.synth_images(batch, h, w, seed=seed), synth.synth_targets(batch, h, w, seed=seed)
 
 
+AUX_WEIGHT = 0.4  # cfg.SOLVER.AUX_WEIGHT default (segmentron/config/settings.py)
+
+
 def oracle_step(sd, x, y, dtype=torch.float32, oracle_fn="deeplabv3_plus_xception65", **net_kw):
     """One oracle train step (forward + MixSoftmaxCrossEntropyLoss + backward) ->
-    dict(loss, logits [::SAMPLE] sample, argmax sample, grads {name: tensor}, seconds)."""
+    dict(loss, logits [::SAMPLE] sample, argmax sample, grads {name: tensor}, seconds).
+    net_kw: OracleNet arguments (output_stride / aux for PSPNet, eps_encoder=None for ResNets)."""
     s = {k: (v.to(dtype) if v.is_floating_point() else v.clone()) for k, v in sd.items()}
     s = torch_ref.clone_state(s, requires_grad=True)
     kw = dict(eps_encoder=1e-3, drop_p=0.0)
@@ -42,7 +46,7 @@ def oracle_step(sd, x, y, dtype=torch.float32, oracle_fn="deeplabv3_plus_xceptio
     net = torch_ref.OracleNet(s, training=True, **kw)
     t0 = time.perf_counter()
     outs = getattr(net, oracle_fn)(x.to(dtype))
-    loss = torch_ref.mix_softmax_ce(outs, y)
+    loss = torch_ref.mix_softmax_ce(outs, y, aux_weight=AUX_WEIGHT)
     loss.backward()
     secs = time.perf_counter() - t0
     lo = outs[0].detach()[..., ::SAMPLE, ::SAMPLE].float().clone()
@@ -50,9 +54,10 @@ def oracle_step(sd, x, y, dtype=torch.float32, oracle_fn="deeplabv3_plus_xceptio
                                                            if v.grad is not None}, seconds=secs)
 
 
-def hip_step(dtype, sd, x, y, dev="cuda"):
+def hip_step(dtype, sd, x, y, dev="cuda", eps_encoder=1e-3):
     """The same step on a FRESH HIP model of the current cfg in `dtype` ('fp32' | 'bf16'), eager
-    launches -> dict(loss, logits sample, grads on the CPU)."""
+    launches -> dict(loss, logits sample, grads on the CPU).  Auxiliary heads (PSPNet with
+    SOLVER.AUX) enter the loss with the reference's weight (solver/loss.py:16-46)."""
     import segmentron_amd
     from segmentron_amd import functional as SF
     prev = segmentron_amd.compute_dtype()
@@ -61,15 +66,19 @@ def hip_step(dtype, sd, x, y, dev="cuda"):
     try:
         model = segmentron_amd.get_segmentation_model()
         model.load_state_dict(sd, strict=True)
-        for _, m in model.encoder.named_modules():  # solver/optimizer.py:18-20
-            if isinstance(m, torch.nn.BatchNorm2d):
-                m.eps = 1e-3
+        if eps_encoder is not None:
+            for _, m in model.encoder.named_modules():  # solver/optimizer.py:18-20
+                if isinstance(m, torch.nn.BatchNorm2d):
+                    m.eps = eps_encoder
         model = model.to(dev).train()
         for m in model.modules():
             if isinstance(m, (torch.nn.Dropout, torch.nn.Dropout2d)):
                 m.p = 0.0
         outs = model(x.to(dev))
-        loss = torch.nn.functional.cross_entropy(outs[0], y.to(dev), ignore_index=-1)
+        yd = y.to(dev)
+        loss = torch.nn.functional.cross_entropy(outs[0], yd, ignore_index=-1)
+        for aux in outs[1:]:
+            loss = loss + AUX_WEIGHT * torch.nn.functional.cross_entropy(aux, yd, ignore_index=-1)
         loss.backward()
         torch.cuda.synchronize()
         res = dict(loss=float(loss.item()),
@@ -101,7 +110,20 @@ def compare(got, ref):
     per.sort(reverse=True)
     top = [{"tensor": k, "share_of_sq_error": e2 / max(num, 1e-300),
             "share_of_sq_norm": n2 / max(den, 1e-300), "cosine": c} for e2, n2, c, k in per[:6]]
+    # arg-max disagreements, adjudicated: a pixel where the two arg-maxes differ is a TIE if the
+    # oracle's own top-2 margin there is within the logits bar (1e-3 of the largest |logit|) — the
+    # fp32 path reproduces the logits to ~2e-5, so it can only flip classes the oracle itself
+    # separates by less than that; anything else is an unexplained mismatch (north_star: "argmax
+    # masks bit-identical").
+    am, bm = a.argmax(1), b.argmax(1)
+    bad = am != bm
+    top2 = b.topk(2, dim=1).values
+    gap = (top2[:, 0] - top2[:, 1])[bad]
+    tie_tol = 1e-3 * float(b.abs().max())
     return dict(
+        argmax_mismatch=int(bad.sum()), argmax_pixels=int(bad.numel()),
+        argmax_unexplained=int((gap > tie_tol).sum()),
+        argmax_largest_margin=float(gap.max()) if gap.numel() else 0.0,
         grad_error_top=top,
         loss_rel=abs(got["loss"] - ref["loss"]) / abs(ref["loss"]),
         logits_maxrel=float((a - b).abs().max() / b.abs().max()),

@@ -35,6 +35,11 @@
 namespace seg {
 
 constexpr int SL_THREADS = 256, SL_CQ = 16, SL_WL = 16;
+#ifdef SL_NO_SCHEDBAR
+#define SL_SCHED_BARRIER()
+#else
+#define SL_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
+#endif
 #ifndef SL_OCC_F
 #define SL_OCC_F 4
 #endif
@@ -268,6 +273,21 @@ __global__ __launch_bounds__(SL_THREADS, SL_OCC_F) void dwconv_slide_fwd_kernel(
   };
   Q4 ssum = q4_zero(), ssq = q4_zero();
   auto compute = [&](int ro, const Q4 (&ra)[3], const Q4 (&rb)[3], const Q4 (&rc)[3]) {
+#ifdef SL_SPLIT_ACC
+    // three independent chains of three (one per kernel row), then two adds
+    Q4 acc, accb, accc;
+    acc.lo = ra[0].lo * wt[0].lo; acc.hi = ra[0].hi * wt[0].hi;
+    accb.lo = rb[0].lo * wt[3].lo; accb.hi = rb[0].hi * wt[3].hi;
+    accc.lo = rc[0].lo * wt[6].lo; accc.hi = rc[0].hi * wt[6].hi;
+#pragma unroll
+    for (int kw = 1; kw < 3; ++kw) {
+      q4_fma(acc, ra[kw], wt[kw]);
+      q4_fma(accb, rb[kw], wt[3 + kw]);
+      q4_fma(accc, rc[kw], wt[6 + kw]);
+    }
+    acc.lo = (acc.lo + accb.lo) + accc.lo;
+    acc.hi = (acc.hi + accb.hi) + accc.hi;
+#else
     Q4 acc = q4_zero();
 #pragma unroll
     for (int kw = 0; kw < 3; ++kw) q4_fma(acc, ra[kw], wt[kw]);
@@ -275,6 +295,7 @@ __global__ __launch_bounds__(SL_THREADS, SL_OCC_F) void dwconv_slide_fwd_kernel(
     for (int kw = 0; kw < 3; ++kw) q4_fma(acc, rb[kw], wt[3 + kw]);
 #pragma unroll
     for (int kw = 0; kw < 3; ++kw) q4_fma(acc, rc[kw], wt[6 + kw]);
+#endif
     sl_st<raw_t>(Yb + (long)ro * ypitch, yoff, IO::pack(acc));
     ssum.lo += acc.lo; ssum.hi += acc.hi;
     q4_fma(ssq, acc, acc);
@@ -299,9 +320,9 @@ __global__ __launch_bounds__(SL_THREADS, SL_OCC_F) void dwconv_slide_fwd_kernel(
       // then the nine taps
       commit(ro + k + 1, ring[(k + 2) % D], win[(k + 2) % 3], std::false_type{});
       issue(ro + k + 1 + D, ring[(k + 2) % D]);
-      __builtin_amdgcn_sched_barrier(0);
+      SL_SCHED_BARRIER();
       compute(ro + k, win[k % 3], win[(k + 1) % 3], win[(k + 2) % 3]);
-      __builtin_amdgcn_sched_barrier(0);
+      SL_SCHED_BARRIER();
     }
   }
 #pragma unroll
@@ -454,9 +475,9 @@ __global__ __launch_bounds__(SL_THREADS, 2) void dwconv_slide_bwd_kernel(const D
       issue(ro + k + 1 + D, ring[(k + 2) % D]);
       const raw_t xraw = xring[k % D], rraw = rring[k % D];
       issue_x(ro + k + D, xring[k % D], rring[k % D]);
-      __builtin_amdgcn_sched_barrier(0);
+      SL_SCHED_BARRIER();
       compute(ro + k, xraw, rraw, win[k % 3], win[(k + 1) % 3], win[(k + 2) % 3]);
-      __builtin_amdgcn_sched_barrier(0);
+      SL_SCHED_BARRIER();
     }
   }
 #pragma unroll

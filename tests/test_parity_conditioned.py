@@ -55,6 +55,21 @@ CASES = {
                hw=(64, 128), momentum=0.01, yaml="configs/cityscapes_hrnet_w18_small_v1.yaml"),
 }
 AUX_WEIGHT = 0.4
+# what the bf16 path measured on the conditioned fixtures at r06 (gpurun_out r06b, printed as
+# PARITY-COND ... bf16 by this file): eval / train logits L2-rel vs the fp32 fixture, arg-max
+# agreement, gradient cosine / global-rel vs the fp64 oracle.  Bars = 1.3 x these.
+BF16_MEASURED = {
+    "c3": dict(eval_l2=3.995e-2, train_l2=1.335e-2, argmax=0.9664, cos=0.99375, grad_rel=1.127e-1),
+    "c2": dict(eval_l2=8.493e-3, train_l2=6.913e-3, argmax=0.9910, cos=0.99993, grad_rel=1.250e-2),
+    "c4": dict(eval_l2=3.028e-2, train_l2=1.845e-2, argmax=0.9692, cos=0.99151, grad_rel=1.308e-1),
+    "c5": dict(eval_l2=1.382e-2, train_l2=1.196e-2, argmax=0.9771, cos=0.99993, grad_rel=1.182e-2),
+}
+# ... and at the large sizes (C3 513x1025, C3 / C4 1025x2049): logits L2-rel, 1 - arg-max, cosine
+BF16_MEASURED_LARGE = {
+    "c3_513x1025": dict(logits_l2=1.432e-2, argmax=0.9881, cos=0.99703, grad_rel=7.736e-2),
+    "c3_1025x2049": dict(logits_l2=1.428e-2, argmax=0.9857, cos=0.99995, loss_rel=7.74e-4),
+    "c4_1025x2049": dict(logits_l2=1.364e-2, argmax=0.9950, cos=0.99993, loss_rel=8.79e-5),
+}
 
 
 def _fixture(tag):
@@ -275,6 +290,14 @@ def test_bf16_eval_and_train_step_vs_oracle_with_the_reference_autocast_yardstic
     assert abs(loss.item() - l64) <= 1e-2 * l64
     assert st["cos"] >= min(0.99, ac_cos) - 0.03
     assert abs(st["ratio"] - 1.0) <= max(0.10, 1.5 * abs(ac_ratio - 1.0))
+    # r06 (VERDICT r05 weak #1c): the yardstick above stopped guarding anything once the image-pooling
+    # branch went to float32 (C3 cosine 0.8975 -> 0.994, bar 0.894) — hold the path to 1.3 x what it
+    # MEASURES now (errors, 1 - cosine, 1 - arg-max agreement), per configuration
+    m = BF16_MEASURED[tag]
+    assert l2e <= 1.3 * m["eval_l2"] and l2t <= 1.3 * m["train_l2"], (l2e, l2t, m)
+    assert 1.0 - agree <= 1.3 * (1.0 - m["argmax"]) + 2e-3, (agree, m)
+    assert 1.0 - st["cos"] <= 1.3 * (1.0 - m["cos"]) + 2e-5, (st["cos"], m)
+    assert st["global_rel"] <= 1.3 * m["grad_rel"], (st["global_rel"], m)
 
 
 @pytest.mark.gpu
@@ -319,6 +342,9 @@ def test_c3_fp32_and_bf16_train_step_513x1025_fixed_bars():
     assert abs(loss.item() - l64) <= 1e-2 * l64
     assert st["cos"] >= min(0.99, ac["grad_cosine"]) - 0.03
     assert abs(st["ratio"] - 1.0) <= max(0.10, 1.5 * abs(ac["grad_norm_ratio"] - 1.0))
+    m = BF16_MEASURED_LARGE["c3_513x1025"]  # (1.3 x measured, see BF16_MEASURED)
+    assert l2t <= 1.3 * m["logits_l2"] and 1.0 - agree <= 1.3 * (1.0 - m["argmax"]) + 2e-3
+    assert 1.0 - st["cos"] <= 1.3 * (1.0 - m["cos"]) + 2e-5 and st["global_rel"] <= 1.3 * m["grad_rel"]
 
 
 @pytest.mark.gpu
@@ -355,11 +381,71 @@ def test_c3_train_full_size_1025x2049_matches_oracle():
     assert f32["grad_tensors_missing"] == 0 and b16["grad_tensors_missing"] == 0
     assert f32["loss_rel"] < 1e-3 and f32["logits_maxrel"] < 1e-3
     assert f32["grad_global_rel"] <= FULL_SIZE_GRAD_BAR_FP32
+    _assert_fp32_argmax(f32, "c3 FULL SIZE")
     assert b16["loss_rel"] <= 1e-2
     assert b16["logits_l2rel"] <= max(2e-2, 1.5 * ac["logits_l2rel"])
     assert b16["argmax_agree"] >= ac["argmax_agree"] - 0.03
     assert b16["grad_cosine"] >= min(0.99, ac["grad_cosine"]) - 0.03
     assert abs(b16["grad_norm_ratio"] - 1.0) <= max(0.10, 1.5 * abs(ac["grad_norm_ratio"] - 1.0))
+    _assert_bf16_large(b16, "c3_1025x2049")
+
+
+def _assert_fp32_argmax(cmp, what):
+    """north_star: "argmax masks bit-identical" — every pixel where the fp32 path's arg-max differs
+    from the oracle's must be one the oracle itself separates by less than the 1e-3 logits bar
+    (oracle/parity.py::compare), and there may only be a handful of them."""
+    print("PARITY-COND %s fp32 arg-max: %d of %d sampled pixels differ, %d of them NOT oracle "
+          "top-2 near-ties (largest margin %.2e)"
+          % (what, cmp["argmax_mismatch"], cmp["argmax_pixels"], cmp["argmax_unexplained"],
+             cmp["argmax_largest_margin"]))
+    assert cmp["argmax_unexplained"] == 0
+    assert cmp["argmax_mismatch"] <= max(3, cmp["argmax_pixels"] // 2000)
+
+
+def _assert_bf16_large(b16, key):
+    m = BF16_MEASURED_LARGE[key]
+    assert b16["logits_l2rel"] <= 1.3 * m["logits_l2"], (b16["logits_l2rel"], m)
+    assert 1.0 - b16["argmax_agree"] <= 1.3 * (1.0 - m["argmax"]) + 2e-3, (b16["argmax_agree"], m)
+    assert 1.0 - b16["grad_cosine"] <= 1.3 * (1.0 - m["cos"]) + 2e-5, (b16["grad_cosine"], m)
+    if "loss_rel" in m:
+        assert b16["loss_rel"] <= max(1e-3, 1.3 * m["loss_rel"]), (b16["loss_rel"], m)
+
+
+@pytest.mark.gpu
+def test_c4_train_full_size_1025x2049_matches_oracle():
+    """BASELINE.json configs[3] at its OWN size: PSPNet-resnet101 (output stride 8, auxiliary
+    head, SOLVER.AUX_WEIGHT 0.4) train step, batch 2 @1025x2049, against the CPU fp32 oracle's
+    step on the same conditioned state (VERDICT r05 Missing #1;
+    /root/reference/segmentron/models/pspnet.py:13-58, /root/reference/tools/train.py:135-146).
+    fp32 kernels: 1e-3 on loss, logits and the global gradient, arg-max identical up to oracle
+    near-ties; bf16: 1.3 x what the path measured when the test was written."""
+    from oracle import parity as OP
+    H, W = 1025, 2049
+    sd = _state("c4")
+    x, y = OP.inputs(2, H, W, seed=0)
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    ref = OP.oracle_step(sd, x, y, torch.float32, oracle_fn="pspnet_resnet", output_stride=8,
+                         aux=True, eps_encoder=None)
+    _build_hip("c4", torch.float32, True)  # (sets cfg; OP.hip_step builds its own models)
+    f32 = OP.compare(OP.hip_step("fp32", sd, x, y, eps_encoder=None), ref)
+    b16 = OP.compare(OP.hip_step("bf16", sd, x, y, eps_encoder=None), ref)
+    print("PARITY-COND c4 FULL SIZE 1025x2049 B=2 vs CPU fp32 oracle (%.0f s): fp32 loss rel %.2e "
+          "logits max-rel %.2e gradients global rel %.2e cosine %.7f | bf16 loss rel %.2e logits "
+          "L2-rel %.3e argmax %.4f gradients global rel %.3e cosine %.5f ratio %.4f"
+          % (ref["seconds"], f32["loss_rel"], f32["logits_maxrel"], f32["grad_global_rel"],
+             f32["grad_cosine"], b16["loss_rel"], b16["logits_l2rel"], b16["argmax_agree"],
+             b16["grad_global_rel"], b16["grad_cosine"], b16["grad_norm_ratio"]))
+    for tag, c in (("fp32", f32), ("bf16", b16)):
+        print("PARITY-COND c4 FULL SIZE %s gradient error shares: %s" % (tag, "; ".join(
+            "%s %.0f%% (cosine %.3f)" % (t["tensor"], 100 * t["share_of_sq_error"], t["cosine"])
+            for t in c["grad_error_top"][:5])))
+    assert f32["finite"] and b16["finite"]
+    assert f32["grad_tensors_missing"] == 0 and b16["grad_tensors_missing"] == 0
+    assert f32["loss_rel"] < 1e-3 and f32["logits_maxrel"] < 1e-3
+    assert f32["grad_global_rel"] <= FULL_SIZE_GRAD_BAR_FP32
+    _assert_fp32_argmax(f32, "c4 FULL SIZE")
+    assert abs(b16["grad_norm_ratio"] - 1.0) <= 0.10
+    _assert_bf16_large(b16, "c4_1025x2049")
 
 
 # north_star's 1e-3 (against the fp32 CPU oracle, which itself sits FULL_SIZE_ORACLE_FP32_VS_FP64
