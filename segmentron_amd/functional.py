@@ -371,8 +371,12 @@ def note_running_stats_changed():
 
 
 def _eval_versions(bn):
-    return tuple(-1 if t is None else t._version
-                 for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var)) \
+    # version AND storage of all four tensors: `bn.weight.data = w` (EMA swaps, re-initialisation,
+    # fusing scripts) rebinds the storage without bumping `_version`
+    ts = (bn.weight, bn.bias, bn.running_mean, bn.running_var)
+    return tuple(-1 if t is None else t._version for t in ts) \
+        + tuple(0 if t is None else t.data_ptr() for t in ts) \
+        + tuple(0 if t is None else id(t) for t in ts) \
         + (float(bn.eps), _STATS_EPOCH[0])
 
 

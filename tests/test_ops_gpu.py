@@ -1039,3 +1039,4 @@ def test_pack_multi_matches_torch_casts_and_transposes(dtype):
     b2 = Fm._WCACHE[(id(w2), ("pw", True, dtype))][3]  # re-made by the same launch
     assert torch.equal(b2, w2.detach().view(24, 32).t().to(dtype).contiguous())
     assert Fm.packed_pointwise(w2, True, dtype) is b2
+

@@ -89,6 +89,11 @@ def main():
     mean, invstd = rn(C) * 0.1, torch.rand(C, device=DEV) + 0.5
     ops["dw_bwd_finalize"] = lambda: K.dw_bwd_finalize(pb_, pw_, float(M), mean, invstd, bnw)
     ops["bn_bwd_finalize_p"] = lambda: K.bn_bwd_finalize_p(pb_, float(M), mean, invstd, bnw)
+    def three():
+        g_, pw2, pb2 = K.dwconv_bwd_fused(x, dy, wdw, 1, pro, want_bn=True, torch_layout=True, raw_dw=True)
+        _, _, c0_, c1_, _ = K.dw_bwd_finalize(pb2, pw2, float(M), mean, invstd, bnw)
+        K.bn_bwd_apply(g_, x, (2, sc, sh), c0_, c1_, out=g_)
+    ops["dw_bwd+fin+apply"] = three
     # what does one extra tiny launch cost inside a graph?  (pair - single)
     def pair():
         K.conv_gemm(x, wpw, C, 1, 1, 1, 0, 1, None, None, None, True)
