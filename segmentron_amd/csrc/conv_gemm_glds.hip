@@ -93,6 +93,23 @@ __global__ __launch_bounds__(GL_THREADS, 2) void conv_gemm_glds_kernel(const Con
     load_params<VEC>(a.ep_c0, o, c0v);
     load_params<VEC>(a.ep_c1, o, c1v);
   }
+  // r06, EP: the x vectors of ALL the wave's pixels are requested before the first patch is
+  // written.  They were requested per 32-pixel block, at the top of the block's iteration, and
+  // each iteration then sat out its own global round trip (~1.5 us under load, four times per
+  // wave: most of what the data gradient's epilogue cost over the forward's).
+  constexpr int NQ_ALL = (32 * VPR) / 64;
+  uint4 xr_all[EP ? IMS : 1][EP ? NQ_ALL : 1];
+  if (EP) {
+#pragma unroll
+    for (int im = 0; im < IMS; ++im)
+#pragma unroll
+      for (int q = 0; q < NQ_ALL; ++q) {
+        const int r = (q * 64 + lane) / VPR;
+        const int p = m0 + wm * 32 * IMS + im * 32 + r;
+        const long pc = p < a.M ? p : a.M - 1;
+        xr_all[im][q] = ldg16(reinterpret_cast<const T*>(a.ep_x) + pc * a.ldep + (epc ? o : 0));
+      }
+  }
 #pragma unroll
   for (int im = 0; im < IMS; ++im) {
 #pragma unroll
@@ -124,11 +141,7 @@ __global__ __launch_bounds__(GL_THREADS, 2) void conv_gemm_glds_kernel(const Con
       } else {
         val[q] = *reinterpret_cast<const uint4*>(ep + r * EP_STRIDE + v * 16);
       }
-      if (EP) {
-        const int p = m0 + wm * 32 * IMS + im * 32 + r;
-        const long pc = p < a.M ? p : a.M - 1;
-        xr[q] = ldg16(reinterpret_cast<const T*>(a.ep_x) + pc * a.ldep + (epc ? o : 0));
-      }
+      if (EP) xr[q] = xr_all[im][q];
     }
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
