@@ -20,13 +20,8 @@ namespace seg {
 
 constexpr int EW_THREADS = 256;
 constexpr int EW_MAX_THREADS = 512;  // the row-tile kernels: rows x channel vectors of a block (ew_geom)
-#ifndef EW_UN_V
-#define EW_UN_V 4
-#endif
-#ifndef EW_CAP
-#define EW_CAP 512
-#endif
-constexpr int EW_UN = EW_UN_V;  // rows per thread per iteration in the row-tile kernels
+constexpr int EW_CAP = 512;  // blocks per launch (grid-stride beyond): 512 vs 8192 measured 13.0 vs 13.9 us on the 24 MB tensors
+constexpr int EW_UN = 4;  // rows per thread per iteration in the row-tile kernels
 
 // ------------------------------------------------------------------ column sums of partials
 // in [R][L] fp32 -> out[gridDim.y][L] (fp64 or fp32)

@@ -32,9 +32,7 @@ constexpr int D3_TH = 8, D3_TW = 32, D3_HH = D3_TH + 2, D3_HW = D3_TW + 2;
 constexpr int D3_THREADS = 256;
 constexpr int D3_MAX_BLOCKS = 512;
 // C = 16: 20 KB of LDS and ~120 VGPRs per block — four blocks per CU hide each other's staging
-#ifndef D3_C16_BLOCKS
-#define D3_C16_BLOCKS 1024
-#endif
+constexpr int D3_C16_BLOCKS = 1024;
 
 typedef __attribute__((address_space(3))) unsigned char d3_lds_t;
 

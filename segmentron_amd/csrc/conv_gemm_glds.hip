@@ -34,10 +34,6 @@ namespace seg {
 // EP: folded-BatchNorm backward correction in the store path; STATS: BatchNorm partial sums
 // KXK: stride-1 KxK convolution as an implicit GEMM (per-lane gather in the DMA source address,
 // gemm_glds.h GlConvA) — ResNet bottleneck / PSP-head 3x3s, C % 32 == 0
-#ifdef LAB_TICKET
-__device__ unsigned g_lab_ticket[64];
-__device__ float g_lab_sink[1024];
-#endif
 
 // IMS: 32-pixel blocks per wave (4: 256-row tile, 3: 192-row tile)
 template <bool EP, bool STATS, bool KXK = false, int IMS = 4>
@@ -198,70 +194,10 @@ __global__ __launch_bounds__(GL_THREADS, 2) void conv_gemm_glds_kernel(const Con
       const int oc = n0 + tid;
       if (oc < a.O) {
         float* dst = a.stat_partial + (long)tile_m * 2 * a.O;
-#if defined(LAB_TICKET) && LAB_TICKET >= 2  // write-through (sc1) rows instead of a release fence
-        __hip_atomic_store(dst + oc, red[0 * 256 + tid] + red[2 * 256 + tid], __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(dst + a.O + oc, red[1 * 256 + tid] + red[3 * 256 + tid],
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#else
         dst[oc] = red[0 * 256 + tid] + red[2 * 256 + tid];
         dst[a.O + oc] = red[1 * 256 + tid] + red[3 * 256 + tid];
-#endif
       }
     }
-#ifdef LAB_TICKET
-    // LAB ONLY (tools/lab builds, never the product library): the cost of a last-arriver
-    // BatchNorm finalize behind this kernel — one agent-scope release + ticket per block, and in
-    // the last block of a column tile an acquire + the fixed-order re-read of that tile's
-    // statistic rows (profiles/r05_last_arriver.md)
-    {
-      int* s_last = reinterpret_cast<int*>(smem_raw + 8192);  // (inside the idle ring: a second
-      __syncthreads();                                        //  __shared__ object would cost the
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       //  main loop a vmcnt(0) per k-step)
-      __syncthreads();
-      if (tid == 0) {
-#if LAB_TICKET < 2
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-        const unsigned t = __hip_atomic_fetch_add(&g_lab_ticket[tile_n & 63], 1u, __ATOMIC_RELAXED,
-                                                  __HIP_MEMORY_SCOPE_AGENT);
-        *s_last = (t % (unsigned)a.tiles_m) == (unsigned)a.tiles_m - 1u;
-#if LAB_TICKET < 2
-        if (*s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-#endif
-      }
-      __syncthreads();
-      if (*s_last && LAB_TICKET != 3) {
-        const int cols = min(256, a.O - n0);
-        for (int e = tid; e < cols * 2; e += GL_THREADS) {
-          const int sub = e / cols, c = e - sub * cols;
-          float tot = 0.f;
-#if LAB_TICKET == 4  // eight rows in flight per thread
-          for (int r0 = 0; r0 < a.tiles_m; r0 += 8) {
-            float v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-              v[u] = __hip_atomic_load(a.stat_partial + ((long)min(r0 + u, a.tiles_m - 1) * 2 + sub) * a.O + n0 + c,
-                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-            for (int u = 0; u < 8; ++u) tot += (r0 + u < a.tiles_m) ? v[u] : 0.f;
-          }
-          if (false)
-#endif
-          for (int r = 0; r < a.tiles_m; ++r) {
-#if LAB_TICKET >= 2
-            tot += __hip_atomic_load(a.stat_partial + ((long)r * 2 + sub) * a.O + n0 + c,
-                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#else
-            tot += a.stat_partial[((long)r * 2 + sub) * a.O + n0 + c];
-#endif
-          }
-          g_lab_sink[e & 1023] = tot;
-        }
-      }
-    }
-#endif
   }
 }
 

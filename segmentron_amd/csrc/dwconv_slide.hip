@@ -28,27 +28,14 @@
 #include <type_traits>
 #include "common.h"
 #include "dwconv_slide.h"
-#ifdef SL_LAB_ENV
-#include <cstdlib>
-#endif
 
 namespace seg {
 
 constexpr int SL_THREADS = 256, SL_CQ = 16, SL_WL = 16;
-#ifdef SL_NO_SCHEDBAR
-#define SL_SCHED_BARRIER()
-#else
+// rows in flight per thread / waves per SIMD (tools/lab sweeps, profiles/r06_dw_slide.md: depth 2 .. 6
+// and 2 .. 4 waves are within 5 % of each other once the loop is branch-free; 2 / 4 / 2 shipped)
+constexpr int SL_DEPTH_F = 2, SL_OCC_F = 4, SL_DEPTH_B = 2;
 #define SL_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
-#endif
-#ifndef SL_OCC_F
-#define SL_OCC_F 4
-#endif
-#ifndef SL_DEPTH_F
-#define SL_DEPTH_F 2
-#endif
-#ifndef SL_DEPTH_B
-#define SL_DEPTH_B 2
-#endif
 
 struct DwSlideArgs {
   const void* x;        // fwd: input; bwd: the forward input (raw tensor + prologue)
@@ -273,21 +260,6 @@ __global__ __launch_bounds__(SL_THREADS, SL_OCC_F) void dwconv_slide_fwd_kernel(
   };
   Q4 ssum = q4_zero(), ssq = q4_zero();
   auto compute = [&](int ro, const Q4 (&ra)[3], const Q4 (&rb)[3], const Q4 (&rc)[3]) {
-#ifdef SL_SPLIT_ACC
-    // three independent chains of three (one per kernel row), then two adds
-    Q4 acc, accb, accc;
-    acc.lo = ra[0].lo * wt[0].lo; acc.hi = ra[0].hi * wt[0].hi;
-    accb.lo = rb[0].lo * wt[3].lo; accb.hi = rb[0].hi * wt[3].hi;
-    accc.lo = rc[0].lo * wt[6].lo; accc.hi = rc[0].hi * wt[6].hi;
-#pragma unroll
-    for (int kw = 1; kw < 3; ++kw) {
-      q4_fma(acc, ra[kw], wt[kw]);
-      q4_fma(accb, rb[kw], wt[3 + kw]);
-      q4_fma(accc, rc[kw], wt[6 + kw]);
-    }
-    acc.lo = (acc.lo + accb.lo) + accc.lo;
-    acc.hi = (acc.hi + accb.hi) + accc.hi;
-#else
     Q4 acc = q4_zero();
 #pragma unroll
     for (int kw = 0; kw < 3; ++kw) q4_fma(acc, ra[kw], wt[kw]);
@@ -295,7 +267,6 @@ __global__ __launch_bounds__(SL_THREADS, SL_OCC_F) void dwconv_slide_fwd_kernel(
     for (int kw = 0; kw < 3; ++kw) q4_fma(acc, rb[kw], wt[3 + kw]);
 #pragma unroll
     for (int kw = 0; kw < 3; ++kw) q4_fma(acc, rc[kw], wt[6 + kw]);
-#endif
     sl_st<raw_t>(Yb + (long)ro * ypitch, yoff, IO::pack(acc));
     ssum.lo += acc.lo; ssum.hi += acc.hi;
     q4_fma(ssq, acc, acc);
@@ -549,9 +520,6 @@ static void slide_geom(DwSlideArgs& a, int N, int H, int W, int C) {
   const long cap = 1024 / ((long)N * a.nwblk);
   if (ns > cap) ns = cap;
   if (ns < 1) ns = 1;
-#ifdef SL_LAB_ENV  // tools/lab variant builds only: sweep the strip count without rebuilding
-  if (const char* e = getenv("SL_NSTRIPS")) ns = atoi(e);
-#endif
   a.rs = (int)((H + ns - 1) / ns);
   a.nstrips = (H + a.rs - 1) / a.rs;
 }

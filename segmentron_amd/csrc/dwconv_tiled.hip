@@ -21,9 +21,6 @@
 namespace seg {
 
 constexpr int LT_TH = 8, LT_TW = 16, LT_CVB = 8, LT_THREADS = 256;
-#ifndef DW_BWD_OCC
-#define DW_BWD_OCC 2
-#endif
 constexpr int DW_BWD_REM_PCT = 6;
 
 struct DwTiledArgs {
@@ -49,57 +46,6 @@ struct DwTiledArgs {
   int ntiles_a, nb, nc, hb0, wc0, hc;
 };
 
-#ifdef LAB_TICKET
-__device__ unsigned g_lab_ticket[64];
-__device__ float g_lab_sink[4096];
-// rows x (nsub sub-rows of `cols` columns at pitch sub_pitch) floats at `base` (row pitch
-// row_pitch): every block arrives; the last one re-reads everything in fixed order
-__device__ __forceinline__ void lab_last_arriver(const float* base, long row_pitch, int rows, int cols,
-                                                 int nsub, long sub_pitch, unsigned* ticket,
-                                                 int expected) {
-  __shared__ int s_last;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0) {
-#if LAB_TICKET < 2
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-    const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_last = (t % (unsigned)expected) == (unsigned)expected - 1u;
-#if LAB_TICKET < 2
-    if (s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-#endif
-  }
-  __syncthreads();
-  if (!s_last || LAB_TICKET == 3) return;
-  for (int e = threadIdx.x; e < cols * nsub; e += blockDim.x) {
-    const int sub = e / cols, c = e - sub * cols;
-    float tot = 0.f;
-#if LAB_TICKET == 4  // eight rows in flight per thread
-    for (int r0 = 0; r0 < rows; r0 += 8) {
-      float v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u)
-        v[u] = __hip_atomic_load(base + (long)min(r0 + u, rows - 1) * row_pitch + sub * sub_pitch + c,
-                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-      for (int u = 0; u < 8; ++u) tot += (r0 + u < rows) ? v[u] : 0.f;
-    }
-    if (false)
-#endif
-    for (int r = 0; r < rows; ++r) {
-#if LAB_TICKET >= 2
-      tot += __hip_atomic_load(base + (long)r * row_pitch + sub * sub_pitch + c, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-#else
-      tot += base[(long)r * row_pitch + sub * sub_pitch + c];
-#endif
-    }
-    g_lab_sink[e & 4095] = tot;
-  }
-}
-#endif
 
 // A tile is TH x TW output pixels (TH * TW / 4 = 32 strips of four for the 32 pixel threads of
 // a block).  8 x 16 everywhere, except for the REMAINDER tiles of the r05 tiling (see DwRem).
@@ -499,21 +445,8 @@ __global__ __launch_bounds__(LT_THREADS, sizeof(T) == 2 ? 3 : 4) void dwconv_til
       const int lcx = tid / (2 * VEC), k = tid - lcx * 2 * VEC;
       const int which = k / VEC, ci = k - which * VEC;
       const int c = (cvb0 + lcx) * VEC + ci;
-#if defined(LAB_TICKET) && LAB_TICKET >= 2
-      if (c < a.C) __hip_atomic_store(a.partial + ((long)lb.y * 2 + which) * a.C + c, tot,
-                                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#else
       if (c < a.C) a.partial[((long)lb.y * 2 + which) * a.C + c] = tot;
-#endif
     }
-#ifdef LAB_TICKET
-    // LAB ONLY (tools/lab, never in the product build): what a last-arriver finalize would add to
-    // this kernel — per block one agent-scope release + ticket, and for the last block of a
-    // channel block an acquire + the fixed-order reduction of that block's partial rows
-    // (profiles/r05_last_arriver.md).
-    lab_last_arriver(a.partial + (long)cvb0 * VEC, 2 * a.C, gridDim.y, LT_CVB * VEC, 2, a.C,
-                     &g_lab_ticket[lb.x & 63], (int)gridDim.y);
-#endif
   }
 }
 
@@ -982,7 +915,7 @@ __device__ __forceinline__ void dw_bwd_edge_tile(
 // REM: this launch has remainder tiles (a separate instance: with their code compiled in, the
 // 8 x 16 loop of the classic tiling spilled 12 bytes and ran 3-5 % slower on the large maps)
 template <typename T, int DIL, bool RES = false, bool REM = false>
-__global__ __launch_bounds__(LT_THREADS, DW_BWD_OCC) void dwconv_bwd_tiled_kernel(const DwTiledArgs a) {
+__global__ __launch_bounds__(LT_THREADS, 2) void dwconv_bwd_tiled_kernel(const DwTiledArgs a) {
   // 4 channels per thread in both element types (8-byte bf16 vectors): this kernel carries nine
   // tap accumulators per channel on top of the data-gradient accumulators
   using G = TileGeom<DIL>;
