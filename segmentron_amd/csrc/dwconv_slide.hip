@@ -188,6 +188,14 @@ struct SlThread {
   int c, w, r0, r1, rlast;
   bool live, lm, rm;
   unsigned off_m, off_0, off_p;  // byte offsets of the three columns inside an image row
+  // r06b: only the wave's two outer columns LOAD a neighbour (left of its first column, right of
+  // its last one, one half-active instruction); the others take the neighbour's centre vector
+  // from the lane 16 below / above (lane = column * 16 + channel quad, four columns per wave) by
+  // ds_bpermute.  Three full loads per row were ~3 us of the 15.7 / 20.9 us launches (TA-bound:
+  // profiles/r06_dw_slide.md, centre-only ablation 12.5 / 18.2 us).
+  bool edge, first, last;
+  unsigned off_e;
+  int bp_up, bp_dn;  // ds_bpermute byte addresses of lane - 16 / lane + 16
 };
 template <int ESIZE>
 __device__ __forceinline__ SlThread sl_thread(const DwSlideArgs& a, const SlBlock& b, long ld) {
@@ -205,11 +213,74 @@ __device__ __forceinline__ SlThread sl_thread(const DwSlideArgs& a, const SlBloc
   t.off_m = (unsigned)((max(t.w - 1, 0) * ld + t.c) * ESIZE);
   t.off_0 = (unsigned)((t.w * ld + t.c) * ESIZE);
   t.off_p = (unsigned)((min(t.w + 1, a.W - 1) * ld + t.c) * ESIZE);
+  const int lane = tid & 63, col = lane >> 4;
+  t.first = col == 0;
+  t.last = col == 3;
+  t.edge = t.first || t.last;
+  t.off_e = t.first ? t.off_m : (t.last ? t.off_p : 0xFFFFFFFFu);  // inner columns: out of range
+  t.bp_up = ((lane - 16) & 63) * 4;
+  t.bp_dn = ((lane + 16) & 63) * 4;
   return t;
 }
 
+// the outer columns' extra load as a BUFFER load over the image row: the inner columns pass an
+// offset past the end of the buffer — they read nothing and get zeros, without a branch around the
+// instruction (a per-lane `if` put an s_cbranch_execz between loads and uses: hipcc then stops
+// counting vmcnt and the register allocation of the ring doubles)
+typedef unsigned int sl_u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int sl_u32x4 __attribute__((ext_vector_type(4)));
+template <typename R> __device__ __forceinline__ R sl_ld_edge(const unsigned char* row, unsigned nbytes, unsigned off);
+template <> __device__ __forceinline__ uint2 sl_ld_edge<uint2>(const unsigned char* row, unsigned nbytes, unsigned off) {
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)row, 0, (int)nbytes, 0x00020000);
+  const sl_u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, 0);
+  return make_uint2(v.x, v.y);
+}
+template <> __device__ __forceinline__ uint4 sl_ld_edge<uint4>(const unsigned char* row, unsigned nbytes, unsigned off) {
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)row, 0, (int)nbytes, 0x00020000);
+  const sl_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+// ... and the store as a buffer store: threads past the last column / channel quad pass an offset
+// out of range and write nothing (with the lane exchange a mirrored thread no longer computes its
+// twin's value — its neighbours are other mirrors — so it must not store at all)
+template <typename R> __device__ __forceinline__ void sl_st_row(unsigned char* row, unsigned nbytes, unsigned off, const R& v);
+template <> __device__ __forceinline__ void sl_st_row<uint2>(unsigned char* row, unsigned nbytes, unsigned off, const uint2& v) {
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)row, 0, (int)nbytes, 0x00020000);
+  const sl_u32x2 d = {v.x, v.y};
+  __builtin_amdgcn_raw_buffer_store_b64(d, r, (int)off, 0, 0);
+}
+template <> __device__ __forceinline__ void sl_st_row<uint4>(unsigned char* row, unsigned nbytes, unsigned off, const uint4& v) {
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)row, 0, (int)nbytes, 0x00020000);
+  const sl_u32x4 d = {v.x, v.y, v.z, v.w};
+  __builtin_amdgcn_raw_buffer_store_b128(d, r, (int)off, 0, 0);
+}
+// the three vectors of a row from (own centre, the outer columns' extra load)
+template <typename R> __device__ __forceinline__ R sl_bperm(int addr, const R& v);
+template <> __device__ __forceinline__ uint2 sl_bperm<uint2>(int addr, const uint2& v) {
+  return make_uint2((unsigned)__builtin_amdgcn_ds_bpermute(addr, (int)v.x),
+                    (unsigned)__builtin_amdgcn_ds_bpermute(addr, (int)v.y));
+}
+template <> __device__ __forceinline__ uint4 sl_bperm<uint4>(int addr, const uint4& v) {
+  return make_uint4((unsigned)__builtin_amdgcn_ds_bpermute(addr, (int)v.x),
+                    (unsigned)__builtin_amdgcn_ds_bpermute(addr, (int)v.y),
+                    (unsigned)__builtin_amdgcn_ds_bpermute(addr, (int)v.z),
+                    (unsigned)__builtin_amdgcn_ds_bpermute(addr, (int)v.w));
+}
+__device__ __forceinline__ uint2 sl_sel(bool c, const uint2& a, const uint2& b) {
+  return make_uint2(c ? a.x : b.x, c ? a.y : b.y);
+}
+__device__ __forceinline__ uint4 sl_sel(bool c, const uint4& a, const uint4& b) {
+  return make_uint4(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z, c ? a.w : b.w);
+}
+template <typename R>
+__device__ __forceinline__ void sl_neighbours(const SlThread& t, const R (&raw)[3], R& left, R& right) {
+  const R up = sl_bperm<R>(t.bp_up, raw[0]), dn = sl_bperm<R>(t.bp_dn, raw[0]);
+  left = sl_sel(t.first, raw[1], up);
+  right = sl_sel(t.last, raw[1], dn);
+}
+
 // ------------------------------------------------------------------------------------ forward
-template <typename T, int MODE>
+template <typename T, int MODE, bool XCHG>
 __global__ __launch_bounds__(SL_THREADS, SL_OCC_F) void dwconv_slide_fwd_kernel(const DwSlideArgs a) {
   using IO = SlIO<T>;
   using raw_t = typename IO::raw_t;
@@ -239,21 +310,35 @@ __global__ __launch_bounds__(SL_THREADS, SL_OCC_F) void dwconv_slide_fwd_kernel(
   unsigned char* __restrict__ Yb = reinterpret_cast<unsigned char*>(a.y) +
                                    (long)b.n * a.H * a.W * a.ldy * ES;
   const long xpitch = (long)a.W * a.ldx * ES, ypitch = (long)a.W * a.ldy * ES;
-  const unsigned yoff = (unsigned)((t.w * a.ldy + t.c) * ES);
+  const unsigned rowbytes = (unsigned)xpitch;
+  const unsigned yoff = t.live ? (unsigned)((t.w * a.ldy + t.c) * ES) : 0xFFFFFFFFu;
 
   // (rows outside [0, rlast] re-read a row of the strip: unconditional, the value is unused/masked)
   auto issue = [&](int r, raw_t (&raw)[3]) {
     const unsigned char* __restrict__ row = Xb + (long)min(max(r, 0), t.rlast) * xpitch;
-    raw[0] = sl_ld<raw_t>(row, t.off_m);
-    raw[1] = sl_ld<raw_t>(row, t.off_0);
-    raw[2] = sl_ld<raw_t>(row, t.off_p);
+    if (XCHG) {
+      raw[0] = sl_ld<raw_t>(row, t.off_0);
+      raw[1] = sl_ld_edge<raw_t>(row, rowbytes, t.off_e);
+    } else {
+      raw[0] = sl_ld<raw_t>(row, t.off_0);
+      raw[1] = sl_ld<raw_t>(row, t.off_m);
+      raw[2] = sl_ld<raw_t>(row, t.off_p);
+    }
   };
   auto commit = [&](int r, const raw_t (&raw)[3], Q4 (&row)[3], auto check) {
     constexpr bool CHECK = decltype(check)::value;
     const bool rv = !CHECK || (r >= 0 && r < a.H);
+    raw_t r3[3];
+    r3[1] = raw[0];
+    if (XCHG) {
+      sl_neighbours<raw_t>(t, raw, r3[0], r3[2]);
+    } else {
+      r3[0] = raw[1];
+      r3[2] = raw[2];
+    }
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      row[k] = IO::unpack(RAWRELU ? IO::relu_raw(raw[k]) : raw[k]);
+      row[k] = IO::unpack(RAWRELU ? IO::relu_raw(r3[k]) : r3[k]);
       sl_act<MODE, RAWRELU>(row[k], sc, sh);
       if (CHECK && !rv) row[k] = q4_zero();  // zero padding AFTER the activation
     }
@@ -267,7 +352,7 @@ __global__ __launch_bounds__(SL_THREADS, SL_OCC_F) void dwconv_slide_fwd_kernel(
     for (int kw = 0; kw < 3; ++kw) q4_fma(acc, rb[kw], wt[3 + kw]);
 #pragma unroll
     for (int kw = 0; kw < 3; ++kw) q4_fma(acc, rc[kw], wt[6 + kw]);
-    sl_st<raw_t>(Yb + (long)ro * ypitch, yoff, IO::pack(acc));
+    sl_st_row<raw_t>(Yb + (long)ro * ypitch, (unsigned)ypitch, yoff, IO::pack(acc));
     ssum.lo += acc.lo; ssum.hi += acc.hi;
     q4_fma(ssq, acc, acc);
   };
@@ -334,7 +419,7 @@ __global__ __launch_bounds__(SL_THREADS, SL_OCC_F) void dwconv_slide_fwd_kernel(
 //   dW[k]  += act(x[q]) * dy[q - d_k]                       the same shifted dy values
 //   (sum g', sum g' * x_raw)                                of the masked gradient before `res`
 // The window holds dy (no activation); window position (a, b) pairs with tap 8 - (3a + b).
-template <typename T, int MODE, bool RES>
+template <typename T, int MODE, bool RES, bool XCHG>
 __global__ __launch_bounds__(SL_THREADS, 2) void dwconv_slide_bwd_kernel(const DwSlideArgs a) {
   using IO = SlIO<T>;
   using raw_t = typename IO::raw_t;
@@ -368,14 +453,20 @@ __global__ __launch_bounds__(SL_THREADS, 2) void dwconv_slide_bwd_kernel(const D
   unsigned char* __restrict__ Gb = reinterpret_cast<unsigned char*>(a.y) + img * a.ldy * ES;
   const long dpitch = (long)a.W * a.lddy * ES, xpitch = (long)a.W * a.ldx * ES;
   const long rpitch = (long)a.W * a.ldr * ES, gpitch = (long)a.W * a.ldy * ES;
+  const unsigned rowbytes = (unsigned)dpitch;
   const unsigned xoff = (unsigned)((t.w * a.ldx + t.c) * ES), roff = (unsigned)((t.w * a.ldr + t.c) * ES);
-  const unsigned goff = (unsigned)((t.w * a.ldy + t.c) * ES);
+  const unsigned goff = t.live ? (unsigned)((t.w * a.ldy + t.c) * ES) : 0xFFFFFFFFu;
 
   auto issue = [&](int r, raw_t (&raw)[3]) {
     const unsigned char* __restrict__ row = Db + (long)min(max(r, 0), t.rlast) * dpitch;
-    raw[0] = sl_ld<raw_t>(row, t.off_m);
-    raw[1] = sl_ld<raw_t>(row, t.off_0);
-    raw[2] = sl_ld<raw_t>(row, t.off_p);
+    if (XCHG) {
+      raw[0] = sl_ld<raw_t>(row, t.off_0);
+      raw[1] = sl_ld_edge<raw_t>(row, rowbytes, t.off_e);
+    } else {
+      raw[0] = sl_ld<raw_t>(row, t.off_0);
+      raw[1] = sl_ld<raw_t>(row, t.off_m);
+      raw[2] = sl_ld<raw_t>(row, t.off_p);
+    }
   };
   auto issue_x = [&](int r, raw_t& xr, raw_t& rr) {  // centre pixel of output row r
     const int rcl = min(r, r1 - 1);
@@ -385,9 +476,17 @@ __global__ __launch_bounds__(SL_THREADS, 2) void dwconv_slide_bwd_kernel(const D
   auto commit = [&](int r, const raw_t (&raw)[3], Q4 (&row)[3], auto check) {
     constexpr bool CHECK = decltype(check)::value;
     const bool rv = !CHECK || (r >= 0 && r < a.H);
+    raw_t r3[3];
+    r3[1] = raw[0];
+    if (XCHG) {
+      sl_neighbours<raw_t>(t, raw, r3[0], r3[2]);
+    } else {
+      r3[0] = raw[1];
+      r3[2] = raw[2];
+    }
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      row[k] = IO::unpack(raw[k]);
+      row[k] = IO::unpack(r3[k]);
       if (CHECK && !rv) row[k] = q4_zero();
     }
   };
@@ -417,9 +516,9 @@ __global__ __launch_bounds__(SL_THREADS, 2) void dwconv_slide_bwd_kernel(const D
       Q4 o;
       o.lo = g.lo + rr.lo;
       o.hi = g.hi + rr.hi;
-      sl_st<raw_t>(Gb + (long)ro * gpitch, goff, IO::pack(o));
+      sl_st_row<raw_t>(Gb + (long)ro * gpitch, (unsigned)gpitch, goff, IO::pack(o));
     } else {
-      sl_st<raw_t>(Gb + (long)ro * gpitch, goff, IO::pack(g));
+      sl_st_row<raw_t>(Gb + (long)ro * gpitch, (unsigned)gpitch, goff, IO::pack(g));
     }
     s1.lo += g.lo; s1.hi += g.hi;
     q4_fma(s2, g, xr);
@@ -530,11 +629,23 @@ int dw_slide_rows(int C, int N, int H, int W) {
   return N * a.nstrips * a.nwblk;
 }
 
+// Neighbour columns by lane exchange (one full + one half-active load per row) or by three loads:
+// the exchange adds ~16 instructions per row step (4 ds_bpermute, 4 selects, the buffer
+// descriptors) and wins where the loads are the limit — every map of >= 30 MB: [2,513,1025,128]
+// forward 154 -> 122 us, backward 270 -> 175; [2,257,513,256] 72 -> 55 / 153 -> 95 — and loses
+// on the 24 MB middle-flow maps (15.7 -> 16.5 / 20.9 -> 21.8 us: issue-bound at 1.7 waves per SIMD).
+static bool slide_exchange(const DwSlideArgs& a, int esize) {
+  return (long)a.N * a.H * a.W * a.C * esize >= (30L << 20);
+}
 template <typename T>
 static void slide_launch_fwd(const DwSlideArgs& a, dim3 grid, hipStream_t st) {
+  const bool xc = slide_exchange(a, (int)sizeof(T));
   switch (a.pro_mode) {
-#define SL_CASE(M) \
-  case M: hipLaunchKernelGGL((dwconv_slide_fwd_kernel<T, M>), grid, dim3(SL_THREADS), 0, st, a); break;
+#define SL_CASE(M)                                                                                  \
+  case M:                                                                                           \
+    if (xc) hipLaunchKernelGGL((dwconv_slide_fwd_kernel<T, M, true>), grid, dim3(SL_THREADS), 0, st, a);  \
+    else hipLaunchKernelGGL((dwconv_slide_fwd_kernel<T, M, false>), grid, dim3(SL_THREADS), 0, st, a);    \
+    break;
     SL_CASE(0) SL_CASE(1) SL_CASE(2) SL_CASE(3) SL_CASE(5) SL_CASE(7)
 #undef SL_CASE
     default: break;
@@ -542,9 +653,13 @@ static void slide_launch_fwd(const DwSlideArgs& a, dim3 grid, hipStream_t st) {
 }
 template <typename T, bool RES>
 static void slide_launch_bwd(const DwSlideArgs& a, dim3 grid, hipStream_t st) {
+  const bool xc = slide_exchange(a, (int)sizeof(T));
   switch (a.pro_mode) {
-#define SL_CASE(M) \
-  case M: hipLaunchKernelGGL((dwconv_slide_bwd_kernel<T, M, RES>), grid, dim3(SL_THREADS), 0, st, a); break;
+#define SL_CASE(M)                                                                                       \
+  case M:                                                                                                \
+    if (xc) hipLaunchKernelGGL((dwconv_slide_bwd_kernel<T, M, RES, true>), grid, dim3(SL_THREADS), 0, st, a);  \
+    else hipLaunchKernelGGL((dwconv_slide_bwd_kernel<T, M, RES, false>), grid, dim3(SL_THREADS), 0, st, a);    \
+    break;
     SL_CASE(0) SL_CASE(1) SL_CASE(2) SL_CASE(3) SL_CASE(5) SL_CASE(7)
 #undef SL_CASE
     default: break;
