@@ -29,8 +29,9 @@ step).  `achieved` = algorithmic FLOPs
 launches / summed launch durations measured with HIP events on the launch stream — in eager
 steps run right after the timed region when that replays a graph (events cannot bracket a node
 of a captured graph); the figure over ALL forward/dgrad GEMM launches is reported beside it
-(`all_gemm_*`).  `gpu_busy_frac` = sum of all kernel durations of one step (torch.profiler /
-roctracer over one eager step issuing the same kernels) / ms_per_step.  `traffic` is filled from profiles/ (rocprofv3 PMC
+(`all_gemm_*`).  `gpu_busy_frac` = kernel durations / wall span of a rocprofv3 kernel trace of the
+replayed step (profiles/rocprof_roofline.json, tools/rocprof_roofline.py; null without one);
+`eager_profile_kernel_ms_per_step` = kernel sum of ONE eager step under torch.profiler.  `traffic` is filled from profiles/ (rocprofv3 PMC
 pass of this build, see profiles/traffic.json "source") when available.
 
 cpu_baseline: the CPU oracle (oracle/torch_ref.py — bit-identical to the reference's module graph
@@ -382,6 +383,13 @@ def extra_legs(args, conf, model, opt, images, targets, step, loss_fn, dev, grap
             segmentron_amd.set_compute_dtype(args.dtype)
             SF.clear_weight_cache()
     return out
+
+
+def _graph_busy():
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "rocprof_roofline.json"))).get("graph_busy_frac")
+    except Exception:  # noqa: BLE001
+        return None
 
 
 def rocprof_fraction(args, flops_per_step, peak_tflops):
@@ -756,8 +764,12 @@ def main():
             "warmup": args.warmup, "prewarm_steps": prewarm, "ms_per_step": ms,
             "higher_is_better": True, "scaling": "weak",
             "launch": "hip_graph" if graph is not None else "eager",
-            "gpu_kernel_ms_per_step": kernel_ms, "kernels_per_step": n_kernels,
-            "gpu_busy_frac": (kernel_ms / ms) if kernel_ms else None,
+            # (an EAGER step under torch.profiler: kernel count and the sum of their durations —
+            # not comparable with the replayed step's wall time, so no ratio is formed from it)
+            "eager_profile_kernel_ms_per_step": kernel_ms, "kernels_per_step": n_kernels,
+            # busy fraction of the REPLAYED step: kernel durations / wall span of one rocprofv3
+            # kernel trace of this command (tools/rocprof_roofline.py), when profiles/ holds one
+            "gpu_busy_frac": _graph_busy(),
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "%s @%dx%d, batch %d/GPU (%s)"
                                    % (conf["workload"], args.height, args.width, batch, conf["tag"]),

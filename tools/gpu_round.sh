@@ -27,6 +27,9 @@ if [ "${SKIP_PROF:-0}" != "1" ]; then
   echo "rocprof rc=$?"
   f=$(find $OUT/prof -name '*kernel_stats.csv' | head -1)
   [ -n "$f" ] && cp $f $OUT/kernel_stats.csv && head -40 $OUT/kernel_stats.csv | cut -c1-200
+  t=$(find $OUT/prof -name '*kernel_trace.csv' | head -1)
+  [ -n "$f" ] && [ -n "$t" ] && python tools/rocprof_roofline.py $OUT/kernel_stats.csv $t > $OUT/rocprof_roofline.txt 2>&1 \
+    && cp $OUT/rocprof_roofline.json $OUT/rocprof_roofline_copy.json 2>/dev/null
   # keep the merge-back small: traces are large, the stats are what gets committed
   find $OUT/prof -name '*kernel_trace.csv' -size +20M -delete
 fi

@@ -33,6 +33,28 @@ def main(path):
            "glds_ms_per_step": tot / steps * 1e-6,
            "all_kernels_ms_per_step": sum(float(r["TotalDurationNs"]) for r in rows
                                           if "spin_kernel" not in r["Name"]) / steps * 1e-6}
+    # r06: GPU busy fraction with numerator AND denominator from the same graph-replay trace
+    # (the old figure divided an eager step's kernel sum by a replayed
+    # step's wall time and printed 1.015): sum of kernel durations / (last end - first start) over
+    # the middle 60 % of the kernel timeline, from the rocprofv3 kernel trace next to the stats CSV
+    trace = [f for f in (path.replace("kernel_stats", "kernel_trace"),
+                         os.path.join(os.path.dirname(path), "kernel_trace.csv")) if os.path.exists(f)]
+    if len(sys.argv) > 2:
+        trace = [sys.argv[2]]
+    if trace:
+        ev = []
+        for r in csv.DictReader(open(trace[0])):
+            if "spin_kernel" in r.get("Kernel_Name", ""):
+                continue
+            ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
+        ev.sort()
+        if len(ev) > 1000:
+            lo, hi = ev[len(ev) // 5][0], ev[len(ev) * 4 // 5][0]
+            win = [(a, b) for a, b in ev if lo <= a < hi]
+            busy = sum(b - a for a, b in win) / float(max(b for _, b in win) - lo)
+            out["graph_busy_frac"] = busy
+            out["graph_busy_note"] = ("sum of kernel durations / wall span over the middle 60 %% of the "
+                                      "kernel timeline of %s (%d kernels)" % (os.path.basename(trace[0]), len(win)))
     dst = os.path.join(os.path.dirname(os.path.abspath(path)), "rocprof_roofline.json")
     json.dump(out, open(dst, "w"), indent=1)
     print(json.dumps(out))
