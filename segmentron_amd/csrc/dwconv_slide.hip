@@ -293,18 +293,6 @@ __global__ __launch_bounds__(SL_THREADS, SL_OCC_F) void dwconv_slide_fwd_kernel(
 
   Q4 wt[9], sc, sh;
   sc = sh = q4_zero();
-  sl_load_taps(a, t.c, wt);
-  if (MODE & PRO_AFFINE) {
-    const float4 s4 = *reinterpret_cast<const float4*>(a.sc + t.c);
-    const float4 t4 = *reinterpret_cast<const float4*>(a.sh + t.c);
-    sc.lo = (f32x2){s4.x, s4.y}; sc.hi = (f32x2){s4.z, s4.w};
-    sh.lo = (f32x2){t4.x, t4.y}; sh.hi = (f32x2){t4.z, t4.w};
-  }
-#pragma unroll
-  for (int kh = 0; kh < 3; ++kh) {  // columns outside the image: zero taps
-    if (!t.lm) wt[kh * 3] = q4_zero();
-    if (!t.rm) wt[kh * 3 + 2] = q4_zero();
-  }
   const unsigned char* __restrict__ Xb = reinterpret_cast<const unsigned char*>(a.x) +
                                          (long)b.n * a.H * a.W * a.ldx * ES;
   unsigned char* __restrict__ Yb = reinterpret_cast<unsigned char*>(a.y) +
@@ -364,6 +352,20 @@ __global__ __launch_bounds__(SL_THREADS, SL_OCC_F) void dwconv_slide_fwd_kernel(
   raw_t ring[D][3];
 #pragma unroll
   for (int j = 0; j < D; ++j) issue(r0 - 1 + j, ring[j]);
+  // (taps and prologue parameters are requested BEHIND the first rows: one memory round trip at
+  // the head of every strip instead of two)
+  sl_load_taps(a, t.c, wt);
+  if (MODE & PRO_AFFINE) {
+    const float4 s4 = *reinterpret_cast<const float4*>(a.sc + t.c);
+    const float4 t4 = *reinterpret_cast<const float4*>(a.sh + t.c);
+    sc.lo = (f32x2){s4.x, s4.y}; sc.hi = (f32x2){s4.z, s4.w};
+    sh.lo = (f32x2){t4.x, t4.y}; sh.hi = (f32x2){t4.z, t4.w};
+  }
+#pragma unroll
+  for (int kh = 0; kh < 3; ++kh) {  // columns outside the image: zero taps
+    if (!t.lm) wt[kh * 3] = q4_zero();
+    if (!t.rm) wt[kh * 3 + 2] = q4_zero();
+  }
   commit(r0 - 1, ring[0], win[0], std::true_type{});
   issue(r0 - 1 + D, ring[0]);
   commit(r0, ring[1 % D], win[1], std::false_type{});
@@ -431,20 +433,6 @@ __global__ __launch_bounds__(SL_THREADS, 2) void dwconv_slide_bwd_kernel(const D
 
   Q4 wt[9], sc, sh;
   sc = sh = q4_zero();
-  sl_load_taps(a, t.c, wt);
-  if (MODE & PRO_AFFINE) {
-    const float4 s4 = *reinterpret_cast<const float4*>(a.sc + t.c);
-    const float4 t4 = *reinterpret_cast<const float4*>(a.sh + t.c);
-    sc.lo = (f32x2){s4.x, s4.y}; sc.hi = (f32x2){s4.z, s4.w};
-    sh.lo = (f32x2){t4.x, t4.y}; sh.hi = (f32x2){t4.z, t4.w};
-  }
-  // window column b pairs with kernel column 2 - b: a dy column outside the image is a zero tap
-  // column for the data gradient (its weight-gradient sums are dropped at the end)
-#pragma unroll
-  for (int kh = 0; kh < 3; ++kh) {
-    if (!t.lm) wt[kh * 3 + 2] = q4_zero();
-    if (!t.rm) wt[kh * 3] = q4_zero();
-  }
   const long img = (long)b.n * a.H * a.W;
   const unsigned char* __restrict__ Db = reinterpret_cast<const unsigned char*>(a.dy) + img * a.lddy * ES;
   const unsigned char* __restrict__ Xb = reinterpret_cast<const unsigned char*>(a.x) + img * a.ldx * ES;
@@ -532,6 +520,20 @@ __global__ __launch_bounds__(SL_THREADS, 2) void dwconv_slide_bwd_kernel(const D
     issue(r0 - 1 + j, ring[j]);
     rring[j] = xring[j] = sl_ld<raw_t>(Xb + (long)min(r0 + j, r1 - 1) * xpitch, xoff);
     if (RES) rring[j] = sl_ld<raw_t>(Rb + (long)min(r0 + j, r1 - 1) * rpitch, roff);
+  }
+  sl_load_taps(a, t.c, wt);
+  if (MODE & PRO_AFFINE) {
+    const float4 s4 = *reinterpret_cast<const float4*>(a.sc + t.c);
+    const float4 t4 = *reinterpret_cast<const float4*>(a.sh + t.c);
+    sc.lo = (f32x2){s4.x, s4.y}; sc.hi = (f32x2){s4.z, s4.w};
+    sh.lo = (f32x2){t4.x, t4.y}; sh.hi = (f32x2){t4.z, t4.w};
+  }
+  // window column b pairs with kernel column 2 - b: a dy column outside the image is a zero tap
+  // column for the data gradient (its weight-gradient sums are dropped at the end)
+#pragma unroll
+  for (int kh = 0; kh < 3; ++kh) {
+    if (!t.lm) wt[kh * 3 + 2] = q4_zero();
+    if (!t.rm) wt[kh * 3] = q4_zero();
   }
   commit(r0 - 1, ring[0], win[0], std::true_type{});
   issue(r0 - 1 + D, ring[0]);
