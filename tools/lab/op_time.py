@@ -94,6 +94,11 @@ def main():
         _, _, c0_, c1_, _ = K.dw_bwd_finalize(pb2, pw2, float(M), mean, invstd, bnw)
         K.bn_bwd_apply(g_, x, (2, sc, sh), c0_, c1_, out=g_)
     ops["dw_bwd+fin+apply"] = three
+
+    def red_fin():
+        pr = K.bn_bwd_reduce_partial(dy, x, (2, sc, sh), None, None)
+        K.bn_bwd_finalize_p(pr, float(M), mean, invstd, bnw)
+    ops["bn_bwd_reduce+fin"] = red_fin
     # what does one extra tiny launch cost inside a graph?  (pair - single)
     def pair():
         K.conv_gemm(x, wpw, C, 1, 1, 1, 0, 1, None, None, None, True)
