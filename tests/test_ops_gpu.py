@@ -266,6 +266,13 @@ DW_CASES = [
     (1, 33, 47, 96, 2, 1, 7),
     (2, 129, 131, 32, 2, 1, 3),
     (1, 19, 22, 40, 2, 1, 0),       # no prologue, ragged channel vectors
+    # r06, register-sliding kernels (csrc/dwconv_slide.hip, stride 1 / dilation 1): a map of >= 30 MB
+    # (neighbour columns by lane exchange + half-active buffer loads; odd width, 58 channel quads =
+    # 3.6 channel blocks, four strips), a map narrower than one column block, a map lower than one
+    # strip with the ReLU6 prologue
+    (2, 130, 259, 232, 1, 1, 3),
+    (1, 45, 5, 24, 1, 1, 1),
+    (1, 7, 130, 136, 1, 1, 7),
 ]
 
 
@@ -1040,3 +1047,27 @@ def test_pack_multi_matches_torch_casts_and_transposes(dtype):
     assert torch.equal(b2, w2.detach().view(24, 32).t().to(dtype).contiguous())
     assert Fm.packed_pointwise(w2, True, dtype) is b2
 
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+@pytest.mark.parametrize("shape", [(2, 65, 129, 728), (1, 33, 50, 72), (2, 130, 259, 232)])
+def test_dwconv_bwd_fused_adds_the_forked_gradient_in_its_store(shape, dtype):
+    """seg_dwconv3x3_bwd_fused_add (the RES instance of the sliding backward, r06; xception.py:36-42:
+    a block input feeds the residual sum and the first separable conv): g = relu_mask(x) * dgrad + res
+    with ONE rounding — against the same launch without `res` plus a float64 add; weight-gradient
+    partials identical to the launch without `res`."""
+    N, H, W, C = shape
+    g0 = torch.Generator(device=DEV).manual_seed(11)
+    x = torch.randn(N, H, W, C, device=DEV, generator=g0).to(dtype)
+    dy = torch.randn(N, H, W, C, device=DEV, generator=g0).to(dtype)
+    res = torch.randn(N, H, W, C, device=DEV, generator=g0).to(dtype)
+    w = torch.randn(C, 1, 3, 3, device=DEV, generator=g0) * 0.3
+    pro = (1, None, None)
+    g_plain, pw0, _ = K().dwconv_bwd_fused(x, dy, w, 1, pro, want_bn=False, torch_layout=True, raw_dw=True)
+    g_res, pw1, _ = K().dwconv_bwd_fused(x, dy, w, 1, pro, want_bn=False, torch_layout=True, raw_dw=True,
+                                         res=res)
+    assert torch.equal(pw0, pw1)
+    ref = g_plain.double() + res.double()
+    # g_plain is already rounded to the storage dtype: one more rounding of the sum
+    tol = (2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -22) * ref.abs().max().item()
+    assert (g_res.double() - ref).abs().max().item() <= tol
