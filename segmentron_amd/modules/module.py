@@ -18,13 +18,52 @@ class _FCNHead(nn.Module):
     def __init__(self, in_channels, channels, norm_layer=nn.BatchNorm2d):
         super().__init__()
         inter = in_channels // 4
+        # r06: hidden widths that are not a multiple of the 16-byte channel vector — DeepLabv3+ on
+        # xception with SOLVER.AUX True builds _FCNHead(728, nclass): 182 channels
+        # (deeplabv3_plus.py:29-30) — are PADDED inside the module (184): the extra output channels
+        # of the 3x3 conv have zero weights, their BatchNorm maps 0 to beta = 0, ReLU keeps 0, and
+        # the classifier's extra input columns are zero, so they carry neither signal nor gradient
+        # and stay at their initial values under SGD.  state_dict() / load_state_dict() speak the
+        # reference's shapes (hooks below): same keys, same tensors, checkpoints interchange.
+        vec = 8
+        inter_p = (inter + vec - 1) // vec * vec
+        self.inter, self.inter_p = inter, inter_p
         self.block = nn.Sequential(
-            nn.Conv2d(in_channels, inter, 3, padding=1, bias=False),
-            norm_layer(inter),
+            nn.Conv2d(in_channels, inter_p, 3, padding=1, bias=False),
+            norm_layer(inter_p),
             nn.ReLU(inplace=True),
             nn.Dropout(0.1),
-            nn.Conv2d(inter, channels, 1))
+            nn.Conv2d(inter_p, channels, 1))
         self.channels = channels
+        if inter_p != inter:
+            with torch.no_grad():
+                self.block[0].weight[inter:].zero_()
+                self.block[4].weight[:, inter:].zero_()
+            self._register_state_dict_hook(_FCNHead._slice_state)
+            self._register_load_state_dict_pre_hook(self._pad_state)
+
+    # (key suffix, dimension that carries the hidden channels, value of the padding)
+    _PADDED = (("block.0.weight", 0, 0.0), ("block.1.weight", 0, 1.0), ("block.1.bias", 0, 0.0),
+               ("block.1.running_mean", 0, 0.0), ("block.1.running_var", 0, 1.0),
+               ("block.4.weight", 1, 0.0))
+
+    @staticmethod
+    def _slice_state(module, state_dict, prefix, local_metadata):
+        for suffix, dim, _ in _FCNHead._PADDED:
+            k = prefix + suffix
+            if k in state_dict and state_dict[k].shape[dim] == module.inter_p:
+                state_dict[k] = state_dict[k].narrow(dim, 0, module.inter)
+        return state_dict
+
+    def _pad_state(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
+                   error_msgs):
+        for suffix, dim, fill in _FCNHead._PADDED:
+            k = prefix + suffix
+            if k in state_dict and state_dict[k].shape[dim] == self.inter:
+                t = state_dict[k]
+                shape = list(t.shape)
+                shape[dim] = self.inter_p - self.inter
+                state_dict[k] = torch.cat([t, torch.full(shape, fill, dtype=t.dtype, device=t.device)], dim)
 
     def forward(self, act):
         return head_tail(act, self.block[0], self.block[1], self.block[3], self.block[4],

@@ -384,3 +384,34 @@ def test_weight_cache_bookkeeping_on_the_host():
         assert id(keep) in F._PLAN_FILTER[0]
     assert F._PLAN_FILTER[0] is None
     F.clear_weight_cache()
+
+
+def test_fcn_head_pads_odd_hidden_width_but_keeps_the_reference_state_dict():
+    """DeepLabv3+ / xception65 with SOLVER.AUX True: _FCNHead(728, nclass) has 728 // 4 = 182 hidden
+    channels in the reference (deeplabv3_plus.py:29-30, module.py:13-26).  The HIP module holds 184
+    (16-byte channel vectors) and speaks 182 in state_dict() / load_state_dict()."""
+    import torch
+    import segmentron_amd
+    from segmentron_amd.config import cfg, reset_cfg
+    from conftest import C3_OVERRIDES
+    reset_cfg()
+    cfg.update_from_list(C3_OVERRIDES + ["SOLVER.AUX", "True"])
+    cfg.PHASE = "test"
+    cfg.check_and_freeze()
+    model = segmentron_amd.get_segmentation_model()
+    sd = model.state_dict()
+    want = {"auxlayer.block.0.weight": (182, 728, 3, 3), "auxlayer.block.1.weight": (182,),
+            "auxlayer.block.1.bias": (182,), "auxlayer.block.1.running_mean": (182,),
+            "auxlayer.block.1.running_var": (182,), "auxlayer.block.1.num_batches_tracked": (),
+            "auxlayer.block.4.weight": (19, 182, 1, 1), "auxlayer.block.4.bias": (19,)}
+    assert {k: tuple(v.shape) for k, v in sd.items() if k.startswith("auxlayer.")} == want
+    new = {k: (torch.randn_like(v) if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+    model.load_state_dict(new, strict=True)
+    back = model.state_dict()
+    assert all(torch.equal(back[k], new[k]) for k in new)
+    head = model.auxlayer
+    assert head.block[0].weight.shape[0] == 184 and head.block[4].weight.shape[1] == 184
+    assert head.block[0].weight[182:].abs().max().item() == 0.0
+    assert head.block[4].weight[:, 182:].abs().max().item() == 0.0
+    assert torch.equal(head.block[1].weight[182:].detach(), torch.ones(2))
+    reset_cfg()

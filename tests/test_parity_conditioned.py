@@ -509,3 +509,42 @@ def test_c3_bf16_graphed_train_steps_follow_the_oracle_trajectory():
     # (the bf16 gradient itself: cosine 0.90 / norm ratio 1.12 vs fp64 on this net, reference
     # autocast 0.92 / 1.10 — test above; measured here 0.90-0.92 / 1.09-1.12)
     assert cos >= 0.85 and abs((na / nb) ** 0.5 - 1.0) <= 0.15
+
+
+@pytest.mark.gpu
+def test_c3_with_auxiliary_head_182_hidden_channels_matches_oracle():
+    """DeepLabv3+/xception65 with SOLVER.AUX True (VERDICT r05 Missing #4): the reference builds
+    _FCNHead(728, nclass) with 728 // 4 = 182 hidden channels
+    (/root/reference/segmentron/models/deeplabv3_plus.py:29-30, modules/module.py:13-26), not a
+    multiple of the 16-byte channel vector; the HIP module pads them to 184 inside and keeps the
+    reference's state_dict (tests/test_host_api.py checks the schema).  One fp32 train step at
+    65x129 against the CPU oracle with the auxiliary loss (weight 0.4): 1e-3 bars."""
+    import segmentron_amd
+    from segmentron_amd.config import cfg, reset_cfg
+    from oracle import parity as OP
+    reset_cfg()
+    cfg.update_from_list(C3_OVERRIDES + ["SOLVER.AUX", "True"])
+    cfg.PHASE = "test"
+    cfg.check_and_freeze()
+    segmentron_amd.set_compute_dtype(torch.float32)
+    model = segmentron_amd.get_segmentation_model()
+    assert model.auxlayer.block[0].weight.shape[0] == 184
+    sd = synth.synth_like(model.state_dict(), seed=3, conditioned=True)
+    assert sd["auxlayer.block.0.weight"].shape[0] == 182
+    del model
+    x, y = OP.inputs(2, 65, 129, seed=3)
+    ref = OP.oracle_step(sd, x, y, torch.float64, aux=True)
+    got = OP.hip_step("fp32", sd, x, y)
+    c = OP.compare(got, ref)
+    aux_keys = [k for k in ref["grads"] if k.startswith("auxlayer.")]
+    assert len(aux_keys) == 5 and all(k in got["grads"] for k in aux_keys)
+    pad = got["grads"]["auxlayer.block.0.weight"][182:].abs().max().item()
+    print("PARITY-COND c3 + aux head (182 -> 184 hidden channels) fp32 65x129: loss rel %.2e logits "
+          "max-rel %.2e gradients global rel %.2e; padded rows' gradient %.1e"
+          % (c["loss_rel"], c["logits_maxrel"], c["grad_global_rel"], pad))
+    assert c["finite"] and c["grad_tensors_missing"] == 0
+    assert c["loss_rel"] < 1e-3 and c["logits_maxrel"] < 1e-3 and c["grad_global_rel"] <= 1e-3
+    assert pad == 0.0  # the padded channels carry no gradient
+    b16 = OP.compare(OP.hip_step("bf16", sd, x, y), ref)  # (the throughput path runs it too)
+    assert b16["finite"] and b16["logits_l2rel"] <= 3e-2 and b16["grad_cosine"] >= 0.98, b16
+    reset_cfg()
