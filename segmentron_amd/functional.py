@@ -170,8 +170,9 @@ def finish_bn(bn, partial, count, mean_offset=None, y=None):
 # `num_batches_tracked += 1` (torch nn.BatchNorm2d, every training forward) is deferred only INSIDE
 # a bn_counter_scope — which SegBaseModel.__call__ opens around every model forward — so that one
 # forward pays ONE multi-tensor launch instead of ~146 scalar increments.  The scope owns the
-# list: a successful forward flushes it, a forward that raised drops it (its BatchNorms did not
-# complete a forward), nothing can stay pending after the outermost scope has closed, and a new
+# list: the outermost scope flushes it on the way out — also when the forward raised, because the
+# BatchNorms it did reach have already moved their running statistics and torch would have counted
+# them — nothing can stay pending after the outermost scope has closed, and a new
 # model cannot forget the flush (r04: CCNet did; VERDICT r04 Weak #1).
 _PENDING_COUNTERS = []
 _COUNTER_SCOPE = [0]
@@ -185,10 +186,7 @@ class bn_counter_scope:
     def __exit__(self, exc_type, exc, tb):
         _COUNTER_SCOPE[0] -= 1
         if _COUNTER_SCOPE[0] == 0:
-            if exc_type is None:
-                flush_bn_counters()
-            else:
-                del _PENDING_COUNTERS[:]
+            flush_bn_counters()
         return False
 
 
