@@ -22,7 +22,8 @@ the timed region replays it; `"launch": "hip_graph"` in the line says so, `--no-
 a failed capture falls back to eager launches.  N > 1 runs eager under DDP.
 
 roofline: the dominant kernel is the MFMA implicit-GEMM `conv_gemm_glds_kernel` (direct-to-LDS
-256x256 / 192x256 tiles, csrc/conv_gemm_glds.hip: every 1x1 stride-1 convolution with O >= 384 whose input needs no prologue,
+256x256 / 192x256 tiles, eight waves; r06: + `conv_gemm_glds4_kernel`, 224x256 tiles on four waves,
+for the launches of at most two rounds), csrc/conv_gemm_glds.hip / conv_gemm_glds4.hip: every 1x1 stride-1 convolution with O >= 384 whose input needs no prologue,
 forward + data gradient: the Xception middle / exit flow — ~110 of the ~157 GEMM launches per
 step).  `achieved` = algorithmic FLOPs
 (2 * output pixels * K * O per launch — SURVEY.md §8d counts conv MACs only) summed over its
@@ -751,7 +752,7 @@ def main():
         # the 256-wide kernel at all — r04's c5 line said frac 0.0 of a kernel it never launched):
         # there the figure is taken over ALL forward / data-gradient conv GEMM launches, and
         # `top_kernels` names what the step actually spends its time in
-        roof_kernel = "conv_gemm_glds_kernel (bf16, direct-to-LDS 1x1 GEMM)" if args.dtype == "bf16" \
+        roof_kernel = "conv_gemm_glds_kernel + conv_gemm_glds4_kernel (bf16, direct-to-LDS 1x1 GEMM)" if args.dtype == "bf16" \
             else "conv_gemm_px256_kernel<fp32>"
         if args.config != "c3" or launches == 0:
             roof_kernel = "conv_gemm_* (all forward / data-gradient convolution GEMM launches)"

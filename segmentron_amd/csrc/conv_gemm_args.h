@@ -36,10 +36,14 @@ int launch_conv_gemm_glds(ConvGemmArgs a, hipStream_t stream);
 bool conv_gemm_glds_kxk_usable(int dtype, const ConvGemmArgs& a);
 int launch_conv_gemm_glds_kxk(ConvGemmArgs a, hipStream_t stream);
 
-// r05: 256- or 192-row tiles, whichever fills the 256 CUs in fewer / shorter rounds; a
-// statistics row describes glds_rows_per_tile(M, O) pixels
-int glds_rows_per_tile(long M, int O);
-int glds_tiles_m(long M, int O);
+// the four-wave generation of the same pipeline (conv_gemm_glds4.hip, 1x1 only); rows = 224 per
+// tile, tiles_m / tiles_n already set for it
+int launch_conv_gemm_glds4(const ConvGemmArgs& a, int rows, hipStream_t stream);
+
+// r05: 256- or 192-row tiles (r06: or 224, 1x1 only), whichever fills the 256 CUs in fewer /
+// shorter rounds; a statistics row describes glds_rows_per_tile(M, O, kxk) pixels
+int glds_rows_per_tile(long M, int O, bool kxk);
+int glds_tiles_m(long M, int O, bool kxk);
 
 // direct 3x3 stride-1 kernel for few channels at large spatial sizes (conv3x3_direct.hip)
 bool conv3x3_direct_usable(int dtype, const ConvGemmArgs& a);

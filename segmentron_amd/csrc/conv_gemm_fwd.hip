@@ -460,7 +460,7 @@ extern "C" int seg_conv_gemm_stat_rows(int dtype, int N, int Ho, int Wo, int C, 
     // checks, which seg_conv_gemm_fwd settles by zero-filling the rows a fallback leaves out)
     if (seg::g_gemm_px256 >= 2 && dtype == seg::DT_BF16 && pro_mode == seg::PRO_NONE &&
         !has_bias && (C % 8) == 0 && (O % 8) == 0)
-      return seg::glds_tiles_m(M, O);
+      return seg::glds_tiles_m(M, O, false);
     return seg::px256_tiles_m(M);
   }
   {  // KxK on the direct-to-LDS pipeline (the predicate does not look at the input size)
@@ -469,7 +469,7 @@ extern "C" int seg_conv_gemm_stat_rows(int dtype, int N, int Ho, int Wo, int C, 
     probe.tconv = tconv; probe.out_s = 1; probe.C = C; probe.O = O; probe.ldx = 8; probe.ldy = 8;
     probe.N = 1; probe.Hi = 1; probe.Wi = 1; probe.M = (int)M; probe.pro_mode = pro_mode;
     probe.bias = has_bias ? reinterpret_cast<const float*>(&probe) : nullptr;
-    if (gemm_use_glds_kxk(dtype, probe)) return seg::glds_tiles_m(M, O);
+    if (gemm_use_glds_kxk(dtype, probe)) return seg::glds_tiles_m(M, O, true);
   }
   {  // the direct 3x3 kernel (stride 1, pad 1: the input has the output's size)
     seg::ConvGemmArgs probe = {};

@@ -154,7 +154,8 @@ __global__ __launch_bounds__(GL_THREADS, 2) void conv_gemm_glds_kernel(const Con
         }
         val[q] = Vec<T>::pack(f);
       }
-      if (STATS) {  // of the values as stored; rows beyond M are exact zeros
+      // of the values as stored; rows beyond M are exact zeros (EP: corrected garbage — skipped)
+      if (STATS && (!EP || p < a.M)) {
         float f[VEC];
         Vec<T>::unpack(val[q], f);
 #pragma unroll
@@ -214,12 +215,25 @@ bool conv_gemm_glds_usable(int dtype, const ConvGemmArgs& a) {
 // shapes of tools/lab/gemm_ab (the twelfth, 304 -> 256 @263682 pixels, 5 vs 6 rounds, by 3 %).
 constexpr int GLDS_FIXED_ROWS = 96;
 
-int glds_rows_per_tile(long M, int O) {
+// r06: + 224 rows, on the four-wave generation (conv_gemm_glds4.hip: 1 x 4 waves of 224 x 64), for
+// 1x1 launches of at most two rounds — where the tile count decides: 16770 pixels x 728 channels are
+// 66 x 3 = 198 tiles of 256 rows (one round, 77 % of the CUs) or 75 x 3 = 225 of 224 (one round,
+// 88 %, 7/8 of the MFMAs per wave); x 1536 channels 396 (two rounds) or 450 (two shorter rounds).
+// In the captured step (tools/lab/prof_ab.sh + trace_ab.py, per layer, profiles/r06_gemm_w4.md):
+// 728 -> 728 forward 29.96 -> 28.88 us, 1024 / 1536 -> 1536 82.1 -> 75.0 and 106.8 -> 97.6.  With
+// many rounds the four-wave kernel is no better than this one (one wave per SIMD: slower ramp and
+// epilogue; 304 -> 256 @263682 pixels: 85.2 -> 83.6 forward, 51.9 -> 57.1 / 76.4 -> 84.0 on the
+// short-K data gradients), and neither are its 256- and 192-row forms (net zero over the exit
+// flow) — they are not instantiated.
+constexpr long GLDS_W4_MAX_TILES = 512;
+
+static int glds_pick_rows(long M, int O, bool with224) {
   const long tn = (O + GL_BN - 1) / GL_BN;
   int best = 256;
   long best_cost = -1;
-  for (int bm = 256; bm >= 192; bm -= 64) {
+  for (int bm = 256; bm >= 192; bm -= 32) {
     const long tiles = ((M + bm - 1) / bm) * tn;
+    if (bm == 224 && (!with224 || tiles > GLDS_W4_MAX_TILES)) continue;
     const long cost = ((tiles + 255) / 256) * (bm + GLDS_FIXED_ROWS);
     if (best_cost < 0 || cost < best_cost) {
       best_cost = cost;
@@ -229,8 +243,10 @@ int glds_rows_per_tile(long M, int O) {
   return best;
 }
 
-int glds_tiles_m(long M, int O) {
-  const int bm = glds_rows_per_tile(M, O);
+int glds_rows_per_tile(long M, int O, bool kxk) { return glds_pick_rows(M, O, !kxk); }
+
+int glds_tiles_m(long M, int O, bool kxk) {
+  const int bm = glds_rows_per_tile(M, O, kxk);
   return (int)((M + bm - 1) / bm);
 }
 
@@ -253,11 +269,20 @@ static int launch_glds_inst(const ConvGemmArgs& a, hipStream_t stream) {
 
 template <bool EP, bool STATS, bool KXK>
 static int launch_glds_rows(ConvGemmArgs a, hipStream_t stream) {
-  const int bm = glds_rows_per_tile(a.M, a.O);
+  // The data gradient with the folded-BatchNorm correction stays on eight waves: its epilogue
+  // (fp32 patch, unpack / correct / round) is instruction-bound and wants the second wave per SIMD
+  // — 728 -> 728 in the step: 33.7 us on 256 rows / eight waves, 34.9 on 224 / four.  It writes no
+  // statistics rows, so its tile height is its own business.
+  const int bm = glds_pick_rows(a.M, a.O, !KXK && !(EP && !STATS));
   a.tiles_m = (a.M + bm - 1) / bm;
   a.tiles_n = (a.O + GL_BN - 1) / GL_BN;
+  if constexpr (!KXK) {
+    if (bm == 224) return launch_conv_gemm_glds4(a, bm, stream);
+  }
   if (bm == 256) return launch_glds_inst<EP, STATS, KXK, 4>(a, stream);
-  return launch_glds_inst<EP, STATS, KXK, 3>(a, stream);
+  if (bm == 192) return launch_glds_inst<EP, STATS, KXK, 3>(a, stream);
+  set_error("conv_gemm_glds: no %d-row tile on the eight-wave kernel", bm);
+  return 2;
 }
 
 int launch_conv_gemm_glds(ConvGemmArgs a, hipStream_t stream) {

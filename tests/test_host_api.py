@@ -236,11 +236,14 @@ def test_torch_custom_ops_are_registered_with_fake_implementations():
         assert tuple(cnt.shape) == (59,) and cnt.dtype == torch.int64
 
 
-def _g4_rows(M, O):
-    """csrc/conv_gemm_glds.hip glds_rows_per_tile: rounds on 256 CUs x (tile rows + fixed cost)."""
+def _g4_rows(M, O, kxk=False):
+    """csrc/conv_gemm_glds.hip glds_rows_per_tile: rounds on 256 CUs x (tile rows + fixed cost);
+    r06: + 224-row tiles (the four-wave kernel, 1x1 only) where they make at most 512 tiles."""
     best = None
-    for bm in (256, 192):
+    for bm in (256, 224, 192):
         tiles = -(-M // bm) * -(-O // 256)
+        if bm == 224 and (kxk or tiles > 512):
+            continue
         cost = -(-tiles // 256) * (bm + 96)
         if best is None or cost < best[0]:
             best = (cost, bm)
@@ -268,12 +271,17 @@ def test_kernel_selection_queries_of_the_c_library():
     # small map: first-generation 128-pixel tiles; 1x1 with O >= 384: the 256-pixel-tile kernels
     assert q("seg_conv_gemm_stat_rows", BF16, 2, 33, 65, 32, 64, 3, 3, 1, 1, 1, 0, 0, 0) == (2 * 33 * 65 + 127) // 128
     # ... bf16 without prologue / bias: the r05 kernel picks 256- or 192-row tiles, whichever
-    # fills the 256 CUs in fewer / shorter rounds (728 -> 728 @ 16770 pixels: 198 tiles of 256
-    # rows in one round; 728 -> 1024: 352 tiles of 192 rows instead of 264 of 256, both two
-    # rounds); with a bias or in fp32: the 256-pixel-tile kernel
-    assert q("seg_conv_gemm_stat_rows", BF16, 2, 65, 129, 728, 728, 1, 1, 1, 0, 1, 0, 0, 0) == (2 * 65 * 129 + 255) // 256
+    # fills the 256 CUs in fewer / shorter rounds, r06 adds 224 rows on the four-wave kernel
+    # (728 -> 728 @ 16770 pixels: 225 tiles of 224 rows in ONE round instead of 198 of 256;
+    # 728 -> 1024: 352 tiles of 192 rows instead of 264 of 256 or 300 of 224, all two rounds;
+    # 1536 -> 1536: 450 of 224, two rounds); with a bias or in fp32: the 256-pixel-tile kernel
+    assert q("seg_conv_gemm_stat_rows", BF16, 2, 65, 129, 728, 728, 1, 1, 1, 0, 1, 0, 0, 0) == (2 * 65 * 129 + 223) // 224
     assert q("seg_conv_gemm_stat_rows", BF16, 2, 65, 129, 728, 1024, 1, 1, 1, 0, 1, 0, 0, 0) == (2 * 65 * 129 + 191) // 192
-    assert _g4_rows(2 * 65 * 129, 728) == 66 and _g4_rows(2 * 65 * 129, 1024) == 88
+    assert q("seg_conv_gemm_stat_rows", BF16, 2, 65, 129, 1536, 1536, 1, 1, 1, 0, 1, 0, 0, 0) == (2 * 65 * 129 + 223) // 224
+    assert _g4_rows(2 * 65 * 129, 728) == 75 and _g4_rows(2 * 65 * 129, 1024) == 88
+    # many rounds: the 224-row tile is not offered (304 -> 256 @ 263682 pixels: 1178 tiles)
+    Md = 2 * 257 * 513
+    assert q("seg_conv_gemm_stat_rows", BF16, 2, 257, 513, 304, 256, 1, 1, 1, 0, 1, 0, 0, 0) == _g4_rows(Md, 256) == (Md + 191) // 192
     assert q("seg_conv_gemm_stat_rows", BF16, 2, 65, 129, 728, 728, 1, 1, 1, 0, 1, 0, 1, 0) == (2 * 65 * 129 + 255) // 256
     assert q("seg_conv_gemm_stat_rows", F32, 2, 65, 129, 728, 728, 1, 1, 1, 0, 1, 0, 0, 0) == (2 * 65 * 129 + 255) // 256
     # a handful of pixels in float32 (ASPP image pooling, PSP bins): one row per 8-pixel chunk
@@ -284,7 +292,7 @@ def test_kernel_selection_queries_of_the_c_library():
     # ResNet layer3 3x3 (256 -> 256, dilation 2) without a prologue: the direct-to-LDS pipeline
     # as an implicit GEMM (256-pixel tiles); with a pending BatchNorm/ReLU: first generation
     Mr = 2 * 129 * 257
-    assert q("seg_conv_gemm_stat_rows", BF16, 2, 129, 257, 256, 256, 3, 3, 1, 2, 2, 0, 0, 0) == _g4_rows(Mr, 256)
+    assert q("seg_conv_gemm_stat_rows", BF16, 2, 129, 257, 256, 256, 3, 3, 1, 2, 2, 0, 0, 0) == _g4_rows(Mr, 256, kxk=True)
     assert q("seg_conv_gemm_stat_rows", BF16, 2, 129, 257, 256, 256, 3, 3, 1, 2, 2, 0, 0, 3) == (Mr + 127) // 128
     # weight gradient: conv2 on the direct kernel (one partial per persistent block); plain 1x1
     # 728x728 on the direct-to-LDS kernel (~one block per CU: 36 tiles x 7 splits)

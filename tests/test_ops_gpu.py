@@ -91,6 +91,11 @@ CONV_CASES = [
     (1, 40, 110, 512, 512, 3, 1, 4, 4, 0, False, False),
     (1, 70, 72, 320, 264, 3, 1, 1, 1, 0, False, True),
     (1, 70, 72, 256, 256, 3, 1, 0, 1, 0, False, False),
+    # r06, the four-wave direct-to-LDS kernel (224-row tiles: 1x1 launches of at most two rounds
+    # in which 192 rows would need one more round than 224): ragged last row tile, ragged column
+    # tile, K not a multiple of 32, slice in / out
+    (1, 130, 200, 200, 392, 1, 1, 0, 1, 0, False, True),
+    (2, 100, 128, 264, 504, 1, 1, 0, 1, 0, False, False),
 ]
 
 
@@ -139,6 +144,38 @@ def test_conv_gemm_fwd(case, dtype):
     if sl:  # nothing outside the slice was touched
         full = y.as_strided((N, Ho, Wo, pitch), y.stride(), y.storage_offset() - vec)
         assert torch.isnan(full[..., :vec].float()).all() and torch.isnan(full[..., vec + O:].float()).all()
+
+
+@pytest.mark.parametrize("want_stats", [False, True], ids=["correction", "correction+stats"])
+@pytest.mark.parametrize("geom", [(1, 130, 200, 200, 392), (2, 45, 47, 328, 728)])
+def test_conv_gemm_epilogue_correction_on_the_direct_to_lds_kernels(geom, want_stats):
+    """y = acc - c0[o] - c1[o] * x[p][o] (the data gradient through a folded BatchNorm) on the
+    bf16 1x1 launches the direct-to-LDS kernels serve.  First geometry: the one whose forward
+    takes 224-row tiles on the four-wave kernel (r06) — correction only stays on eight waves
+    with its own tile height, correction + statistics must follow the statistics rows the
+    caller sized (four waves); second: 192-row tiles on eight waves.  Statistics are those of
+    the values as stored."""
+    N, H, W, C, O = geom
+    dtype = torch.bfloat16
+    x = quant(rnd((N, C, H, W), 1), dtype)
+    w = quant(rnd((O, C, 1, 1), 2, (2.0 / C) ** 0.5), dtype)
+    xe = quant(rnd((N, O, H, W), 3), dtype)
+    c0, c1 = rnd((O,), 4, 0.05), rnd((O,), 5, 0.3)
+    ref = TF.conv2d(x.double(), w.double()) - c0.view(1, -1, 1, 1).double() \
+        - c1.view(1, -1, 1, 1).double() * xe.double()
+    xd, xed = to_dev_nhwc(x, dtype), to_dev_nhwc(xe, dtype)
+    wp = F().pack_conv_weight(w.to(DEV), C, dtype)
+    y, partial = K().conv_gemm(xd, wp, O, 1, 1, 1, 0, 1, None, None, None, want_stats=want_stats,
+                               ep=(xed, c0.to(DEV), c1.to(DEV)))
+    got = to_cpu_nchw(y)
+    assert_close(got, ref, dtype, "corrected y")
+    assert (partial is not None) == want_stats
+    if want_stats:
+        st = got.double()  # the values as stored
+        sums = K().colsum(partial.view(partial.shape[0], -1)).cpu()
+        assert_close(sums[:O], st.sum((0, 2, 3)), torch.float32, "sum",
+                     scale=st.abs().sum((0, 2, 3)).max().item(), fac=5)
+        assert_close(sums[O:], (st * st).sum((0, 2, 3)), torch.float32, "sumsq", fac=5)
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=IDS)

@@ -17,6 +17,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <vector>
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
@@ -127,7 +128,20 @@ int main(int argc, char** argv) {
       CK(hipMalloc(&y[k], M * c.O * 2)); CK(hipMalloc(&sp[k], (long)rows[k] * 2 * c.O * 4));
       CK(hipMemset(y[k], 0xff, M * c.O * 2)); CK(hipMemset(sp[k], 0xff, (long)rows[k] * 2 * c.O * 4));
     }
+    // GEMM_AB_ROTATE=n: the timed launches cycle through n copies of the pixel operand (and of the
+    // correction operand), so that it comes from the Infinity Cache / HBM as in the train step, not
+    // from the 32 MB of L2 a back-to-back repeat of ONE launch leaves it in (r06: the repeat flattered
+    // every main-loop improvement: 3.80 -> 3.63 ms in this harness was 2.461 -> 2.441 ms in the step)
+    static const int rot = getenv("GEMM_AB_ROTATE") ? atoi(getenv("GEMM_AB_ROTATE")) : 1;
+    std::vector<uint16_t*> xs(rot, x), eps(rot, epx);
+    for (int r = 1; r < rot; ++r) {
+      CK(hipMalloc(&xs[r], M * c.C * 2)); CK(hipMalloc(&eps[r], M * c.O * 2));
+      CK(hipMemcpy(xs[r], x, M * c.C * 2, hipMemcpyDeviceToDevice));
+      CK(hipMemcpy(eps[r], epx, M * c.O * 2, hipMemcpyDeviceToDevice));
+    }
+    int turn = 0;
     auto run = [&](int k) {
+      const uint16_t* x = xs[turn % rot]; const uint16_t* epx = eps[turn % rot]; ++turn;
       return L[k].fwd(DT_BF16, x, c.C, c.N, c.H, c.W, c.C, w, c.O, c.KH, c.KH, 1, pad, c.dil, 0, nullptr,
                       nullptr, nullptr, y[k], c.O, c.H, c.W, c.H, c.W, 1, c.mode == 1 ? sp[k] : nullptr,
                       c.mode == 2 ? epx : nullptr, c.O, c.mode == 2 ? c0 : nullptr,
@@ -211,6 +225,7 @@ int main(int argc, char** argv) {
       step_us[k] += (double)t[0] * c.per_step;
       CK(hipFree(y[k])); CK(hipFree(sp[k]));
     }
+    for (int r = 1; r < rot; ++r) { CK(hipFree(xs[r])); CK(hipFree(eps[r])); }
     CK(hipFree(x)); CK(hipFree(w)); CK(hipFree(epx)); CK(hipFree(c0)); CK(hipFree(c1));
   }
   printf("per-step estimate (launch counts of one C3 train step on these shapes):\n");

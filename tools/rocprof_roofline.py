@@ -25,7 +25,9 @@ def main(path):
         sys.exit("no ce_fwd_kernel launches in %s" % path)
     # the direct-to-LDS 1x1 GEMM (its KxK instances excluded: bench.py counts the FLOPs of the
     # 1x1 launches it times)
-    glds = [r for r in rows if "conv_gemm_glds_kernel" in r["Name"] and not _is_kxk(r["Name"])]
+    # (r06: + its four-wave generation conv_gemm_glds4_kernel<EP, STATS, WM, IM, JN>, 1x1 only)
+    glds = [r for r in rows if ("conv_gemm_glds_kernel" in r["Name"] and not _is_kxk(r["Name"]))
+            or "conv_gemm_glds4_kernel" in r["Name"]]
     tot = sum(float(r["TotalDurationNs"]) for r in glds)
     calls = sum(int(r["Calls"]) for r in glds)
     out = {"source": os.path.relpath(path, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))),

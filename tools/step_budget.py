@@ -11,7 +11,7 @@ import re
 import sys
 
 CLASSES = [
-    ("forward / data-gradient GEMM, direct-to-LDS (conv_gemm_glds)", r"conv_gemm_glds_kernel|conv_gemm_g4_kernel"),
+    ("forward / data-gradient GEMM, direct-to-LDS (conv_gemm_glds)", r"conv_gemm_glds_kernel|conv_gemm_glds4_kernel|conv_gemm_g4_kernel"),
     ("forward / data-gradient convolutions, other (first-generation GEMM, px256, direct 3x3)",
      r"conv_gemm_fwd_kernel|conv_gemm_px256_kernel|conv3x3_direct_kernel"),
     ("weight-gradient GEMM", r"conv_wgrad_glds_kernel|conv_gemm_wgrad_kernel|conv3x3_wgrad_direct"),
