@@ -235,6 +235,30 @@ int seg_bn_bwd_apply(int dtype, const void* g, long ldg, const void* x, long ldx
                      const float* chan_mul, long rows_per_n, const void* elem_mul, long ldm,
                      void* dx, long lddx, long M, int C, void* stream);
 
+/* ---- nn.GroupNorm(min(32, C), C): the 'GN' choice of cfg.MODEL.BN_TYPE -------------------------
+ * Replaces the nn.GroupNorm modules segmentron/modules/batch_norm.py:105-108,129 builds (F.group_norm
+ * forward + autograd backward).  Group statistics are per SAMPLE: z = x*a[n][c] + b[n][c] — a
+ * per-(sample, channel) affine, materialised (it cannot ride in a per-channel prologue).
+ *   seg_gn_moments      partial[n][chunk][2][C] = (sum u, sum u*v) over the chunk's pixels; v null:
+ *                       v = u (sum x, sum x^2).  chunks = seg_gn_chunks(HW).
+ *   seg_gn_fwd_finalize mean_rstd[n][g][2] and coef[n][3][C] = (gamma*rstd, 0, beta - mean*gamma*rstd)
+ *                       (gamma / beta nullable: affine=False), float64 sums, biased variance
+ *   seg_gn_bwd_finalize from the moments of (u, v) = (dz, x): coef[n][3][C] of
+ *                       dx = k1*dz + k2*x + k3, and contrib[n][2][C] = per-sample terms of
+ *                       (dgamma, dbeta) — sum over n with seg_colsum
+ *   seg_gn_affine       out = coef[n][0][c]*u + coef[n][1][c]*v + coef[n][2][c]   (v nullable) */
+int seg_gn_chunks(long HW);
+int seg_gn_moments(int dtype, const void* u, long ldu, const void* v, long ldv, int N, long HW,
+                   int C, float* partial, void* stream);
+int seg_gn_fwd_finalize(const float* partial, int N, long HW, int C, int G, const float* gamma,
+                        const float* beta, double eps, float* mean_rstd, float* coef,
+                        void* stream);
+int seg_gn_bwd_finalize(const float* partial, int N, long HW, int C, int G,
+                        const float* mean_rstd, const float* gamma, float* coef, float* contrib,
+                        void* stream);
+int seg_gn_affine(int dtype, const void* u, long ldu, const void* v, long ldv, const float* coef,
+                  void* out, long ldo, int N, long HW, int C, void* stream);
+
 /* ---- linear BatchNorm folded into a 1x1 convolution -------------------------------------------
  * `relu_first` SeparableConv2d (segmentron/modules/basic.py:46-50) has no non-linearity between
  * bn_depth and the pointwise conv: W (s.*x + t) = (W diag(s)) x + W t.

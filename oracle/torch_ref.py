@@ -27,8 +27,12 @@ class OracleNet:
     """
 
     def __init__(self, sd, training=False, eps_encoder=None, eps_decoder=None, momentum=None,
-                 drop_p=0.1, output_stride=16, aux=False, nclass=19, multi_dilation=None):
+                 drop_p=0.1, output_stride=16, aux=False, nclass=19, multi_dilation=None,
+                 norm="BN"):
         self.sd = sd
+        # cfg.MODEL.BN_TYPE: "BN" or "GN" = nn.GroupNorm(min(32, C), C), eps 1e-5 — the eps setter
+        # of solver/optimizer.py:10-11 only touches BatchNorm classes (modules/batch_norm.py:105-108)
+        self.norm = norm
         self.training = training
         self.eps_encoder = 1e-5 if eps_encoder is None else eps_encoder
         self.eps_decoder = 1e-5 if eps_decoder is None else eps_decoder
@@ -47,6 +51,11 @@ class OracleNet:
         """nn.BatchNorm2d forward: train = biased batch var for
         normalisation, unbiased for running_var; eval = running stats."""
         sd = self.sd
+        if self.norm == "GN" and (prefix + ".running_mean") not in sd:
+            # (the reference builds its heads without passing norm_layer — pspnet.py:23-25 —
+            # so they keep BatchNorm2d under BN_TYPE 'GN': the state_dict tells which is which)
+            C = x.shape[1]
+            return F.group_norm(x, min(32, C), sd[prefix + ".weight"], sd[prefix + ".bias"], 1e-5)
         if self.training:
             sd[prefix + ".num_batches_tracked"] += 1
         return F.batch_norm(x, sd[prefix + ".running_mean"], sd[prefix + ".running_var"],

@@ -24,13 +24,14 @@
 namespace seg {
 
 constexpr int GL4_THREADS = 256;
-// Ring depth.  A slot requested at the barrier of slot j is needed RING - 1 slot times later: with
-// four slots and a ~2 us DMA round trip under load a slot cannot take less than 2 / 3 us — measured:
-// 0.70 us per slot against 0.44 us of MFMAs.  Five slots (all 160 KiB of the CU's LDS) keep four
-// requests in flight.
-#ifndef GL4_RING
-#define GL4_RING 4
-#endif
+// Ring depth: four slots, three requests in flight.  Five (all 160 KiB of the CU's LDS) were
+// measured and are not faster (profiles/r06_gemm_w4.md: 3.699 vs 3.633 ms on the harness) — the
+// slot time is not the DMA round trip divided by the ring depth.  The loop below is written for
+// either; the waits for 5 are kept beside those for 4.
+constexpr int GL4_RING = 4;
+// MFMA pairs at the end of a k-step with nothing issued behind them (they cover the last fragment
+// reads' LDS latency): 1 / 2 / 3 measured, 3.607 / 3.653 / 3.645 ms.
+constexpr int GL4_COVER = 1;
 constexpr int GL4_LDS_BYTES = GL4_RING * GL_SLOT_BYTES;
 
 template <int IM, int JN> struct Gl4Frags { bf16x8 n[JN], m[IM]; };
@@ -135,9 +136,6 @@ __device__ __forceinline__ void gl4_mainloop(const GemmOperand& A, const GemmOpe
   static_assert(NM % 2 == 0, "pairs");
   // k-step 0: reads spread over the gaps behind pairs 0 .. R0-1 — the last GL4_COVER pairs have
   // nothing behind them: their 64 clk each cover the last reads' LDS latency
-#ifndef GL4_COVER
-#define GL4_COVER 1
-#endif
   constexpr int R0 = P - GL4_COVER;
   // k-step 1: pair 0 goes ahead of the barrier; DMA pieces and reads spread over the gaps IN FRONT
   // of pairs 1 .. R1

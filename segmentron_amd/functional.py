@@ -1291,14 +1291,56 @@ def channel_attention(x, gamma):
 _NO_FOLD = os.environ.get("SEG_NO_FOLD") == "1"
 
 
+class _GroupNormFn(torch.autograd.Function):
+    """nn.GroupNorm on a plain NHWC tensor (csrc/groupnorm.hip; the reference's `GN` norm layer,
+    /root/reference/segmentron/modules/batch_norm.py:105-108: nn.GroupNorm(min(32, C), C)).
+    Group statistics are per sample, so the layer is materialised: it returns the normalised
+    tensor, not a pending per-channel affine."""
+
+    @staticmethod
+    def forward(ctx, y, weight, bias, groups, eps, out):
+        N, H, W, C = y.shape
+        mean_rstd, coef = K.gn_fwd_finalize(K.gn_moments(y), H * W, groups, weight, bias, eps)
+        ctx.save_for_backward(y, weight, mean_rstd)
+        ctx.groups, ctx.has_bias = groups, bias is not None
+        return K.gn_affine(y, None, coef, out=out)  # (`out`: a channel slice of a concat buffer)
+
+    @staticmethod
+    def backward(ctx, dz):
+        y, weight, mean_rstd = ctx.saved_tensors
+        N, H, W, C = y.shape
+        if dz.dtype != y.dtype:
+            dz = dz.to(y.dtype)
+        coef, contrib = K.gn_bwd_finalize(K.gn_moments(dz, y), H * W, ctx.groups, mean_rstd, weight)
+        dx = K.gn_affine(dz, y, coef) if ctx.needs_input_grad[0] else None
+        dw = db = None
+        if weight is not None and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]):
+            sums = K.colsum(contrib.view(N, 2 * C), f64=False)
+            dw = sums[:C].to(weight.dtype) if ctx.needs_input_grad[1] else None
+            db = sums[C:].to(weight.dtype) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return dx, dw, db, None, None, None
+
+
+def is_group_norm(norm):
+    return isinstance(norm, torch.nn.GroupNorm)
+
+
+def group_norm(y, gn, out=None):
+    """-> Act(GroupNorm(y)): plain (nothing pending)."""
+    return Act(_GroupNormFn.apply(y, gn.weight, gn.bias, gn.num_groups, gn.eps, out))
+
+
 def conv_bn(act, conv, bn=None, out=None, fork=None):
     """conv (nn.Conv2d, groups=1) [+ BatchNorm statistics].  Returns an Act whose BN (if any) and
     ReLU are pending; caller sets ``.relu``.  `fork`: see GradFork (the input is a forked plain
     activation whose other consumer parks its gradient for this conv's data-gradient GEMM)."""
     x = act.t
+    gn = bn if is_group_norm(bn) else None
+    if gn is not None:  # the conv keeps its bias and takes no statistics; see _GroupNormFn
+        bn = None
     batch_stats = bn is not None and uses_batch_stats(bn)
-    spec = ConvSpec(act, conv.stride[0], conv.padding[0], conv.dilation[0], out,
-                    want_stats=batch_stats)
+    spec = ConvSpec(act, conv.stride[0], conv.padding[0], conv.dilation[0],
+                    None if gn is not None else out, want_stats=batch_stats)
     g, b = act.params
     foldable = (act.bn is not None and not act.relu and conv.kernel_size == (1, 1)
                 and conv.padding[0] == 0 and conv.bias is None and not _NO_FOLD)
@@ -1320,6 +1362,8 @@ def conv_bn(act, conv, bn=None, out=None, fork=None):
         spec.fork = fork
         y = _ConvFn.apply(x, g, b, conv.weight, conv.bias, spec)
         offset = conv.bias.detach() if spec.drop_bias else None
+    if gn is not None:
+        return group_norm(y, gn, out)
     if bn is None:
         return Act(y)
     N, Ho, Wo, _ = y.shape
@@ -1327,12 +1371,16 @@ def conv_bn(act, conv, bn=None, out=None, fork=None):
 
 
 def dwconv_bn(act, conv, bn, out=None, fork=None):
-    spec = ConvSpec(act, conv.stride[0], conv.padding[0], conv.dilation[0], out,
-                    want_stats=uses_batch_stats(bn))
+    gn = bn if is_group_norm(bn) else None
+    spec = ConvSpec(act, conv.stride[0], conv.padding[0], conv.dilation[0],
+                    None if gn is not None else out,
+                    want_stats=gn is None and uses_batch_stats(bn))
     spec.fork = fork
     assert conv.padding[0] == conv.dilation[0] and conv.kernel_size[0] == 3
     g, b = act.params
     y = _DwFn.apply(act.t, g, b, conv.weight, spec)
+    if gn is not None:
+        return group_norm(y, gn, out)
     N, Ho, Wo, _ = y.shape
     return Act(y, finish_bn(bn, spec.partial, N * Ho * Wo, y=y))
 

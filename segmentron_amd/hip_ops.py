@@ -135,6 +135,54 @@ def colsum(partial2d, f64=True):
     return out
 
 
+# ---- nn.GroupNorm (csrc/groupnorm.hip) ----------------------------------------------------------
+def gn_moments(u, v=None):
+    """NHWC u (, v) -> fp32 [N, chunks, 2, C]: (sum u, sum u*v) per sample, pixel chunk and channel
+    (v None: sum u, sum u^2)."""
+    N, H, W, C, ldu = nhwc(u)
+    ldv = 0
+    if v is not None:
+        assert tuple(v.shape) == tuple(u.shape) and v.dtype == u.dtype
+        ldv = nhwc(v)[4]
+    chunks = LIB.query("seg_gn_chunks", H * W)
+    partial = torch.empty((N, chunks, 2, C), dtype=torch.float32, device=u.device)
+    LIB.call("seg_gn_moments", _DT[u.dtype], _p(u), ldu, _p(v), ldv, N, H * W, C, _p(partial),
+             _stream())
+    return partial
+
+
+def gn_fwd_finalize(partial, HW, G, gamma, beta, eps):
+    """-> (mean_rstd fp32 [N, G, 2], coef fp32 [N, 3, C]) with z = coef[n,0,c]*x + coef[n,2,c]."""
+    N, _, _, C = partial.shape
+    mean_rstd = torch.empty((N, G, 2), dtype=torch.float32, device=partial.device)
+    coef = torch.empty((N, 3, C), dtype=torch.float32, device=partial.device)
+    LIB.call("seg_gn_fwd_finalize", _p(partial), N, HW, C, G, _p(gamma), _p(beta), float(eps),
+             _p(mean_rstd), _p(coef), _stream())
+    return mean_rstd, coef
+
+
+def gn_bwd_finalize(partial, HW, G, mean_rstd, gamma):
+    """moments of (dz, x) -> (coef [N, 3, C] of dx = k1*dz + k2*x + k3, contrib [N, 2, C]: the
+    per-sample terms of dgamma | dbeta)."""
+    N, _, _, C = partial.shape
+    coef = torch.empty((N, 3, C), dtype=torch.float32, device=partial.device)
+    contrib = torch.empty((N, 2, C), dtype=torch.float32, device=partial.device)
+    LIB.call("seg_gn_bwd_finalize", _p(partial), N, HW, C, G, _p(mean_rstd), _p(gamma), _p(coef),
+             _p(contrib), _stream())
+    return coef, contrib
+
+
+def gn_affine(u, v, coef, out=None):
+    """out = coef[n,0,c]*u + coef[n,1,c]*v + coef[n,2,c]  (v may be None)."""
+    N, H, W, C, ldu = nhwc(u)
+    ldv = 0 if v is None else nhwc(v)[4]
+    if out is None:
+        out = torch.empty((N, H, W, C), dtype=u.dtype, device=u.device)
+    LIB.call("seg_gn_affine", _DT[u.dtype], _p(u), ldu, _p(v), ldv, _p(coef), _p(out),
+             nhwc(out)[4], N, H * W, C, _stream())
+    return out
+
+
 def colsum_count(partial2d, count):
     """partial2d fp32 [R, L] -> float64 [L + 1] = (column sums | count): the SyncBatchNorm
     forward message of one BatchNorm in one launch."""

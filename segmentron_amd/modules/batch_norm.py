@@ -86,16 +86,19 @@ class FrozenBatchNorm2d(nn.Module):
         return res
 
 
+def groupNorm(num_channels, eps=1e-5, momentum=0.1, affine=True):
+    """The reference's `GN` factory (batch_norm.py:105-108): nn.GroupNorm(min(32, C), C).
+    Served by csrc/groupnorm.hip through functional.conv_bn / dwconv_bn (materialised: group
+    statistics are per sample)."""
+    return nn.GroupNorm(min(32, num_channels), num_channels, eps=eps, affine=affine)
+
+
 def get_norm(norm):
-    support = ["BN", "SyncBN", "nnSyncBN", "FrozenBN"]
-    unsupported = ["GN"]
+    support = ["BN", "SyncBN", "nnSyncBN", "FrozenBN", "GN"]
     if isinstance(norm, str):
-        if norm in unsupported:
-            raise NotImplementedError(
-                "BN_TYPE %r is outside the MI355X hot path (only %s are served by HIP kernels)"
-                % (norm, support))
         assert norm in support, "Unknown norm type {}, support norm types are {}".format(
-            norm, support + unsupported)
+            norm, support)
         return {"BN": nn.BatchNorm2d, "SyncBN": NaiveSyncBatchNorm,
-                "nnSyncBN": nn.SyncBatchNorm, "FrozenBN": FrozenBatchNorm2d}[norm]
+                "nnSyncBN": nn.SyncBatchNorm, "FrozenBN": FrozenBatchNorm2d,
+                "GN": groupNorm}[norm]
     return norm

@@ -307,14 +307,19 @@ def test_kernel_selection_queries_of_the_c_library():
 
 def test_frozen_batchnorm_module_contract():
     """get_norm('FrozenBN') — segmentron/modules/batch_norm.py:10-104,107-132: four BUFFERS, the
-    reference's state_dict keys, its version-3 loading rule, convert_frozen_batchnorm; 'GN' stays
-    outside the hot path."""
+    reference's state_dict keys, its version-3 loading rule, convert_frozen_batchnorm; 'GN'
+    (batch_norm.py:105-108,129) builds nn.GroupNorm(min(32, C), C) with the reference's state_dict
+    keys (r06: served by csrc/groupnorm.hip)."""
     import pytest
     from segmentron_amd import functional as F
     from segmentron_amd.modules.batch_norm import FrozenBatchNorm2d, get_norm
     assert get_norm("FrozenBN") is FrozenBatchNorm2d
-    with pytest.raises(NotImplementedError):
-        get_norm("GN")
+    gn = get_norm("GN")(256)
+    assert isinstance(gn, torch.nn.GroupNorm) and gn.num_groups == 32 and gn.eps == 1e-5 and gn.affine
+    assert get_norm("GN")(16).num_groups == 16 and F.is_group_norm(gn)
+    assert list(gn.state_dict().keys()) == ["weight", "bias"]
+    with pytest.raises(AssertionError):
+        get_norm("LN")
     m = FrozenBatchNorm2d(6, eps=1e-3)
     assert list(m.state_dict().keys()) == ["weight", "bias", "running_mean", "running_var"]
     assert not list(m.parameters()) and not F.uses_batch_stats(m.train())

@@ -739,6 +739,45 @@ def test_fold_linear_bn_into_pointwise_matches_autograd(dtype):
     assert_close(to_cpu_nchw(dx), xr.grad, dtype, "folded dx", fac=3)
 
 
+# ------------------------------------------------------------------------------ GroupNorm
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+@pytest.mark.parametrize("geom", [(2, 17, 23, 64), (3, 6, 6, 512), (2, 1, 1, 2048),
+                                  (1, 65, 129, 256), (2, 33, 35, 24)])
+def test_group_norm_fwd_bwd_matches_torch(geom, dtype):
+    """nn.GroupNorm(min(32, C), C) — the reference's 'GN' norm layer (modules/batch_norm.py:
+    105-108) — forward, dx, dgamma, dbeta against torch in float64: 2 .. 64 channels per group,
+    one channel per group (C = 24), a 1 x 1 map (statistics over the group's channels only), the
+    PSP pyramid bins; also written into a channel slice of a wider buffer."""
+    N, H, W, C = geom
+    gn = torch.nn.GroupNorm(min(32, C), C).to(DEV)
+    with torch.no_grad():
+        gn.weight.copy_(torch.rand(C, generator=torch.Generator().manual_seed(3)) + 0.5)
+        gn.bias.copy_(rnd((C,), 4, 0.3))
+    x = quant(rnd((N, C, H, W), 1) * 1.5 + 0.4, dtype)
+    dz = quant(rnd((N, C, H, W), 2), dtype)
+    xr = x.double().requires_grad_()
+    wr, br = gn.weight.detach().cpu().double().requires_grad_(), gn.bias.detach().cpu().double().requires_grad_()
+    ref = TF.group_norm(xr, gn.num_groups, wr, br, gn.eps)
+    ref.backward(dz.double())
+    xd = to_dev_nhwc(x, dtype).requires_grad_()
+    z = F().group_norm(xd, gn).t
+    z.backward(to_dev_nhwc(dz, dtype))
+    assert_close(to_cpu_nchw(z.detach()), ref.detach(), dtype, "gn z", fac=2)
+    assert_close(to_cpu_nchw(xd.grad), xr.grad, dtype, "gn dx", fac=4)
+    scale = (dz.double().abs() * ((x.double() - x.double().mean()) / x.double().std()).abs()).sum((0, 2, 3)).max().item()
+    assert_close(gn.weight.grad.cpu(), wr.grad, torch.float32, "gn dgamma", scale=scale, fac=20)
+    assert_close(gn.bias.grad.cpu(), br.grad, torch.float32, "gn dbeta",
+                 scale=dz.double().abs().sum((0, 2, 3)).max().item(), fac=20)
+    # into a channel slice of a concat buffer (functional.conv_bn(out=...))
+    vec = 8 if dtype == torch.bfloat16 else 4
+    buf = torch.full((N, H, W, C + 2 * vec), float("nan"), dtype=dtype, device=DEV)
+    with torch.no_grad():
+        z2 = F().group_norm(xd.detach(), gn, out=buf[..., vec:vec + C]).t
+    assert z2.data_ptr() == buf[..., vec:vec + C].data_ptr()
+    assert torch.equal(z2, z.detach()) and torch.isnan(buf[..., :vec].float()).all() \
+        and torch.isnan(buf[..., vec + C:].float()).all()
+
+
 # ------------------------------------------------------------------------------ pooling / misc
 @pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
 def test_maxpool_fwd_bwd(dtype):

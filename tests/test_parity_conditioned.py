@@ -71,6 +71,8 @@ BF16_MEASURED_LARGE = {
     "c4_1025x2049": dict(logits_l2=1.364e-2, argmax=0.9950, cos=0.99993, loss_rel=8.79e-5),
     # C3 + auxiliary head at 65 x 129, seed 3 (9 x 17 maps: the noisiest geometry of the suite)
     "c3_aux_65x129": dict(logits_l2=1.796e-2, cos=0.97958),
+    # PSPNet / resnet50 with GroupNorm in the encoder, 65 x 97, seed 5
+    "pspnet_gn_65x97": dict(logits_l2=4.303e-2, cos=0.99484),
 }
 
 
@@ -552,6 +554,61 @@ def test_c3_with_auxiliary_head_182_hidden_channels_matches_oracle():
     print("PARITY-COND c3 + aux head bf16: logits L2-rel %.3e gradient cosine %.5f"
           % (b16["logits_l2rel"], b16["grad_cosine"]))
     assert b16["finite"] and b16["grad_tensors_missing"] == 0
+    assert b16["logits_l2rel"] <= 1.3 * m["logits_l2"], (b16["logits_l2rel"], m)
+    assert 1.0 - b16["grad_cosine"] <= 1.3 * (1.0 - m["cos"]) + 2e-5, (b16["grad_cosine"], m)
+    reset_cfg()
+
+
+@pytest.mark.gpu
+def test_pspnet_resnet50_with_group_norm_matches_oracle():
+    """cfg.MODEL.BN_TYPE 'GN' (VERDICT r05 Missing #3): the reference maps it to
+    nn.GroupNorm(min(32, C), C) in every norm_layer slot (/root/reference/segmentron/modules/
+    batch_norm.py:105-108,129; models/segbase.py:23) — PSPNet / resnet50 (every width divisible
+    by 32; xception's 728 channels are not: torch itself refuses GroupNorm(32, 728)), output
+    stride 8, auxiliary head, the pyramid bins' 1 x 1 .. 6 x 6 maps.  One train step at 65 x 97
+    against the float64 oracle (F.group_norm): fp32 kernels 1e-3 on loss, logits and the global
+    gradient; bf16: finite, logits L2-rel / gradient cosine recorded bars."""
+    import segmentron_amd
+    from segmentron_amd.config import cfg, reset_cfg
+    from oracle import parity as OP
+    reset_cfg()
+    cfg.update_from_list(["DATASET.NAME", "cityscape", "MODEL.MODEL_NAME", "PSPNet",
+                          "MODEL.BACKBONE", "resnet50", "MODEL.OUTPUT_STRIDE", "8",
+                          "MODEL.BN_TYPE", "GN", "SOLVER.AUX", "True", "SOLVER.AUX_WEIGHT",
+                          str(AUX_WEIGHT), "TRAIN.BACKBONE_PRETRAINED", "False"])
+    cfg.PHASE = "test"
+    cfg.check_and_freeze()
+    segmentron_amd.set_compute_dtype(torch.float32)
+    model = segmentron_amd.get_segmentation_model()
+    gns = [n for n, m in model.named_modules() if isinstance(m, torch.nn.GroupNorm)]
+    # (as in the reference, whose PSPNet builds _PSPHead / _FCNHead without norm_layer —
+    # pspnet.py:23-25 — the heads keep BatchNorm2d: 53 GroupNorms in the encoder, 6 BatchNorms)
+    bns = [n for n, m in model.named_modules() if isinstance(m, torch.nn.BatchNorm2d)]
+    assert len(gns) == 53 and all(n.startswith("encoder.") for n in gns)
+    assert len(bns) == 6 and not any(n.startswith("encoder.") for n in bns)
+    state = model.state_dict()
+    # the conditioned state's rules key on BatchNorm buffers (oracle/synth.py): name them for the
+    # GroupNorm affines so that they get the same treatment (small gamma on the last norm of a
+    # residual branch, beta = +2 gamma elsewhere)
+    names = set(state) | set(n + ".running_mean" for n in gns)
+    sd = {k: synth.synth_tensor(k, tuple(v.shape), seed=5, conditioned=True, all_keys=names)
+          for k, v in state.items()}
+    del model
+    H, W = 65, 97
+    x, y = OP.inputs(2, H, W, seed=5)
+    ref = OP.oracle_step(sd, x, y, torch.float64, oracle_fn="pspnet_resnet", output_stride=8,
+                         aux=True, eps_encoder=None, norm="GN")
+    f32 = OP.compare(OP.hip_step("fp32", sd, x, y, eps_encoder=None), ref)
+    b16 = OP.compare(OP.hip_step("bf16", sd, x, y, eps_encoder=None), ref)
+    print("PARITY-COND PSPNet/resnet50 GroupNorm %dx%d: fp32 loss rel %.2e logits max-rel %.2e "
+          "gradients global rel %.2e | bf16 logits L2-rel %.3e gradient cosine %.5f"
+          % (H, W, f32["loss_rel"], f32["logits_maxrel"], f32["grad_global_rel"],
+             b16["logits_l2rel"], b16["grad_cosine"]))
+    assert f32["finite"] and f32["grad_tensors_missing"] == 0
+    assert f32["loss_rel"] < 1e-3 and f32["logits_maxrel"] < 1e-3 and f32["grad_global_rel"] <= 1e-3
+    _assert_fp32_argmax(f32, "PSPNet GroupNorm")
+    assert b16["finite"] and b16["grad_tensors_missing"] == 0
+    m = BF16_MEASURED_LARGE["pspnet_gn_65x97"]  # (1.3 x measured, see BF16_MEASURED)
     assert b16["logits_l2rel"] <= 1.3 * m["logits_l2"], (b16["logits_l2rel"], m)
     assert 1.0 - b16["grad_cosine"] <= 1.3 * (1.0 - m["cos"]) + 2e-5, (b16["grad_cosine"], m)
     reset_cfg()

@@ -63,9 +63,11 @@ def main():
             g[2] += db
     print("all kernels: %.3f -> %.3f ms per step" % (ta * 1e-3, tb * 1e-3))
     sa = sb = 0.0
-    for k, (n, da, db) in sorted(groups.items(), key=lambda kv: -kv[1][1]):
+    for rank, (k, (n, da, db)) in enumerate(sorted(groups.items(), key=lambda kv: -kv[1][1])):
         sa += da
         sb += db
+        if rank >= int(__import__("os").environ.get("TRACE_AB_TOP", "1000")):
+            continue
         print("%3d x  %-52s grid %-8s %8.2f us  ->  %-52s grid %-8s %8.2f us  (%+.1f %%)"
               % (n, k[0], k[1], da / n, k[2], k[3], db / n, (db / da - 1) * 100))
     print("matching launches: %.3f -> %.3f ms per step" % (sa * 1e-3, sb * 1e-3))
