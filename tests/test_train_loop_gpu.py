@@ -183,7 +183,7 @@ def test_evaluate_graph_mode_equals_eager_bit_for_bit():
     assert not torch.equal(a[0], a[1])
 
 
-def _train_validate_train(tag, graph, hw, epochs=2, iters=4):
+def _train_validate_train(tag, graph, hw, epochs=2, iters=4, builder=None):
     """tools/train.py's epoch structure: `iters` loop iterations, then `validation()`
     (train.py:173-199: model.eval(), `model(image)[0]` under no_grad per sample), `model.train()`,
     and on."""
@@ -195,7 +195,7 @@ def _train_validate_train(tag, graph, hw, epochs=2, iters=4):
     prev = os.environ.get("SEGMENTRON_HIP_GRAPH")
     os.environ["SEGMENTRON_HIP_GRAPH"] = "1" if graph else "0"
     try:
-        model, _ = MM._build_hip(tag, torch.bfloat16, True)
+        model = builder() if builder is not None else MM._build_hip(tag, torch.bfloat16, True)[0]
         tg = getattr(model, "_transparent_graph", None)
         assert (tg is not None) == graph
         criterion = MixSoftmaxCrossEntropyLoss(aux=True, aux_weight=0.4, ignore_index=-1).cuda()
@@ -262,3 +262,40 @@ def test_train_validate_train_graph_mode_equals_eager_bit_for_bit(tag):
     bad = [k for k in se if not torch.equal(se[k], sg[k])]
     assert not bad, bad[:5]
     assert not torch.equal(ve[0], ve[3])  # the second epoch validates an updated model
+
+
+def _build_pspnet_group_norm():
+    """PSPNet / resnet50, cfg.MODEL.BN_TYPE 'GN' (GroupNorm in the encoder, BatchNorm in the
+    heads as in the reference), auxiliary head, bf16, conditioned synthetic state."""
+    import segmentron_amd
+    from segmentron_amd.config import cfg, reset_cfg
+    reset_cfg()
+    cfg.update_from_list(["DATASET.NAME", "cityscape", "MODEL.MODEL_NAME", "PSPNet",
+                          "MODEL.BACKBONE", "resnet50", "MODEL.OUTPUT_STRIDE", "8",
+                          "MODEL.BN_TYPE", "GN", "SOLVER.AUX", "True", "SOLVER.LR", "0.002",
+                          "TRAIN.BACKBONE_PRETRAINED", "False"])
+    cfg.PHASE = "train"
+    cfg.check_and_freeze()
+    segmentron_amd.set_compute_dtype(torch.bfloat16)
+    model = segmentron_amd.get_segmentation_model()
+    model.load_state_dict(synth.synth_like(model.state_dict(), seed=2, conditioned=True))
+    model = model.cuda().train()
+    for m in model.modules():
+        if isinstance(m, (nn.Dropout, nn.Dropout2d)):
+            m.p = 0.0
+    return model
+
+
+def test_group_norm_model_graph_mode_equals_eager_bit_for_bit():
+    """The GroupNorm kernels (csrc/groupnorm.hip: moments / finalize / affine, both directions) are
+    capture-safe: the train / validate / train structure of tools/train.py on PSPNet-resnet50 with
+    BN_TYPE 'GN' under SEGMENTRON_HIP_GRAPH=1 equals eager launches bit for bit."""
+    hw = (65, 97)
+    le, ve, se = _train_validate_train("gn", False, hw, epochs=2, iters=3, builder=_build_pspnet_group_norm)
+    lg, vg, sg = _train_validate_train("gn", True, hw, epochs=2, iters=3, builder=_build_pspnet_group_norm)
+    assert le == lg, (le, lg)
+    assert all(l == l and abs(l) < 1e4 for l in le), le
+    for i, (a, b) in enumerate(zip(ve, vg)):
+        assert torch.equal(a, b), ("validation output", i)
+    bad = [k for k in se if not torch.equal(se[k], sg[k])]
+    assert not bad, bad[:5]
