@@ -375,7 +375,10 @@ def _eval_versions(bn):
     return tuple(-1 if t is None else t._version for t in ts) \
         + tuple(0 if t is None else t.data_ptr() for t in ts) \
         + tuple(0 if t is None else id(t) for t in ts) \
-        + (float(bn.eps), _STATS_EPOCH[0])
+        + (float(bn.eps), 0 if getattr(bn, "frozen", False) else _STATS_EPOCH[0])
+    # (a FrozenBatchNorm2d's statistics are never written by a training replay: leaving the epoch
+    # out of ITS key keeps a frozen backbone's affines cached while the head's BatchNorms train —
+    # with it every training finish_bn invalidated them all, O(n^2) recomputations)
 
 
 def eval_affine(bn):

@@ -166,7 +166,9 @@ class _GraphedSegment(torch.autograd.Function):
             # gradients over several backward calls (or scaled / clipped / zeroed them in place —
             # a version counter cannot tell these apart, so nothing is inferred from it): keep
             # the current values, the replay overwrites the buffers, add them back.  The
-            # reference's loop (zero_grad() -> set_to_none) never takes this path.
+            # reference's loop (zero_grad() -> set_to_none) never takes this path: it is the
+            # fast path; a loop on zero_grad(set_to_none=False) pays a full-model gradient clone
+            # and a foreach_add per step here.
             held = [g for p, g in zip(seg.params, seg.grads) if g is not None and p.grad is g]
             old = [g.clone() for g in held]
             seg.bwd.replay()
@@ -371,8 +373,10 @@ class TransparentTrainGraph:
                 grads = torch.autograd.grad(seg.lo, leaves, seg.grad_lo, allow_unused=True)
             # (a .contiguous() copy taken here would NOT be a node of the graph: replays would
             # never refresh it)
-            if any(g is not None and not g.is_contiguous() for g in grads):
-                raise RuntimeError("transparent capture needs contiguous parameter gradients")
+            ragged = [n for (n, _), g in zip(named, grads) if g is not None and not g.is_contiguous()]
+            if ragged:  # (named: the eager fallback this triggers must be diagnosable)
+                raise RuntimeError("transparent capture needs contiguous parameter gradients; "
+                                   "not contiguous: " + ", ".join(ragged[:4]))
             seg.grads = list(grads)
             torch.cuda.synchronize()
         finally:  # (ids of dead aliases would be recycled by unrelated tensors)
