@@ -21,8 +21,15 @@ def steps(path):
         grid = r.get("Grid_Size") or r.get("Grid_Size_X") or "?"
         ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), n, grid))
     ev.sort()
-    # a step = the dispatches between two ce_fwd_kernel launches; keep the most common length
-    cuts = [i for i, e in enumerate(ev) if "ce_fwd_kernel" in e[2]]
+    # a step = the dispatches between two "first ce_fwd_kernel launches after an optimizer launch"
+    # (models with auxiliary heads run several loss kernels per step); keep the most common length
+    cuts, seen_opt = [], True
+    for i, e in enumerate(ev):
+        if "sgd_multi_tensor_kernel" in e[2]:
+            seen_opt = True
+        elif "ce_fwd_kernel" in e[2] and seen_opt:
+            cuts.append(i)
+            seen_opt = False
     segs = [ev[a:b] for a, b in zip(cuts[:-1], cuts[1:])]
     lens = defaultdict(int)
     for s in segs:
