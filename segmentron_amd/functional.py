@@ -1314,6 +1314,10 @@ class _GroupNormFn(torch.autograd.Function):
         N, H, W, C = y.shape
         if dz.dtype != y.dtype:
             dz = dz.to(y.dtype)
+        # (a channel slice of a concat gradient is fine as long as its pitch and start keep the
+        # 16-byte vectors whole; anything else — a broadcast, an odd pitch — is copied once)
+        if not _sum_n_operand_ok(dz, K.vec_of(y.dtype)):
+            dz = dz.contiguous()
         coef, contrib = K.gn_bwd_finalize(K.gn_moments(dz, y), H * W, ctx.groups, mean_rstd, weight)
         dx = K.gn_affine(dz, y, coef) if ctx.needs_input_grad[0] else None
         dw = db = None
