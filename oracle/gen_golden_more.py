@@ -6,6 +6,7 @@
     python oracle/gen_golden_more.py c2     # DeepLabv3+ mobilenet_v2        -> tests/golden/c2_*
     python oracle/gen_golden_more.py c5     # HRNet hrnet_w18_small_v1       -> tests/golden/c5_*
     python oracle/gen_golden_more.py c6     # CCNet resnet101 (stubbed _C)   -> tests/golden/c6_*
+    python oracle/gen_golden_more.py c9     # PSPNet resnet50, BN_TYPE GN    -> tests/golden/c9_*
 
 One process per model (the reference cfg singleton freezes).  C1 / C4 use resnet101, the
 backbone BASELINE.md names (BASELINE C1 as written, "FCN-resnet18", cannot run in the reference:
@@ -33,6 +34,12 @@ CASES = {
                fn="fcn_resnet", os=16, aux=False, hw=(65, 97), eps_enc=None),
     "c4": dict(yaml="configs/cityscapes_pspnet_resnet.yaml", over=["MODEL.BACKBONE", "resnet101"],
                fn="pspnet_resnet", os=8, aux=True, hw=(49, 65), eps_enc=None),
+    # cfg.MODEL.BN_TYPE 'GN' (modules/batch_norm.py:105-108,129): GroupNorm(min(32, C), C) in the
+    # encoder; the reference's PSPNet builds its heads without norm_layer (pspnet.py:23-25), so they
+    # keep BatchNorm2d.  resnet50: every width divisible by 32
+    "c9": dict(yaml="configs/cityscapes_pspnet_resnet.yaml",
+               over=["MODEL.BACKBONE", "resnet50", "MODEL.BN_TYPE", "GN"],
+               fn="pspnet_resnet", os=8, aux=True, hw=(49, 65), eps_enc=None, norm="GN"),
     "c2": dict(yaml="configs/cityscapes_deeplabv3_plus_mobilenet.yaml", over=[],
                fn="deeplab_mobilenet", os=16, aux=False, hw=(65, 97), eps_enc=None),
     # HRNet needs H, W divisible by 32 (nearest x2 upsamples must meet the stride-2 conv sizes)
@@ -130,7 +137,8 @@ def main(tag):
     model.load_state_dict(sd, strict=True)
 
     kw = dict(output_stride=c["os"], aux=c["aux"], eps_encoder=c["eps_enc"], drop_p=0.0,
-              momentum=c.get("mom"), multi_dilation=c.get("multi_dilation"))
+              momentum=c.get("mom"), multi_dilation=c.get("multi_dilation"),
+              norm=c.get("norm", "BN"))
     model.eval()
     with torch.no_grad():
         outs = model(x)

@@ -34,6 +34,12 @@ CASES = {
     "c8": dict(model="DANet", backbone="resnet101", os=8, aux=False, fn="danet_resnet",
                hw=(49, 65), aux_weight=0.4, nout=3, multi_dilation=[4, 8, 16],
                over=["MODEL.DANET.MULTI_GRID", "True", "MODEL.DANET.MULTI_DILATION", "[4, 8, 16]"]),
+    # cfg.MODEL.BN_TYPE 'GN' (r06; modules/batch_norm.py:105-108,129): GroupNorm(min(32, C), C) in
+    # the encoder, BatchNorm2d in the heads (the reference builds them without norm_layer,
+    # pspnet.py:23-25); fixtures from the reference itself (oracle/gen_golden_more.py c9)
+    "c9": dict(model="PSPNet", backbone="resnet50", os=8, aux=True, fn="pspnet_resnet",
+               hw=(49, 65), aux_weight=0.4, over=["MODEL.BN_TYPE", "GN"], norm="GN",
+               tie_delta=1e-5),
     # Fast-SCNN (SURVEY §8 f4 tail; configs/cityscapes_fast_scnn.yaml: AUX True, BN momentum 0.01)
     "c7": dict(model="FastSCNN", backbone="", os=16, aux=True, fn="fast_scnn", hw=(192, 192),
                aux_weight=0.4, momentum=0.01, tie_delta=1e-5),
@@ -106,7 +112,8 @@ def _oracle_impl(tag, sd, x, training, dtype=torch.float32, y=None):
     s = {k: (v.to(dtype) if v.is_floating_point() else v.clone()) for k, v in sd.items()}
     s = torch_ref.clone_state(s, requires_grad=training)
     net = torch_ref.OracleNet(s, training=training, output_stride=c["os"], aux=c["aux"], drop_p=0.0,
-                              momentum=c.get("momentum"), multi_dilation=c.get("multi_dilation"))
+                              momentum=c.get("momentum"), multi_dilation=c.get("multi_dilation"),
+                              norm=c.get("norm", "BN"))
     outs = getattr(net, c["fn"])(x.to(dtype))
     if not training:
         return outs, None, None
